@@ -1,0 +1,885 @@
+/*
+ * saip_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked, imported or called by the product).
+ *
+ * Plain-C, single-robot, FP64 restatement of the reference's per-cycle control path, written to
+ * follow the reference line by line (literal path: SVDs, explicit general inverses, duplicated
+ * Jacobian/FK evaluation, per-cycle joint-limit-avoidance model update), so that it can serve as
+ *   (1) the parity oracle the HIP engine is compared with in tests/ and __graft_entry__.smoke(), and
+ *   (2) the "port" CPU baseline timed by bench.py's cpu_baseline leg.
+ *
+ * Reference lines followed (all under /root/reference/src):
+ *   RobotController.cpp:68-118                 -> orc_instance_cycle()
+ *   tasks/MotionForceTask.cpp:247-268          -> mf_update_task_model()
+ *   tasks/MotionForceTask.cpp:270-509,892-971  -> mf_compute_torques()
+ *   tasks/SingularityHandler.cpp:75-228        -> sh_update_task_model()   (non-singular branch; others flagged)
+ *   tasks/SingularityHandler.cpp:297-309       -> sh_compute_torques()
+ *   tasks/JointTask.cpp:218-283, 285-356       -> jt_update_task_model(), jt_compute_torques()
+ *   tasks/JointLimitAvoidanceTask.cpp:124-252  -> jla_update_task_model()
+ *   tasks/MotionForceTask.cpp:28,55-87,143-168 -> orc_add_motion_force_task() (partial task projector)
+ * sai-model / RBDL / Eigen are NOT in /root/reference (un-vendored, unpinned @master dependency);
+ * their semantics are restated from the algebraic definitions of SURVEY.md Appendix B:
+ *   M(q) (here: sum over bodies of Jacobian-form kinetic energy, equal to CRBA), M^-1 (general inverse),
+ *   JWorldFrame = [Jv;Jw], positionInWorld/rotationInWorld, operationalSpaceMatrices
+ *   (Lambda=(J M^-1 J^T)^-1, Jbar=M^-1 J^T Lambda, N=I-Jbar J), matrixRangeBasis (SVD, tol 1e-3),
+ *   orientationError(Rd,Rc) = -1/2 sum_i Rc[:,i] x Rd[:,i].
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
+ * built here (Eigen3, sai-model, RBDL absent).  This oracle is pinned only by (i) the analytic invariants
+ * of SURVEY.md Appendix E (tests/test_oracle_invariants.py) and (ii) agreement <=1e-10 with the independent
+ * NumPy restatement in workloads.py (tests/golden/, tests/test_oracle_vs_numpy.py).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXN 32  /* max dof */
+#define MAXL 40  /* max links incl. fixed */
+#define MAXT 8   /* max tasks */
+
+enum { JT_FIXED = 0, JT_REVOLUTE = 1, JT_PRISMATIC = 2 };
+enum { TASK_MOTION_FORCE = 1, TASK_JOINT = 2 };
+enum { FULL_DYNAMIC_DECOUPLING = 0, BOUNDED_INERTIA_ESTIMATES = 1, IMPEDANCE = 2 };
+enum { ST_OK = 0, ST_SINGULAR = 1 };
+
+typedef struct {
+	int type;
+	double dt;
+	int decoupling;
+	double bie_threshold;
+	/* motion force */
+	int link;
+	double pos_in_link[3], rot_in_link[9];
+	double P[36];          /* _partial_task_projection */
+	int pos_range, ori_range;
+	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
+	double s_min, s_max, s_abs_tol;
+	/* joint */
+	int m;
+	double S[MAXN * MAXN]; /* m x n row-major */
+	double kp[MAXN], kv[MAXN], ki[MAXN];
+} orc_task;
+
+typedef struct {
+	int nl, n;
+	int joint_type[MAXL], dof_of_link[MAXL];
+	double R0[MAXL][9], p0[MAXL][3], axis[MAXL][3];
+	double mass[MAXL], com[MAXL][3], inertia[MAXL][9];
+	double q_lo[MAXN], q_hi[MAXN], vel[MAXN], effort[MAXN];
+	int nt;
+	orc_task task[MAXT];
+	int gravity_comp, jla_enabled, torque_sat;
+	double gravity[3];
+	/* per-instance integrator state (lazily sized) */
+	int state_B;
+	double* integ; /* [B][MAXT][MAXN] (motion force uses 6) */
+} orc_ctx;
+
+/* ------------------------------------------------------------------ small dense helpers (row-major) */
+static void mm(const double* A, const double* B, double* C, int m, int k, int p) {
+	for (int i = 0; i < m; i++)
+		for (int j = 0; j < p; j++) {
+			double s = 0;
+			for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * p + j];
+			C[i * p + j] = s;
+		}
+}
+static void mmT(const double* A, const double* B, double* C, int m, int k, int p) { /* C = A * B^T, B is p x k */
+	for (int i = 0; i < m; i++)
+		for (int j = 0; j < p; j++) {
+			double s = 0;
+			for (int l = 0; l < k; l++) s += A[i * k + l] * B[j * k + l];
+			C[i * p + j] = s;
+		}
+}
+static void mTm(const double* A, const double* B, double* C, int k, int m, int p) { /* C = A^T * B, A is k x m, B k x p */
+	for (int i = 0; i < m; i++)
+		for (int j = 0; j < p; j++) {
+			double s = 0;
+			for (int l = 0; l < k; l++) s += A[l * m + i] * B[l * p + j];
+			C[i * p + j] = s;
+		}
+}
+static double fro(const double* A, int len) {
+	double s = 0;
+	for (int i = 0; i < len; i++) s += A[i] * A[i];
+	return sqrt(s);
+}
+static void eye(double* A, int n) {
+	memset(A, 0, sizeof(double) * n * n);
+	for (int i = 0; i < n; i++) A[i * n + i] = 1;
+}
+/* general inverse, Gauss-Jordan with partial pivoting (Eigen's dynamic .inverse() is PartialPivLU) */
+static int inverse(const double* A, double* Ainv, int n) {
+	double W[MAXN * 2 * MAXN];
+	int w = 2 * n;
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) {
+			W[i * w + j] = A[i * n + j];
+			W[i * w + n + j] = (i == j);
+		}
+	for (int c = 0; c < n; c++) {
+		int piv = c;
+		for (int r = c + 1; r < n; r++)
+			if (fabs(W[r * w + c]) > fabs(W[piv * w + c])) piv = r;
+		if (W[piv * w + c] == 0) return -1;
+		if (piv != c)
+			for (int j = 0; j < w; j++) {
+				double t = W[c * w + j];
+				W[c * w + j] = W[piv * w + j];
+				W[piv * w + j] = t;
+			}
+		double d = 1.0 / W[c * w + c];
+		for (int j = 0; j < w; j++) W[c * w + j] *= d;
+		for (int r = 0; r < n; r++)
+			if (r != c) {
+				double f = W[r * w + c];
+				if (f != 0)
+					for (int j = 0; j < w; j++) W[r * w + j] -= f * W[c * w + j];
+			}
+	}
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) Ainv[i * n + j] = W[i * w + n + j];
+	return 0;
+}
+
+/* thin SVD by one-sided (Hestenes) Jacobi.  A m x n -> U m x r, s r, V n x r, r=min(m,n), descending.
+ * columns of U belonging to sigma==0 are set to zero (never used by the callers). */
+static void svd_tall(const double* A, int m, int n, double* U, double* s, double* V) { /* m >= n */
+	double W[MAXN * MAXN], VV[MAXN * MAXN];
+	memcpy(W, A, sizeof(double) * m * n);
+	eye(VV, n);
+	for (int sweep = 0; sweep < 80; sweep++) {
+		int rotated = 0;
+		for (int p = 0; p < n - 1; p++)
+			for (int q = p + 1; q < n; q++) {
+				double al = 0, be = 0, ga = 0;
+				for (int i = 0; i < m; i++) {
+					al += W[i * n + p] * W[i * n + p];
+					be += W[i * n + q] * W[i * n + q];
+					ga += W[i * n + p] * W[i * n + q];
+				}
+				if (al == 0 || be == 0) continue;
+				if (fabs(ga) <= 1e-16 * sqrt(al * be)) continue;
+				rotated = 1;
+				double zeta = (be - al) / (2 * ga);
+				double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+				double c = 1 / sqrt(1 + t * t), sn = c * t;
+				for (int i = 0; i < m; i++) {
+					double a = W[i * n + p], b = W[i * n + q];
+					W[i * n + p] = c * a - sn * b;
+					W[i * n + q] = sn * a + c * b;
+				}
+				for (int i = 0; i < n; i++) {
+					double a = VV[i * n + p], b = VV[i * n + q];
+					VV[i * n + p] = c * a - sn * b;
+					VV[i * n + q] = sn * a + c * b;
+				}
+			}
+		if (!rotated) break;
+	}
+	double nrm[MAXN];
+	int idx[MAXN];
+	for (int j = 0; j < n; j++) {
+		double a = 0;
+		for (int i = 0; i < m; i++) a += W[i * n + j] * W[i * n + j];
+		nrm[j] = sqrt(a);
+		idx[j] = j;
+	}
+	for (int a = 0; a < n; a++) /* selection sort, descending */
+		for (int b = a + 1; b < n; b++)
+			if (nrm[idx[b]] > nrm[idx[a]]) {
+				int t = idx[a];
+				idx[a] = idx[b];
+				idx[b] = t;
+			}
+	double smax = nrm[idx[0]];
+	for (int j = 0; j < n; j++) {
+		int c = idx[j];
+		s[j] = nrm[c];
+		int dead = !(nrm[c] > 1e-300 && nrm[c] > 1e-14 * smax);
+		for (int i = 0; i < m; i++) U[i * n + j] = dead ? 0.0 : W[i * n + c] / nrm[c];
+		for (int i = 0; i < n; i++) V[i * n + j] = VV[i * n + c];
+	}
+}
+static void svd_thin(const double* A, int m, int n, double* U, double* s, double* V) {
+	if (m >= n) {
+		svd_tall(A, m, n, U, s, V);
+	} else {
+		double At[MAXN * MAXN];
+		for (int i = 0; i < m; i++)
+			for (int j = 0; j < n; j++) At[j * m + i] = A[i * n + j];
+		/* A^T (n x m) = U' S V'^T  =>  A = V' S U'^T */
+		svd_tall(At, n, m, V, s, U);
+	}
+}
+
+/* SaiModel::matrixRangeBasis [RECALLED, SURVEY App. A-5/B]: returns number of columns (>=1); a single zero
+ * column means "empty range". U is rows x cols_out row-major. */
+static int matrix_range_basis(const double* A, int rows, int cols, double* U, double tol) {
+	if (rows == 0 || cols == 0 || fro(A, rows * cols) < tol) {
+		for (int i = 0; i < rows; i++) U[i] = 0;
+		return 1;
+	}
+	int r = rows < cols ? rows : cols;
+	double Uf[MAXN * MAXN], s[MAXN], V[MAXN * MAXN];
+	svd_thin(A, rows, cols, Uf, s, V);
+	if (s[0] < tol) {
+		for (int i = 0; i < rows; i++) U[i] = 0;
+		return 1;
+	}
+	int task_dof = r;
+	for (int i = r - 1; i > 0; i--) {
+		if (s[i] / s[0] < tol) task_dof--;
+		else break;
+	}
+	if (task_dof == rows) {
+		eye(U, rows);
+		return rows;
+	}
+	for (int i = 0; i < rows; i++)
+		for (int j = 0; j < task_dof; j++) U[i * task_dof + j] = Uf[i * r + j];
+	return task_dof;
+}
+
+/* ------------------------------------------------------------------ robot model (sai-model restatement) */
+typedef struct {
+	double q[MAXN], dq[MAXN];
+	double R[MAXL][9], o[MAXL][3]; /* world pose of every link frame */
+	double M[MAXN * MAXN], Minv[MAXN * MAXN];
+} robot_state;
+
+static void rot_rpy(const double rpy[3], double R[9]) {
+	double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
+	/* Rz(y) Ry(p) Rx(r) */
+	R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+	R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+	R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+static void rot_axis(const double a[3], double q, double R[9]) {
+	double c = cos(q), s = sin(q), v = 1 - c;
+	R[0] = c + a[0] * a[0] * v;        R[1] = a[0] * a[1] * v - a[2] * s; R[2] = a[0] * a[2] * v + a[1] * s;
+	R[3] = a[1] * a[0] * v + a[2] * s; R[4] = c + a[1] * a[1] * v;        R[5] = a[1] * a[2] * v - a[0] * s;
+	R[6] = a[2] * a[0] * v - a[1] * s; R[7] = a[2] * a[1] * v + a[0] * s; R[8] = c + a[2] * a[2] * v;
+}
+static void mat3v(const double R[9], const double v[3], double out[3]) {
+	for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+static void cross3(const double a[3], const double b[3], double c[3]) {
+	c[0] = a[1] * b[2] - a[2] * b[1];
+	c[1] = a[2] * b[0] - a[0] * b[2];
+	c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static void update_kinematics(const orc_ctx* c, robot_state* rs) {
+	double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, op[3] = {0, 0, 0};
+	for (int l = 0; l < c->nl; l++) {
+		double t[3], Rt[9];
+		mat3v(Rp, c->p0[l], t);
+		for (int i = 0; i < 3; i++) rs->o[l][i] = op[i] + t[i];
+		mm(Rp, c->R0[l], Rt, 3, 3, 3);
+		if (c->joint_type[l] == JT_REVOLUTE) {
+			double Rq[9];
+			rot_axis(c->axis[l], rs->q[c->dof_of_link[l]], Rq);
+			mm(Rt, Rq, rs->R[l], 3, 3, 3);
+		} else {
+			memcpy(rs->R[l], Rt, sizeof(Rt));
+			if (c->joint_type[l] == JT_PRISMATIC) {
+				double z[3];
+				mat3v(Rt, c->axis[l], z);
+				for (int i = 0; i < 3; i++) rs->o[l][i] += z[i] * rs->q[c->dof_of_link[l]];
+			}
+		}
+		memcpy(Rp, rs->R[l], sizeof(Rp));
+		memcpy(op, rs->o[l], sizeof(op));
+	}
+}
+/* JWorldFrame(link, pos_in_link): 6 x n, rows [Jv; Jw] */
+static void jacobian_world(const orc_ctx* c, const robot_state* rs, int link, const double p_world[3], double* J) {
+	int n = c->n;
+	memset(J, 0, sizeof(double) * 6 * n);
+	for (int l = 0; l <= link; l++) {
+		int d = c->dof_of_link[l];
+		if (d < 0) continue;
+		double z[3];
+		mat3v(rs->R[l], c->axis[l], z);
+		if (c->joint_type[l] == JT_REVOLUTE) {
+			double r[3] = {p_world[0] - rs->o[l][0], p_world[1] - rs->o[l][1], p_world[2] - rs->o[l][2]}, v[3];
+			cross3(z, r, v);
+			for (int i = 0; i < 3; i++) {
+				J[i * n + d] = v[i];
+				J[(3 + i) * n + d] = z[i];
+			}
+		} else {
+			for (int i = 0; i < 3; i++) J[i * n + d] = z[i];
+		}
+	}
+}
+static void position_in_world(const robot_state* rs, int link, const double pos_in_link[3], double p[3]) {
+	double t[3];
+	mat3v(rs->R[link], pos_in_link, t);
+	for (int i = 0; i < 3; i++) p[i] = rs->o[link][i] + t[i];
+}
+/* updateModel(): kinematics + M (body sum, equals CRBA) + M^-1 */
+static void update_model(const orc_ctx* c, robot_state* rs) {
+	int n = c->n;
+	update_kinematics(c, rs);
+	memset(rs->M, 0, sizeof(double) * n * n);
+	for (int l = 0; l < c->nl; l++) {
+		double pc[3], J[6 * MAXN], Iw[9], T[9], IJ[3 * MAXN];
+		position_in_world(rs, l, c->com[l], pc);
+		jacobian_world(c, rs, l, pc, J);
+		mm(rs->R[l], c->inertia[l], T, 3, 3, 3);
+		mmT(T, rs->R[l], Iw, 3, 3, 3);
+		mm(Iw, J + 3 * n, IJ, 3, 3, n);
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < n; j++) {
+				double s = 0;
+				for (int k = 0; k < 3; k++) s += c->mass[l] * J[k * n + i] * J[k * n + j] + J[(3 + k) * n + i] * IJ[k * n + j];
+				rs->M[i * n + j] += s;
+			}
+	}
+	inverse(rs->M, rs->Minv, n);
+}
+static void joint_gravity_vector(const orc_ctx* c, const robot_state* rs, double* g) {
+	int n = c->n;
+	for (int i = 0; i < n; i++) g[i] = 0;
+	for (int l = 0; l < c->nl; l++) {
+		double pc[3], J[6 * MAXN];
+		position_in_world(rs, l, c->com[l], pc);
+		jacobian_world(c, rs, l, pc, J);
+		for (int i = 0; i < n; i++)
+			for (int k = 0; k < 3; k++) g[i] -= c->mass[l] * J[k * n + i] * c->gravity[k];
+	}
+}
+/* operationalSpaceMatrices(J): Lambda k x k, Jbar n x k, N n x n */
+static void op_space_matrices(const robot_state* rs, int n, const double* J, int k, double* Lambda, double* Jbar, double* N) {
+	double T[MAXN * MAXN], Li[MAXN * MAXN], T2[MAXN * MAXN];
+	mm(J, rs->Minv, T, k, n, n);
+	mmT(T, J, Li, k, n, k);
+	inverse(Li, Lambda, k);
+	for (int i = 0; i < n; i++) /* T2 = Minv J^T (n x k) */
+		for (int j = 0; j < k; j++) {
+			double s = 0;
+			for (int l = 0; l < n; l++) s += rs->Minv[i * n + l] * J[j * n + l];
+			T2[i * k + j] = s;
+		}
+	mm(T2, Lambda, Jbar, n, k, k);
+	mm(Jbar, J, N, n, k, n);
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++) N[i * n + j] = (i == j) - N[i * n + j];
+}
+static void bie_inverse(const robot_state* rs, int n, double thr, double* MinvB) {
+	double Mb[MAXN * MAXN];
+	memcpy(Mb, rs->M, sizeof(double) * n * n);
+	for (int i = 0; i < n; i++)
+		if (Mb[i * n + i] < thr) Mb[i * n + i] = thr;
+	inverse(Mb, MinvB, n);
+}
+static void orientation_error(const double Rd[9], const double Rc[9], double e[3]) {
+	e[0] = e[1] = e[2] = 0;
+	for (int col = 0; col < 3; col++) {
+		double a[3] = {Rc[col], Rc[3 + col], Rc[6 + col]}, b[3] = {Rd[col], Rd[3 + col], Rd[6 + col]}, x[3];
+		cross3(a, b, x);
+		for (int i = 0; i < 3; i++) e[i] += -0.5 * x[i];
+	}
+}
+
+/* ------------------------------------------------------------------ per-task cached models */
+typedef struct {
+	double N_prec[MAXN * MAXN], N[MAXN * MAXN];
+	/* motion force + singularity handler */
+	double jacobian[6 * MAXN], projected_jacobian[6 * MAXN];
+	int k;
+	double task_range_ns[36], projected_jacobian_ns[6 * MAXN], Lambda_ns[36], Lambda_ns_modified[36];
+	double sv[6];
+	int singular;
+	/* joint */
+	int r, empty;
+	double jt_projected_jacobian[MAXN * MAXN], current_task_range[MAXN * MAXN], M_partial[MAXN * MAXN],
+		M_partial_modified[MAXN * MAXN];
+} task_model;
+
+/* SingularityHandler::updateTaskModel, SingularityHandler.cpp:75-228 (non-singular branch :123-141,146-148,175-193) */
+static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm) {
+	int n = c->n, k = t->pos_range + t->ori_range;
+	double U[36], s[6], V[MAXN * 6];
+	tm->k = k;
+	svd_thin(tm->projected_jacobian, 6, n, U, s, V); /* :78-81 */
+	int r = n < 6 ? n : 6;
+	for (int i = 0; i < 6; i++) tm->sv[i] = i < r ? s[i] : 0;
+	tm->singular = 0;
+	if (s[0] < t->s_abs_tol) { /* :83 fully singular */
+		tm->singular = 1;
+		return;
+	}
+	if (k < 2) { /* :100 loop never runs: rank-1 tasks leave stale state */
+		tm->singular = 1;
+		return;
+	}
+	for (int i = 1; i < k; i++) {
+		double inv_condition_number = s[i] / s[0];
+		if (inv_condition_number < t->s_max) { /* :103 blending region */
+			tm->singular = 1;
+			return;
+		}
+	}
+	/* :123-141 fully non-singular: alpha = 1 */
+	for (int i = 0; i < 6; i++)
+		for (int j = 0; j < k; j++) tm->task_range_ns[i * k + j] = U[i * r + j]; /* _svd_U.leftCols(task_rank) */
+	mTm(tm->task_range_ns, tm->projected_jacobian, tm->projected_jacobian_ns, 6, k, n);
+	double Jbar[MAXN * 6];
+	op_space_matrices(rs, n, tm->projected_jacobian_ns, k, tm->Lambda_ns, Jbar, tm->N); /* _N = _N_ns :146-148 */
+	switch (t->decoupling) {
+		case FULL_DYNAMIC_DECOUPLING: memcpy(tm->Lambda_ns_modified, tm->Lambda_ns, sizeof(double) * k * k); break;
+		case IMPEDANCE: eye(tm->Lambda_ns_modified, k); break;
+		default: { /* BOUNDED_INERTIA_ESTIMATES :175-193 */
+			double MinvB[MAXN * MAXN], T[6 * MAXN], Li[36];
+			bie_inverse(rs, n, t->bie_threshold, MinvB);
+			mm(tm->projected_jacobian_ns, MinvB, T, k, n, n);
+			mmT(T, tm->projected_jacobian_ns, Li, k, n, k);
+			inverse(Li, tm->Lambda_ns_modified, k);
+		}
+	}
+}
+/* MotionForceTask::updateTaskModel, MotionForceTask.cpp:247-268 */
+static void mf_update_task_model(const orc_ctx* c, const orc_task* t, const robot_state* rs, const double* N_prec, task_model* tm) {
+	int n = c->n;
+	double p[3], Jw[6 * MAXN];
+	memcpy(tm->N_prec, N_prec, sizeof(double) * n * n);
+	position_in_world(rs, t->link, t->pos_in_link, p);
+	jacobian_world(c, rs, t->link, p, Jw);
+	mm(t->P, Jw, tm->jacobian, 6, 6, n);                       /* :261-263 */
+	mm(tm->jacobian, tm->N_prec, tm->projected_jacobian, 6, n, n); /* :264 */
+	sh_update_task_model(c, t, rs, tm);                        /* :266 */
+}
+/* MotionForceTask::computeTorques(), :278-509, with sigma_force = sigma_moment = 0 (defaults, :897-899, :937-939),
+ * OTG disabled (desired = goal, :385-391), velocity saturation off, open-loop force control. */
+static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm, const double* goal,
+								double* integ, double* tau) {
+	int n = c->n, k = tm->k;
+	double p[3], Jw[6 * MAXN], Rc[9];
+	position_in_world(rs, t->link, t->pos_in_link, p);         /* :286-287 */
+	jacobian_world(c, rs, t->link, p, Jw);
+	mm(t->P, Jw, tm->jacobian, 6, 6, n);                       /* :280-282 (recomputed) */
+	mm(tm->jacobian, tm->N_prec, tm->projected_jacobian, 6, n, n); /* :283 */
+	mm(rs->R[t->link], t->rot_in_link, Rc, 3, 3, 3);           /* :288-289 */
+	const double *xd = goal, *Rd = goal + 3, *vd = goal + 12, *wd = goal + 15, *ad = goal + 18, *ald = goal + 21;
+	double v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < n; j++) {
+			v[i] += tm->jacobian[i * n + j] * rs->dq[j];       /* :293-298 */
+			w[i] += tm->jacobian[(3 + i) * n + j] * rs->dq[j];
+		}
+	double sig_p[9], sig_o[9], Pp[9], Po[9], T[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			Pp[i * 3 + j] = t->P[i * 6 + j];
+			Po[i * 3 + j] = t->P[(3 + i) * 6 + 3 + j];
+		}
+	mmT(Pp, Pp, sig_p, 3, 3, 3); /* sigmaPosition = Ppos (I - 0) Ppos^T, :927-930 */
+	mmT(Po, Po, sig_o, 3, 3, 3); /* :968-971 */
+	(void)T;
+	double e[3], tmp[3], F_um[6];
+	for (int i = 0; i < 3; i++) e[i] = p[i] - xd[i];
+	mat3v(sig_p, e, tmp);
+	for (int i = 0; i < 3; i++) integ[i] += tmp[i] * t->dt;   /* :411-413 */
+	for (int i = 0; i < 3; i++) tmp[i] = ad[i] - t->kp_pos[i] * e[i] - t->kv_pos[i] * (v[i] - vd[i]) - t->ki_pos[i] * integ[i];
+	mat3v(sig_p, tmp, F_um);                                   /* :431-437 */
+	double oe[3], dphi[3];
+	orientation_error(Rd, Rc, oe);
+	mat3v(sig_o, oe, dphi);                                    /* :441-443 */
+	for (int i = 0; i < 3; i++) integ[3 + i] += dphi[i] * t->dt; /* :446 */
+	for (int i = 0; i < 3; i++) tmp[i] = ald[i] - t->kp_ori[i] * dphi[i] - t->kv_ori[i] * (w[i] - wd[i]) - t->ki_ori[i] * integ[3 + i];
+	mat3v(sig_o, tmp, F_um + 3);                               /* :463-468 */
+	/* force_moment_contribution + feedforward = 0 with sigma_force = sigma_moment = 0 (:350-354,:379-383,:480-482) */
+	double F_f[6] = {0, 0, 0, 0, 0, 0};
+	/* SingularityHandler::computeTorques, :307-309 */
+	double a[6], b[6], f[6];
+	mTm(tm->task_range_ns, F_um, a, 6, k, 1);
+	mTm(tm->task_range_ns, F_f, b, 6, k, 1);
+	mm(tm->Lambda_ns_modified, a, f, k, k, 1);
+	for (int i = 0; i < k; i++) f[i] += b[i];
+	mTm(tm->projected_jacobian_ns, f, tau, k, n, 1);
+	/* computeTorques(tau_prec) :270-276: _Lambda is all zeros (never written) => no compensation (App. C-1) */
+}
+/* JointTask::updateTaskModel, JointTask.cpp:218-283 */
+static void jt_update_task_model(const orc_ctx* c, const orc_task* t, const robot_state* rs, const double* N_prec, task_model* tm) {
+	int n = c->n, m = t->m;
+	memcpy(tm->N_prec, N_prec, sizeof(double) * n * n);
+	mm(t->S, tm->N_prec, tm->jt_projected_jacobian, m, n, n); /* :231 */
+	tm->r = matrix_range_basis(tm->jt_projected_jacobian, m, n, tm->current_task_range, 1e-3); /* :233 */
+	tm->empty = 0;
+	if (fro(tm->current_task_range, m * tm->r) == 0) {         /* :234-239 */
+		eye(tm->N, n);
+		tm->empty = 1;
+		return;
+	}
+	int r = tm->r;
+	double Jh[MAXN * MAXN], Jbar[MAXN * MAXN];
+	mTm(tm->current_task_range, tm->jt_projected_jacobian, Jh, m, r, n);
+	op_space_matrices(rs, n, Jh, r, tm->M_partial, Jbar, tm->N); /* :241-245 */
+	switch (t->decoupling) {
+		case FULL_DYNAMIC_DECOUPLING: memcpy(tm->M_partial_modified, tm->M_partial, sizeof(double) * r * r); break;
+		case IMPEDANCE: eye(tm->M_partial_modified, r); break;
+		default: { /* :253-267 */
+			double MinvB[MAXN * MAXN], T[MAXN * MAXN], Li[MAXN * MAXN];
+			bie_inverse(rs, n, t->bie_threshold, MinvB);
+			mm(Jh, MinvB, T, r, n, n);
+			mmT(T, Jh, Li, r, n, r);
+			inverse(Li, tm->M_partial_modified, r);
+		}
+	}
+}
+/* JointTask::computeTorques(tau_prec), :285-356 */
+static void jt_compute_torques(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm, const double* goal,
+								double* integ, const double* tau_prec, double* tau) {
+	int n = c->n, m = t->m, r = tm->r;
+	for (int i = 0; i < n; i++) tau[i] = 0;
+	mm(t->S, tm->N_prec, tm->jt_projected_jacobian, m, n, n);  /* :296 */
+	if (tm->empty) return;                                      /* :302-306 */
+	double cur[MAXN], vel[MAXN], f[MAXN];
+	mm(t->S, rs->q, cur, m, n, 1);
+	mm(t->S, rs->dq, vel, m, n, 1);
+	const double *qd = goal, *dqd = goal + m, *ddqd = goal + 2 * m;
+	for (int i = 0; i < m; i++) {
+		integ[i] += (cur[i] - qd[i]) * t->dt;                   /* :323-324 */
+		f[i] = -t->kp[i] * (cur[i] - qd[i]) - t->kv[i] * (vel[i] - dqd[i]) - t->ki[i] * integ[i]; /* :342-345 */
+	}
+	double a[MAXN], b[MAXN], fr[MAXN], g[MAXN], Ua[MAXN];
+	mTm(tm->current_task_range, ddqd, a, m, r, 1);
+	mTm(tm->current_task_range, f, b, m, r, 1);
+	mm(tm->M_partial, a, fr, r, r, 1);
+	mm(tm->M_partial_modified, b, g, r, r, 1);
+	for (int i = 0; i < r; i++) fr[i] += g[i];                  /* :348-351 */
+	mm(tm->current_task_range, fr, Ua, m, r, 1);
+	mTm(tm->jt_projected_jacobian, Ua, tau, m, n, 1);           /* :354-355 */
+	/* disturbance compensation :287-291 */
+	double mt[MAXN], smt[MAXN], d[MAXN];
+	mm(rs->Minv, tau_prec, mt, n, n, 1);
+	mm(t->S, mt, smt, m, n, 1);
+	mTm(tm->current_task_range, smt, a, m, r, 1);
+	mm(tm->M_partial, a, b, r, r, 1);
+	mm(tm->current_task_range, b, Ua, m, r, 1);
+	mTm(tm->jt_projected_jacobian, Ua, d, m, n, 1);
+	for (int i = 0; i < n; i++) tau[i] -= d[i];
+}
+/* JointLimitAvoidanceTask::updateTaskModel, JointLimitAvoidanceTask.cpp:124-252 (status only; the torque path
+ * :258-421 is a "next" row and only entered when the controller enables JLA, RobotController.cpp:96) */
+static void jla_update_task_model(const orc_ctx* c, const robot_state* rs, const double* N_prec, double* N_constraints) {
+	int n = c->n;
+	const double pz1 = 9 * M_PI / 180.0, vz1 = 0.5;              /* JointLimitAvoidanceTask.h:29-32 */
+	int active[MAXN], na = 0;
+	for (int i = 0; i < n; i++) {                               /* updateLimitStatus :171-239 */
+		int on = 0, dir = +1;
+		int pos_valid = c->q_hi[i] - c->q_lo[i] > 2 * pz1, vel_valid = c->vel[i] > 2 * vz1;
+		if (pos_valid && rs->q[i] > c->q_hi[i] - pz1) { on = 1; dir = +1; }
+		if (pos_valid && rs->q[i] < c->q_lo[i] + pz1) { on = 1; dir = -1; }
+		if (vel_valid && (!on || dir < 0) && rs->dq[i] > c->vel[i] - vz1) { on = 1; dir = +1; }
+		if (vel_valid && (!on || dir > 0) && rs->dq[i] < -c->vel[i] + vz1) { on = 1; dir = -1; }
+		if (on) active[na++] = i;
+	}
+	double S[MAXN * MAXN], Jp[MAXN * MAXN], U[MAXN * MAXN];
+	memset(S, 0, sizeof(double) * (na ? na : 1) * n);
+	for (int r = 0; r < na; r++) S[r * n + active[r]] = 1;     /* computeJointSelectionMatrix :241-252 */
+	mm(S, N_prec, Jp, na, n, n);                               /* :145 */
+	int r0 = matrix_range_basis(S, na, n, U, 1e-3);            /* :147-154 (N_unconstrained unused when JLA off) */
+	(void)r0;
+	int r = matrix_range_basis(Jp, na, n, U, 1e-3);            /* :156 */
+	if (fro(U, na * r) == 0) {                                 /* :157-162 */
+		eye(N_constraints, n);
+		return;
+	}
+	double Jh[MAXN * MAXN], Lam[MAXN * MAXN], Jbar[MAXN * MAXN], N[MAXN * MAXN];
+	mTm(U, Jp, Jh, na, r, n);
+	op_space_matrices(rs, n, Jh, r, Lam, Jbar, N);             /* :164-168 */
+	mm(N, N_prec, N_constraints, n, n, n);
+}
+
+/* ------------------------------------------------------------------ RobotController cycle for one instance */
+typedef struct {
+	double* N_out;      /* optional [nt][n*n] task nullspaces (N of each task) */
+	double* Lambda_out; /* optional [nt][MAXN*MAXN] Lambda (k x k or r x r, row-major, leading dim = its size) */
+	double* sv_out;     /* optional [nt][6] singular values of projected jacobian (motion force tasks) */
+	double* M_out;      /* optional n*n */
+	double* task_tau;   /* optional [nt][n] */
+} orc_details;
+
+static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* dq, const double* const* goal, double* integ,
+							  double* tau, orc_details* det) {
+	int n = c->n;
+	robot_state rs;
+	task_model tm[MAXT];
+	memcpy(rs.q, q, sizeof(double) * n);
+	memcpy(rs.dq, dq, sizeof(double) * n);
+	update_model(c, &rs); /* robot->updateModel() */
+	if (det && det->M_out) memcpy(det->M_out, rs.M, sizeof(double) * n * n);
+
+	/* updateControllerTaskModels, RobotController.cpp:68-77 */
+	double N_prec[MAXN * MAXN], N_constraints[MAXN * MAXN], T[MAXN * MAXN];
+	eye(N_prec, n);
+	jla_update_task_model(c, &rs, N_prec, N_constraints); /* :71-72, runs even when JLA is disabled */
+	int status = ST_OK;
+	for (int t = 0; t < c->nt; t++) {
+		const orc_task* tk = &c->task[t];
+		if (tk->type == TASK_MOTION_FORCE) {
+			mf_update_task_model(c, tk, &rs, N_prec, &tm[t]);
+			if (tm[t].singular) status = ST_SINGULAR;
+			if (det && det->sv_out) memcpy(det->sv_out + 6 * t, tm[t].sv, sizeof(double) * 6);
+			if (status != ST_OK) break;
+			if (det && det->Lambda_out) memcpy(det->Lambda_out + t * MAXN * MAXN, tm[t].Lambda_ns, sizeof(double) * tm[t].k * tm[t].k);
+		} else {
+			jt_update_task_model(c, tk, &rs, N_prec, &tm[t]);
+			if (det && det->Lambda_out && !tm[t].empty)
+				memcpy(det->Lambda_out + t * MAXN * MAXN, tm[t].M_partial, sizeof(double) * tm[t].r * tm[t].r);
+		}
+		if (det && det->N_out) memcpy(det->N_out + t * n * n, tm[t].N, sizeof(double) * n * n);
+		mm(tm[t].N, tm[t].N_prec, T, n, n, n); /* getTaskAndPreviousNullspace */
+		memcpy(N_prec, T, sizeof(double) * n * n);
+	}
+	if (status != ST_OK) {
+		for (int i = 0; i < n; i++) tau[i] = NAN;
+		return status;
+	}
+	/* computeControlTorques, RobotController.cpp:79-118 */
+	double tt[MAXN];
+	for (int i = 0; i < n; i++) tau[i] = 0;
+	for (int t = 0; t < c->nt; t++) {
+		const orc_task* tk = &c->task[t];
+		if (tk->type == TASK_MOTION_FORCE) mf_compute_torques(c, tk, &rs, &tm[t], goal[t], integ + t * MAXN, tt);
+		else jt_compute_torques(c, tk, &rs, &tm[t], goal[t], integ + t * MAXN, tau, tt);
+		if (det && det->task_tau) memcpy(det->task_tau + t * n, tt, sizeof(double) * n);
+		for (int i = 0; i < n; i++) tau[i] += tt[i];
+	}
+	if (c->torque_sat) /* :86-94 */
+		for (int i = 0; i < n; i++) {
+			if (tau[i] > c->effort[i]) tau[i] = c->effort[i];
+			else if (tau[i] < -c->effort[i]) tau[i] = -c->effort[i];
+		}
+	/* :96-112 JLA wrap: "next" row (not restated yet); orc_set_options rejects jla_enabled */
+	if (c->gravity_comp) { /* :114-116 */
+		double g[MAXN];
+		joint_gravity_vector(c, &rs, g);
+		for (int i = 0; i < n; i++) tau[i] += g[i];
+	}
+	return ST_OK;
+}
+
+/* ------------------------------------------------------------------ exported API (ctypes) */
+orc_ctx* orc_create(int n_links, const int* joint_type, const double* xyz, const double* rpy, const double* axis,
+					const double* mass, const double* com, const double* inertia6, const double* q_lo, const double* q_hi,
+					const double* vel, const double* effort) {
+	if (n_links > MAXL) return NULL;
+	orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+	c->nl = n_links;
+	int n = 0;
+	for (int l = 0; l < n_links; l++) {
+		c->joint_type[l] = joint_type[l];
+		rot_rpy(rpy + 3 * l, c->R0[l]);
+		double an = sqrt(axis[3 * l] * axis[3 * l] + axis[3 * l + 1] * axis[3 * l + 1] + axis[3 * l + 2] * axis[3 * l + 2]);
+		for (int i = 0; i < 3; i++) {
+			c->p0[l][i] = xyz[3 * l + i];
+			c->axis[l][i] = an > 0 ? axis[3 * l + i] / an : 0;
+			c->com[l][i] = com[3 * l + i];
+		}
+		c->mass[l] = mass[l];
+		const double* I = inertia6 + 6 * l; /* ixx iyy izz ixy ixz iyz */
+		double Im[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
+		memcpy(c->inertia[l], Im, sizeof(Im));
+		if (joint_type[l] == JT_FIXED) {
+			c->dof_of_link[l] = -1;
+		} else {
+			if (n >= MAXN) { free(c); return NULL; }
+			c->dof_of_link[l] = n;
+			c->q_lo[n] = q_lo[l]; c->q_hi[n] = q_hi[l]; c->vel[n] = vel[l]; c->effort[n] = effort[l];
+			n++;
+		}
+	}
+	c->n = n;
+	c->gravity[2] = -9.81;
+	return c;
+}
+void orc_destroy(orc_ctx* c) {
+	if (c) { free(c->integ); free(c); }
+}
+int orc_dof(const orc_ctx* c) { return c->n; }
+
+static void task_defaults(orc_task* t) {
+	t->dt = 0.001;
+	t->decoupling = BOUNDED_INERTIA_ESTIMATES; /* MotionForceTask.h:41-43, JointTask.h:35-37 */
+	t->bie_threshold = 0.1;
+}
+/* MotionForceTask ctor: nt<0 && nr<0 => full task (P = I, MotionForceTask.cpp:28); otherwise :55-87 */
+int orc_add_motion_force_task(orc_ctx* c, int link, const double* pos_in_link, const double* rot_in_link, const double* dirs_t,
+							  int nt, const double* dirs_r, int nr) {
+	if (c->nt >= MAXT || link < 0 || link >= c->nl) return -1;
+	orc_task* t = &c->task[c->nt];
+	memset(t, 0, sizeof(*t));
+	task_defaults(t);
+	t->type = TASK_MOTION_FORCE;
+	t->link = link;
+	memcpy(t->pos_in_link, pos_in_link, sizeof(double) * 3);
+	memcpy(t->rot_in_link, rot_in_link, sizeof(double) * 9);
+	if (nt < 0 && nr < 0) {
+		eye(t->P, 6);
+	} else {
+		if (nt <= 0 && nr <= 0) return -1; /* :47-53 */
+		if (nt > 8 || nr > 8) return -1;
+		double bt[9] = {0}, br[9] = {0}, A[24];
+		int ct = 1, cr = 1;
+		if (nt > 0) { /* 3 x nt matrix whose columns are the directions */
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < nt; j++) A[i * nt + j] = dirs_t[3 * j + i];
+			ct = matrix_range_basis(A, 3, nt, bt, 1e-3);
+		}
+		if (nr > 0) {
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < nr; j++) A[i * nr + j] = dirs_r[3 * j + i];
+			cr = matrix_range_basis(A, 3, nr, br, 1e-3);
+		}
+		double Pt[9], Pr[9];
+		mmT(bt, bt, Pt, 3, ct, 3);
+		mmT(br, br, Pr, 3, cr, 3);
+		memset(t->P, 0, sizeof(t->P));
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) {
+				t->P[i * 6 + j] = Pt[i * 3 + j];
+				t->P[(3 + i) * 6 + 3 + j] = Pr[i * 3 + j];
+			}
+	}
+	/* initialSetup :143-152 */
+	double Pp[9], Po[9], U[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			Pp[i * 3 + j] = t->P[i * 6 + j];
+			Po[i * 3 + j] = t->P[(3 + i) * 6 + 3 + j];
+		}
+	int cp = matrix_range_basis(Pp, 3, 3, U, 1e-3);
+	t->pos_range = fro(U, 3 * cp) == 0 ? 0 : cp;
+	int co = matrix_range_basis(Po, 3, 3, U, 1e-3);
+	t->ori_range = fro(U, 3 * co) == 0 ? 0 : co;
+	if (t->pos_range + t->ori_range == 0) return -1;
+	for (int i = 0; i < 3; i++) { /* MotionForceTask.h:44-49 */
+		t->kp_pos[i] = 100.0; t->kv_pos[i] = 20.0; t->ki_pos[i] = 0.0;
+		t->kp_ori[i] = 200.0; t->kv_ori[i] = 28.3; t->ki_ori[i] = 0.0;
+	}
+	t->s_min = 6e-3; t->s_max = 6e-2; /* MotionForceTask.cpp:197 */
+	t->s_abs_tol = 1e-3;              /* SingularityHandler.cpp:11 */
+	return c->nt++;
+}
+/* JointTask ctor: rows<=0 => full (S = I, JointTask.cpp:18-19) */
+int orc_add_joint_task(orc_ctx* c, const double* S, int rows) {
+	if (c->nt >= MAXT) return -1;
+	orc_task* t = &c->task[c->nt];
+	memset(t, 0, sizeof(*t));
+	task_defaults(t);
+	t->type = TASK_JOINT;
+	if (rows <= 0) {
+		t->m = c->n;
+		eye(t->S, c->n);
+	} else {
+		if (rows > c->n) return -1;
+		t->m = rows;
+		memcpy(t->S, S, sizeof(double) * rows * c->n);
+	}
+	for (int i = 0; i < t->m; i++) { t->kp[i] = 50.0; t->kv[i] = 14.0; t->ki[i] = 0.0; } /* JointTask.h:32-34 */
+	return c->nt++;
+}
+void orc_set_mf_gains(orc_ctx* c, int task, const double* kp_pos, const double* kv_pos, const double* ki_pos, const double* kp_ori,
+					  const double* kv_ori, const double* ki_ori) {
+	orc_task* t = &c->task[task];
+	for (int i = 0; i < 3; i++) {
+		t->kp_pos[i] = kp_pos[i]; t->kv_pos[i] = kv_pos[i]; t->ki_pos[i] = ki_pos[i];
+		t->kp_ori[i] = kp_ori[i]; t->kv_ori[i] = kv_ori[i]; t->ki_ori[i] = ki_ori[i];
+	}
+}
+void orc_set_joint_gains(orc_ctx* c, int task, const double* kp, const double* kv, const double* ki) {
+	orc_task* t = &c->task[task];
+	for (int i = 0; i < t->m; i++) { t->kp[i] = kp[i]; t->kv[i] = kv[i]; t->ki[i] = ki[i]; }
+}
+void orc_set_decoupling(orc_ctx* c, int task, int type, double bie_threshold) {
+	c->task[task].decoupling = type;
+	c->task[task].bie_threshold = bie_threshold;
+}
+void orc_set_singularity_bounds(orc_ctx* c, int task, double s_min, double s_max) {
+	c->task[task].s_min = s_min;
+	c->task[task].s_max = s_max;
+}
+void orc_set_timestep(orc_ctx* c, int task, double dt) { c->task[task].dt = dt; }
+int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
+	if (jla) return -1; /* JLA torque path not restated yet */
+	c->gravity_comp = gravity_comp;
+	c->torque_sat = torque_sat;
+	return 0;
+}
+int orc_goal_size(const orc_ctx* c, int task) { return c->task[task].type == TASK_MOTION_FORCE ? 24 : 3 * c->task[task].m; }
+void orc_reset_state(orc_ctx* c) {
+	free(c->integ);
+	c->integ = NULL;
+	c->state_B = 0;
+}
+
+typedef struct {
+	const orc_ctx* c;
+	int B, b0, b1;
+	const double *q, *dq;
+	const double* const* goals;
+	double* tau;
+	unsigned char* status;
+	double* integ;
+} worker_arg;
+
+static void* worker(void* p) {
+	worker_arg* a = (worker_arg*)p;
+	const orc_ctx* c = a->c;
+	int n = c->n, B = a->B;
+	double q[MAXN], dq[MAXN], tau[MAXN], gbuf[MAXT][3 * MAXN > 24 ? 3 * MAXN : 24];
+	const double* gp[MAXT];
+	for (int b = a->b0; b < a->b1; b++) {
+		for (int i = 0; i < n; i++) { q[i] = a->q[(size_t)i * B + b]; dq[i] = a->dq[(size_t)i * B + b]; }
+		for (int t = 0; t < c->nt; t++) {
+			int gs = orc_goal_size(c, t);
+			for (int i = 0; i < gs; i++) gbuf[t][i] = a->goals[t][(size_t)i * B + b];
+			gp[t] = gbuf[t];
+		}
+		int st = orc_instance_cycle(c, q, dq, gp, a->integ + (size_t)b * MAXT * MAXN, tau, NULL);
+		for (int i = 0; i < n; i++) a->tau[(size_t)i * B + b] = tau[i];
+		if (a->status) a->status[b] = (unsigned char)st;
+	}
+	return NULL;
+}
+
+/* One control cycle for B instances. Layout: q,dq [n][B]; goals[t] [goal_size][B]; tau [n][B]; status [B]. */
+int orc_step_batch(orc_ctx* c, int B, const double* q, const double* dq, const double* const* goals, double* tau,
+				   unsigned char* status, int nthreads) {
+	if (c->state_B != B) {
+		free(c->integ);
+		c->integ = (double*)calloc((size_t)B * MAXT * MAXN, sizeof(double));
+		c->state_B = B;
+	}
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 256) nthreads = 256;
+	if (nthreads > B) nthreads = B;
+	pthread_t th[256];
+	worker_arg wa[256];
+	for (int i = 0; i < nthreads; i++) {
+		wa[i] = (worker_arg){c, B, (int)((long long)B * i / nthreads), (int)((long long)B * (i + 1) / nthreads), q, dq, goals, tau, status, c->integ};
+		if (nthreads == 1) worker(&wa[i]);
+		else pthread_create(&th[i], NULL, worker, &wa[i]);
+	}
+	if (nthreads > 1)
+		for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+	return 0;
+}
+
+/* Single instance with intermediate quantities (for invariant tests). Arrays are instance-contiguous. Integrators start at 0. */
+int orc_step_details(const orc_ctx* c, const double* q, const double* dq, const double* const* goals, double* tau, double* N_out,
+					 double* Lambda_out, double* sv_out, double* M_out, double* task_tau) {
+	double integ[MAXT * MAXN];
+	memset(integ, 0, sizeof(integ));
+	orc_details d = {N_out, Lambda_out, sv_out, M_out, task_tau};
+	return orc_instance_cycle(c, q, dq, goals, integ, tau, &d);
+}
+int orc_maxn(void) { return MAXN; }

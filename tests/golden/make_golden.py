@@ -1,0 +1,47 @@
+"""Generates tests/golden/*.npz: seeded inputs + expected joint torques of the reference hot path,
+computed by the independent NumPy restatement in workloads.py (NOT by the C oracle, NOT by the
+product).  The reference itself cannot be built or imported here (C++ needing Eigen3/sai-model/RBDL,
+SURVEY.md 8(c)), so these vectors pin the C oracle against a second restatement, not against the
+reference binary ("parity unpinned", see oracle/saip_oracle.c header).
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import workloads as W  # noqa: E402
+
+# name -> (config id, instances, controller options)
+SCENARIOS = {
+    "cfg1_joint_pd": (1, 1, {}),
+    "cfg2_mf_joint": (2, 48, {}),
+    "cfg3_partial": (3, 48, {}),
+    "cfg5_chain30": (5, 6, {}),
+    "cfg6_sliding_base": (6, 32, {}),
+    "cfg7_ori_only_full_decoupling": (7, 32, {}),
+    "cfg8_planar_impedance": (8, 32, {}),
+    "cfg2_gravity_saturation": (2, 32, dict(gravity_comp=True, torque_saturation=True)),
+}
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, (cfg, B, opts) in SCENARIOS.items():
+        d = W.make_inputs(cfg, B)
+        tau, status = W.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"], **opts)
+        assert status.sum() == 0, name
+        arrs = dict(cfg=np.int64(cfg), q=d["q"], dq=d["dq"], tau=tau, status=status,
+                    gravity_comp=np.bool_(opts.get("gravity_comp", False)),
+                    torque_saturation=np.bool_(opts.get("torque_saturation", False)))
+        for i, g in enumerate(d["goals"]):
+            arrs[f"goal{i}"] = g
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **{k: np.asarray(v, dtype=v.dtype.newbyteorder("<") if hasattr(v, "dtype") and v.dtype.kind == "f" else None) for k, v in arrs.items()})
+        print(name, "B", B, "max|tau|", float(np.abs(tau).max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+"""CPU tests that pin the C oracle (oracle/saip_oracle.c):
+ (i)  against the committed golden vectors (tests/golden/*.npz, made by the independent NumPy
+      restatement, tests/golden/make_golden.py),
+ (ii) against the NumPy restatement on fresh seeds,
+ (iii) against the closed-form invariants of SURVEY.md Appendix E (no second implementation needed).
+The reference has no tests/fixtures for this path and cannot be built here => "parity unpinned"."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import workloads as W
+from oracle import Oracle
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load_golden(path):
+    z = np.load(path)
+    cfg = int(z["cfg"])
+    model = W.load_robot(W.CONFIGS[cfg]["robot"])
+    tasks = W.config_tasks(cfg)
+    goals = [z[f"goal{i}"] for i in range(len(tasks))]
+    opts = dict(gravity_comp=bool(z["gravity_comp"]), torque_saturation=bool(z["torque_saturation"]))
+    return model, tasks, z["q"], z["dq"], goals, z["tau"], opts
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_golden(path):
+    model, tasks, q, dq, goals, tau_ref, opts = load_golden(path)
+    tau, status = Oracle(model, tasks, **opts).step(q, dq, goals)
+    assert status.sum() == 0
+    assert W.torque_error(tau, tau_ref) < 1e-9
+
+
+def test_golden_inputs_reproducible():
+    """the committed inputs are exactly what the seeded generator produces today"""
+    model, tasks, q, dq, goals, _, _ = load_golden([p for p in GOLDEN if "cfg2_mf_joint" in p][0])
+    d = W.make_inputs(2, q.shape[0])
+    assert np.array_equal(d["q"], q) and np.array_equal(d["dq"], dq)
+    for a, b in zip(d["goals"], goals):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 40), (3, 40), (6, 24), (8, 24)])
+def test_oracle_matches_numpy_fresh_seed(cfg, B):
+    d = W.make_inputs(cfg, B, shard=3)  # instances [3B,4B) of the stream: disjoint from the golden ones
+    tau, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"])
+    tn, sn = W.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"])
+    assert st.sum() == 0 and sn.sum() == 0
+    assert W.torque_error(tau, tn) < 1e-9
+
+
+def test_multithreaded_batch_is_identical():
+    d = W.make_inputs(2, 64)
+    o = Oracle(d["model"], d["tasks"])
+    t1, _ = o.step(d["q"], d["dq"], d["goals"], nthreads=1)
+    o.reset_state()
+    t4, _ = o.step(d["q"], d["dq"], d["goals"], nthreads=4)
+    assert np.array_equal(t1, t4)
+
+
+# ------------------------------------------------------------------ Appendix E invariants
+def _cfg2_details(i=0, **kw):
+    d = W.make_inputs(2, 8)
+    tasks = W.config_tasks(2)
+    for t in tasks:
+        t.update(kw)
+    o = Oracle(d["model"], tasks)
+    det = o.details(d["q"][i], d["dq"][i], [g[i] for g in d["goals"]])
+    return d, tasks, det
+
+
+def test_E1_projector_identities():
+    d, tasks, det = _cfg2_details()
+    n = 7
+    M = det["M"]
+    Minv = np.linalg.inv(M)
+    assert np.allclose(M, M.T, atol=1e-13) and np.linalg.eigvalsh(M).min() > 0        # E-8
+    N1 = det["N"][0]
+    Lam = det["Lambda"][0][:36].reshape(6, 6)
+    assert np.allclose(Lam, Lam.T, atol=1e-9 * np.abs(Lam).max()) and np.linalg.eigvalsh((Lam + Lam.T) / 2).min() > 0
+    assert np.allclose(N1 @ N1, N1, atol=1e-10)                                        # N^2 = N
+    # J N = 0 for the world Jacobian of the control point
+    model = d["model"]
+    fr = W.fk(model, d["q"][:1])
+    li = model.link_index("end-effector")
+    p = fr[li][1] + fr[li][0] @ np.array([0, 0, 0.07])
+    J = W.jacobian(model, fr, li, p)[0]
+    assert np.abs(J @ N1).max() < 1e-10
+    Jbar = Minv @ J.T @ np.linalg.inv(J @ Minv @ J.T)
+    assert np.allclose(J @ Jbar, np.eye(6), atol=1e-10) and np.abs(N1 @ Jbar).max() < 1e-10
+    # E-2: the joint task produces zero task-1 acceleration
+    assert np.abs(J @ Minv @ det["task_tau"][1]).max() < 1e-9 * max(1.0, np.abs(det["task_tau"][1]).max())
+
+
+def test_E3_full_decoupling_unit_mass_force():
+    """FULL_DYNAMIC_DECOUPLING, single full task: J M^-1 tau = F_um"""
+    d = W.make_inputs(2, 4)
+    tasks = [W.motion_force_task("t", "end-effector", (0, 0, 0.07), decoupling=W.FULL_DYNAMIC_DECOUPLING)]
+    o = Oracle(d["model"], tasks)
+    i = 1
+    det = o.details(d["q"][i], d["dq"][i], [d["goals"][0][i]])
+    details = []
+    W.controller_step_single(d["model"], tasks, d["q"][i], d["dq"][i], [d["goals"][0][i]], details=details)
+    F_um = details[0]["F_um"]
+    J = details[0]["J"]
+    acc = J @ np.linalg.inv(det["M"]) @ det["tau"]
+    assert np.allclose(acc, F_um, rtol=1e-9, atol=1e-9)
+
+
+def test_E4_config1_closed_form():
+    """tau = M qdd_d + M_BIE f  """
+    d = W.make_inputs(1)
+    o = Oracle(d["model"], d["tasks"])
+    det = o.details(d["q"][0], d["dq"][0], [d["goals"][0][0]])
+    M = det["M"]
+    Mb = W.bie_mass(M, 0.1)
+    g = d["goals"][0][0]
+    f = -100.0 * (d["q"][0] - g[:7]) - 20.0 * (d["dq"][0] - g[7:14])
+    assert np.allclose(det["tau"], M @ g[14:21] + Mb @ f, rtol=1e-12, atol=1e-12)
+    assert np.abs(det["N"][0]).max() < 1e-12  # N = 0 for a full joint task at the top
+
+
+def test_E6_orientation_error_sign():
+    """positive kp_ori must reduce the orientation error in a one-step toy integration"""
+    d = W.make_inputs(2, 4)
+    model = d["model"]
+    tasks = [W.motion_force_task("t", "end-effector", (0, 0, 0.07), decoupling=W.FULL_DYNAMIC_DECOUPLING,
+                                 kp_pos=0.0, kv_pos=0.0, kv_ori=0.0)]
+    o = Oracle(model, tasks)
+    q = d["q"][0]
+    fr = W.fk(model, q[None])
+    li = model.link_index("end-effector")
+    Rc, oc = fr[li][0][0], fr[li][1][0]
+    x = oc + Rc @ np.array([0, 0, 0.07])
+    Rd = W._expm_so3(np.array([[0.0, 0.0, 0.3]]))[0] @ Rc
+    goal = np.concatenate([x, Rd.reshape(9), np.zeros(12)])
+    tau = o.details(q, np.zeros(7), [goal])["tau"]
+    M = W.mass_matrix(model, fr)[0]
+    ddq = np.linalg.solve(M, tau)
+    q2 = q + 0.5 * ddq * 1e-3 ** 2 * 100  # small step along the commanded acceleration
+    R2 = W.fk(model, q2[None])[li][0][0]
+    ang = lambda R: np.arccos(np.clip((np.trace(Rd.T @ R) - 1) / 2, -1, 1))
+    assert ang(R2) < ang(Rc)
+
+
+def test_E7_jacobian_finite_difference_and_kinetic_energy():
+    d = W.make_inputs(2, 2)
+    model = d["model"]
+    o = Oracle(model, d["tasks"])
+    det = o.details(d["q"][0], d["dq"][0], [g[0] for g in d["goals"]])
+    # kinetic energy: 1/2 dq^T M dq == sum_links (1/2 m |v_c|^2 + 1/2 w^T I w) via finite-difference body velocities
+    q, dq = d["q"][0], d["dq"][0]
+    eps = 1e-6
+    f0, f1 = W.fk(model, (q - eps * dq)[None]), W.fk(model, (q + eps * dq)[None])
+    fr = W.fk(model, q[None])
+    T = 0.0
+    for li, l in enumerate(model.links):
+        c0 = f0[li][1][0] + f0[li][0][0] @ np.array(l["com"])
+        c1 = f1[li][1][0] + f1[li][0][0] @ np.array(l["com"])
+        v = (c1 - c0) / (2 * eps)
+        dR = (f1[li][0][0] - f0[li][0][0]) / (2 * eps) @ fr[li][0][0].T
+        w = np.array([dR[2, 1], dR[0, 2], dR[1, 0]])
+        ixx, iyy, izz, ixy, ixz, iyz = l["inertia"]
+        I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+        Iw = fr[li][0][0] @ I @ fr[li][0][0].T
+        T += 0.5 * l["mass"] * v @ v + 0.5 * w @ Iw @ w
+    assert abs(0.5 * dq @ det["M"] @ dq - T) < 1e-7 * max(T, 1.0)
+
+
+def test_singular_pose_is_flagged():
+    """outstretched arm (q4 ~ 0): the motion-force task leaves the non-singular branch
+    (SingularityHandler.cpp:100-121) -> status 1, NaN torques (no silent wrong numbers)."""
+    d = W.make_inputs(2, 2)
+    q = d["q"].copy()
+    q[0] = np.array([0.0, 0.0, 0.0, -0.0698, 0.0, 0.0, 0.0])
+    tau, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"])
+    _, sn = W.controller_step(d["model"], d["tasks"], q, d["dq"], d["goals"])
+    assert st[0] == 1 and sn[0] == 1 and np.isnan(tau[0]).all()
+    assert st[1] == 0 and np.isfinite(tau[1]).all()
+
+
+def test_integrators_advance_like_reference():
+    """ki != 0: the integral terms accumulate over successive cycles (MotionForceTask.cpp:411-413,446; JointTask.cpp:323-324)"""
+    d = W.make_inputs(2, 4)
+    tasks = W.config_tasks(2)
+    tasks[0].update(ki_pos=5.0, ki_ori=7.0)
+    tasks[1].update(ki=3.0)
+    o = Oracle(d["model"], tasks)
+    states = [[dict(int_pos=np.zeros(3), int_ori=np.zeros(3)), dict(int_err=np.zeros(7))] for _ in range(4)]
+    for _ in range(3):
+        tau, _ = o.step(d["q"], d["dq"], d["goals"])
+        ref = np.stack([W.controller_step_single(d["model"], tasks, d["q"][b], d["dq"][b], [g[b] for g in d["goals"]],
+                                                 state=states[b]) for b in range(4)])
+        assert W.torque_error(tau, ref) < 1e-9

@@ -1,0 +1,601 @@
+"""Harness-only module: robot descriptions, the synthetic workload generator of
+SURVEY.md 8(d), and an independent NumPy restatement of the reference hot path.
+
+NOT part of the product path.  The product is the HIP engine behind include/saip.h;
+nothing in here is called by it.  This file is used by
+  * tests/ and tests/golden/make_golden.py (second, independent restatement that the C
+    oracle in oracle/ is cross-checked against),
+  * bench.py / tests to synthesise inputs (needs FK + Jacobian singular values for the
+    rejection sampling rule "resample while s_min/s_0 < 0.10").
+
+The restatement follows, literally (SVD path, explicit inverses):
+  /root/reference/src/RobotController.cpp:68-118
+  /root/reference/src/tasks/MotionForceTask.cpp:247-509, 892-971
+  /root/reference/src/tasks/SingularityHandler.cpp:75-228, 297-368
+  /root/reference/src/tasks/JointTask.cpp:218-356
+sai-model semantics (external, not in /root/reference) are restated from their algebraic
+definitions, SURVEY.md Appendix B.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROBOT_DIR = os.path.join(_HERE, "sai-primitives_amd", "robots")
+
+FULL_DYNAMIC_DECOUPLING = 0  # SaiPrimitivesCommonDefinitions.h:14-20
+BOUNDED_INERTIA_ESTIMATES = 1
+IMPEDANCE = 2
+
+
+# --------------------------------------------------------------------------- PRNG
+_MASK = (1 << 64) - 1
+
+
+def _sm64_mix(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+class SplitMix64Streams:
+    """One SplitMix64 stream per instance (instance-major generation).
+
+    Stream b is seeded with mix(seed + (b+1)*GOLDEN); every draw advances only that
+    instance's state, so rejection re-draws of one instance never shift another's."""
+
+    GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+    def __init__(self, seed: int, batch: int):
+        with np.errstate(over="ignore"):
+            b = np.arange(1, batch + 1, dtype=np.uint64)
+            self.state = _sm64_mix(np.uint64(seed & _MASK) + b * self.GOLDEN)
+
+    def uniform(self, mask=None) -> np.ndarray:
+        """next U[0,1) double per instance (only instances in `mask` advance)."""
+        with np.errstate(over="ignore"):
+            nxt = self.state + self.GOLDEN
+            out = _sm64_mix(nxt)
+        if mask is None:
+            self.state = nxt
+        else:
+            self.state = np.where(mask, nxt, self.state)
+        return (out >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def uniform_range(self, lo, hi, count, mask=None) -> np.ndarray:
+        """(B, count) draws in [lo, hi)."""
+        cols = [self.uniform(mask) for _ in range(count)]
+        u = np.stack(cols, axis=1)
+        return lo + (hi - lo) * u
+
+
+# --------------------------------------------------------------------------- model
+class RobotModel:
+    def __init__(self, desc: dict):
+        self.name = desc["name"]
+        self.links = desc["links"]
+        self.nl = len(self.links)
+        self.link_names = [l["name"] for l in self.links]
+        self.dof_of_link = []
+        n = 0
+        for l in self.links:
+            if l["joint_type"] == "fixed":
+                self.dof_of_link.append(-1)
+            else:
+                self.dof_of_link.append(n)
+                n += 1
+        self.dof = n
+        mov = [l for l in self.links if l["joint_type"] != "fixed"]
+        self.q_lower = np.array([l["q_lower"] for l in mov])
+        self.q_upper = np.array([l["q_upper"] for l in mov])
+        self.vel_limit = np.array([l["velocity_limit"] for l in mov])
+        self.effort = np.array([l["effort_limit"] for l in mov])
+        self.q_nominal = np.deg2rad(np.array([l.get("q_nominal_deg", 0.0) for l in mov]))
+
+    def link_index(self, name: str) -> int:
+        return self.link_names.index(name)
+
+
+def load_robot(name: str) -> RobotModel:
+    with open(os.path.join(ROBOT_DIR, name + ".json")) as f:
+        return RobotModel(json.load(f))
+
+
+def rot_rpy(rpy) -> np.ndarray:
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+
+
+def rodrigues(axis, q: np.ndarray) -> np.ndarray:
+    """(B,3,3) rotation about unit `axis` by q (B,)"""
+    a = np.asarray(axis, float)
+    a = a / np.linalg.norm(a)
+    K = _skew(a)
+    c = np.cos(q)[:, None, None]
+    s = np.sin(q)[:, None, None]
+    return np.eye(3)[None] + s * K[None] + (1 - c) * (K @ K)[None]
+
+
+def fk(model: RobotModel, q: np.ndarray):
+    """q (B,n) -> list of (R (B,3,3), o (B,3)) per link, world == base frame."""
+    B = q.shape[0]
+    R = np.broadcast_to(np.eye(3), (B, 3, 3)).copy()
+    o = np.zeros((B, 3))
+    out = []
+    for li, l in enumerate(model.links):
+        R0 = rot_rpy(l["origin_rpy"])
+        o = o + R @ np.asarray(l["origin_xyz"], float)
+        R = R @ R0
+        d = model.dof_of_link[li]
+        if l["joint_type"] == "revolute":
+            R = R @ rodrigues(l["axis"], q[:, d])
+        elif l["joint_type"] == "prismatic":
+            a = np.asarray(l["axis"], float)
+            o = o + (R @ a) * q[:, d][:, None]
+        out.append((R, o))
+    return out
+
+
+def jacobian(model: RobotModel, frames, link: int, p_world: np.ndarray) -> np.ndarray:
+    """(B,6,n) geometric Jacobian [Jv;Jw] of a point fixed in `link` (world frame)."""
+    B = p_world.shape[0]
+    J = np.zeros((B, 6, model.dof))
+    for li in range(link + 1):
+        d = model.dof_of_link[li]
+        if d < 0:
+            continue
+        R, o = frames[li]
+        z = R @ (np.asarray(model.links[li]["axis"], float) / np.linalg.norm(model.links[li]["axis"]))
+        if model.links[li]["joint_type"] == "revolute":
+            J[:, 0:3, d] = np.cross(z, p_world - o)
+            J[:, 3:6, d] = z
+        else:
+            J[:, 0:3, d] = z
+    return J
+
+
+def mass_matrix(model: RobotModel, frames) -> np.ndarray:
+    """M = sum_bodies m Jv^T Jv + Jw^T (R I R^T) Jw (Jacobian form; RBDL uses CRBA)."""
+    B = frames[0][0].shape[0]
+    n = model.dof
+    M = np.zeros((B, n, n))
+    for li, l in enumerate(model.links):
+        R, o = frames[li]
+        c = o + R @ np.asarray(l["com"], float)
+        J = jacobian(model, frames, li, c)
+        ixx, iyy, izz, ixy, ixz, iyz = l["inertia"]
+        I = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+        Iw = R @ I @ np.swapaxes(R, 1, 2)
+        Jv, Jw = J[:, :3], J[:, 3:]
+        M += l["mass"] * np.swapaxes(Jv, 1, 2) @ Jv + np.swapaxes(Jw, 1, 2) @ Iw @ Jw
+    return M
+
+
+def gravity_vector(model: RobotModel, frames, g=(0.0, 0.0, -9.81)) -> np.ndarray:
+    """jointGravityVector: tau_g = -sum_b m_b Jv_b^T g   (so that tau_g compensates gravity)."""
+    B = frames[0][0].shape[0]
+    tau = np.zeros((B, model.dof))
+    gv = np.asarray(g, float)
+    for li, l in enumerate(model.links):
+        R, o = frames[li]
+        c = o + R @ np.asarray(l["com"], float)
+        J = jacobian(model, frames, li, c)
+        tau -= l["mass"] * np.einsum("bij,i->bj", J[:, :3], gv)
+    return tau
+
+
+# ----------------------------------------------------------- sai-model style helpers
+def matrix_range_basis(A: np.ndarray, tol: float = 1e-3) -> np.ndarray:
+    """SaiModel::matrixRangeBasis [RECALLED]: zeros(rows,1) if ~0, identity if full row
+    rank, else the left singular vectors with sigma_i/sigma_0 >= tol."""
+    rows, cols = A.shape
+    if np.linalg.norm(A) < tol:
+        return np.zeros((rows, 1))
+    U, s, _ = np.linalg.svd(A, full_matrices=False)
+    if s[0] < tol:
+        return np.zeros((rows, 1))
+    task_dof = min(rows, cols)
+    for i in range(len(s) - 1, 0, -1):
+        if s[i] / s[0] < tol:
+            task_dof -= 1
+        else:
+            break
+    if task_dof == rows:
+        return np.eye(rows)
+    return U[:, :task_dof]
+
+
+def op_space_matrices(J, Minv):
+    Lam = np.linalg.inv(J @ Minv @ J.T)
+    Jbar = Minv @ J.T @ Lam
+    N = np.eye(Minv.shape[0]) - Jbar @ J
+    return Lam, Jbar, N
+
+
+def orientation_error(Rd, Rc):
+    """SaiModel::orientationError(desired, current) = -1/2 sum_i Rc[:,i] x Rd[:,i]"""
+    e = np.zeros(3)
+    for i in range(3):
+        e += np.cross(Rc[:, i], Rd[:, i])
+    return -0.5 * e
+
+
+def bie_mass(M, thr):
+    Mb = M.copy()
+    for i in range(M.shape[0]):
+        if Mb[i, i] < thr:
+            Mb[i, i] = thr
+    return Mb
+
+
+# --------------------------------------------------------------------------- tasks
+def motion_force_task(name, link, pos_in_link=(0, 0, 0), rot_in_link=None, dirs_trans=None,
+                      dirs_rot=None, **kw):
+    """Task spec; defaults = MotionForceTask.h:40-75 with OTG disabled."""
+    t = dict(type="motion_force", name=name, link=link, pos_in_link=list(map(float, pos_in_link)),
+             rot_in_link=(np.eye(3) if rot_in_link is None else np.asarray(rot_in_link, float)).tolist(),
+             dirs_trans=dirs_trans, dirs_rot=dirs_rot,
+             kp_pos=100.0, kv_pos=20.0, ki_pos=0.0, kp_ori=200.0, kv_ori=28.3, ki_ori=0.0,
+             decoupling=BOUNDED_INERTIA_ESTIMATES, bie_threshold=0.1, s_min=6e-3, s_max=6e-2,
+             dt=0.001)
+    t.update(kw)
+    return t
+
+
+def joint_task(name, S=None, **kw):
+    """Task spec; defaults = JointTask.h:31-45 with OTG disabled. S = list of rows or None."""
+    t = dict(type="joint", name=name, S=S, kp=50.0, kv=14.0, ki=0.0,
+             decoupling=BOUNDED_INERTIA_ESTIMATES, bie_threshold=0.1, dt=0.001)
+    t.update(kw)
+    return t
+
+
+def mf_projection(task):
+    """Partial task projector P (6x6) and task range basis (6xk), MotionForceTask.cpp:28, 55-87, 143-168."""
+    if task["dirs_trans"] is None and task["dirs_rot"] is None:
+        P = np.eye(6)
+    else:
+        bt = np.zeros((3, 1))
+        br = np.zeros((3, 1))
+        if task["dirs_trans"]:
+            bt = matrix_range_basis(np.array(task["dirs_trans"], float).T)
+        if task["dirs_rot"]:
+            br = matrix_range_basis(np.array(task["dirs_rot"], float).T)
+        P = np.zeros((6, 6))
+        P[:3, :3] = bt @ bt.T
+        P[3:, 3:] = br @ br.T
+    rp = matrix_range_basis(P[:3, :3])
+    ro = matrix_range_basis(P[3:, 3:])
+    pr = 0 if np.linalg.norm(rp) == 0 else rp.shape[1]
+    orr = 0 if np.linalg.norm(ro) == 0 else ro.shape[1]
+    Bm = np.zeros((6, pr + orr))
+    if pr:
+        Bm[:3, :pr] = rp
+    if orr:
+        Bm[3:, pr:] = ro
+    return P, Bm, pr, orr
+
+
+def joint_selection(task, n):
+    if task["S"] is None:
+        return np.eye(n)
+    S = np.asarray(task["S"], float)
+    if S.ndim == 1:  # list of joint indices
+        rows = [int(i) for i in S]
+        S = np.zeros((len(rows), n))
+        for r, i in enumerate(rows):
+            S[r, i] = 1.0
+    return S
+
+
+def goal_size(task, n):
+    if task["type"] == "motion_force":
+        return 24  # x3, R9 (row-major), v3, w3, a3, alpha3
+    return 3 * joint_selection(task, n).shape[0]
+
+
+# --------------------------------------------------- literal single-instance controller
+class Singular(Exception):
+    pass
+
+
+def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_comp=False,
+                           torque_saturation=False, details=None):
+    """One control cycle for ONE instance, literal reference path (SVDs, explicit inverses).
+    goals[t]: flat vector (goal_size).  Returns tau (n,).  Raises Singular when an instance
+    leaves the non-singular branch of SingularityHandler (alpha != 1)."""
+    n = model.dof
+    frames = fk(model, q[None])
+    M = mass_matrix(model, frames)[0]
+    Minv = np.linalg.inv(M)
+    frames1 = [(R[0], o[0]) for R, o in frames]
+
+    # ---- updateControllerTaskModels, RobotController.cpp:68-77
+    N_prec = np.eye(n)
+    tm = []
+    for t in tasks:
+        if t["type"] == "motion_force":
+            li = model.link_index(t["link"]) if isinstance(t["link"], str) else t["link"]
+            R_l, o_l = frames1[li]
+            p = o_l + R_l @ np.asarray(t["pos_in_link"])
+            P, Bm, pr, orr = mf_projection(t)
+            k = pr + orr
+            Jw = jacobian(model, frames, li, p[None])[0]
+            J = P @ Jw                                              # MotionForceTask.cpp:261-263
+            Jp = J @ N_prec                                         # :264
+            U, s, Vt = np.linalg.svd(Jp, full_matrices=False)       # SingularityHandler.cpp:78-81
+            if s[0] < 1e-3:
+                raise Singular("fully singular")
+            if k == 1:
+                raise Singular("rank-1 motion force task unsupported (SURVEY App. C-4)")
+            for i in range(1, k):
+                if s[i] / s[0] < t["s_max"]:
+                    raise Singular("blending region")               # :100-121
+            U_ns = U[:, :k]                                          # :128
+            J_ns = U_ns.T @ Jp
+            Lam, Jbar, N = op_space_matrices(J_ns, Minv)             # :130-134
+            if t["decoupling"] == FULL_DYNAMIC_DECOUPLING:
+                Lam_mod = Lam
+            elif t["decoupling"] == IMPEDANCE:
+                Lam_mod = np.eye(k)
+            else:
+                Mb = bie_mass(M, t["bie_threshold"])                 # :175-193
+                Lam_mod = np.linalg.inv(J_ns @ np.linalg.inv(Mb) @ J_ns.T)
+            tm.append(dict(J=J, Jp=Jp, U_ns=U_ns, J_ns=J_ns, Lam=Lam, Lam_mod=Lam_mod, N=N,
+                           N_prec=N_prec, P=P, R=R_l @ np.asarray(t["rot_in_link"]), x=p, sv=s))
+            N_prec = N @ N_prec                                      # MotionForceTask.h:207-209
+        else:
+            S = joint_selection(t, n)
+            Jp = S @ N_prec                                          # JointTask.cpp:231
+            U = matrix_range_basis(Jp)                               # :233
+            if np.linalg.norm(U) == 0:
+                tm.append(dict(empty=True, N=np.eye(n), N_prec=N_prec))
+                N_prec = N_prec.copy()
+                continue
+            Jh = U.T @ Jp
+            Lam, _, N = op_space_matrices(Jh, Minv)                  # :241-245
+            if t["decoupling"] == FULL_DYNAMIC_DECOUPLING:
+                Lam_mod = Lam
+            elif t["decoupling"] == IMPEDANCE:
+                Lam_mod = np.eye(U.shape[1])
+            else:
+                Mb = bie_mass(M, t["bie_threshold"])
+                Lam_mod = np.linalg.inv(U.T @ Jp @ np.linalg.inv(Mb) @ Jp.T @ U)  # :253-267
+            tm.append(dict(empty=False, S=S, Jp=Jp, U=U, Lam=Lam, Lam_mod=Lam_mod, N=N, N_prec=N_prec))
+            N_prec = N @ N_prec
+
+    # ---- computeControlTorques, RobotController.cpp:79-118
+    tau = np.zeros(n)
+    for ti, (t, m) in enumerate(zip(tasks, tm)):
+        g = np.asarray(goals[ti], float)
+        st = None if state is None else state[ti]
+        if t["type"] == "motion_force":
+            xd, Rd = g[0:3], g[3:12].reshape(3, 3)
+            vd, wd, ad, ald = g[12:15], g[15:18], g[18:21], g[21:24]
+            J, P = m["J"], m["P"]
+            v = J[:3] @ dq                                           # MotionForceTask.cpp:293-298
+            w = J[3:] @ dq
+            sig_p = P[:3, :3] @ np.eye(3) @ P[:3, :3].T              # :927-930 (sigma_force = 0)
+            sig_o = P[3:, 3:] @ np.eye(3) @ P[3:, 3:].T
+            kp, kv, ki = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_pos", "kv_pos", "ki_pos"))
+            kpo, kvo, kio = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_ori", "kv_ori", "ki_ori"))
+            ipos = np.zeros(3) if st is None else st["int_pos"]
+            iori = np.zeros(3) if st is None else st["int_ori"]
+            ipos = ipos + sig_p @ (m["x"] - xd) * t["dt"]             # :411-413
+            F_p = sig_p @ (ad - kp @ (m["x"] - xd) - kv @ (v - vd) - ki @ ipos)   # :431-437
+            dphi = sig_o @ orientation_error(Rd, m["R"])             # :441-443
+            iori = iori + dphi * t["dt"]                             # :446
+            F_o = sig_o @ (ald - kpo @ dphi - kvo @ (w - wd) - kio @ iori)        # :463-468
+            if st is not None:
+                st["int_pos"], st["int_ori"] = ipos, iori
+            F_um = np.concatenate([F_p, F_o])
+            F_f = np.zeros(6)                                        # sigma_force = sigma_moment = 0
+            tt = m["J_ns"].T @ (m["Lam_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)  # SH.cpp:307-309
+            # computeTorques(tau_prec): _Lambda is never written => compensation == 0 (App. C-1)
+            tau = tau + tt
+            if details is not None:
+                details.append(dict(F_um=F_um, tau=tt, **m))
+        else:
+            if m["empty"]:
+                if details is not None:
+                    details.append(dict(tau=np.zeros(n), **m))
+                continue
+            S, U, Jp = m["S"], m["U"], m["Jp"]
+            mm = S.shape[0]
+            qd, dqd, ddqd = g[0:mm], g[mm:2 * mm], g[2 * mm:3 * mm]
+            kp, kv, ki = (np.diag(np.broadcast_to(t[k_], mm)) for k_ in ("kp", "kv", "ki"))
+            e = S @ q - qd
+            ie = np.zeros(mm) if st is None else st["int_err"]
+            ie = ie + e * t["dt"]                                    # JointTask.cpp:323-324
+            if st is not None:
+                st["int_err"] = ie
+            f = -kp @ e - kv @ (S @ dq - dqd) - ki @ ie              # :342-345
+            tr = m["Lam"] @ U.T @ ddqd + m["Lam_mod"] @ U.T @ f      # :348-351
+            tt = Jp.T @ U @ tr                                       # :354-355
+            comp = Jp.T @ U @ m["Lam"] @ U.T @ S @ Minv @ tau        # :287-291
+            tt = tt - comp
+            tau = tau + tt
+            if details is not None:
+                details.append(dict(tau=tt, **m))
+    if torque_saturation:
+        tau = np.clip(tau, -model.effort, model.effort)              # RobotController.cpp:86-94
+    if gravity_comp:
+        tau = tau + gravity_vector(model, frames)[0]                 # :114-116
+    return tau
+
+
+def controller_step(model, tasks, q, dq, goals, **kw):
+    """Batched wrapper. q,dq (B,n); goals[t] (B, goal_size). Returns tau (B,n), status (B,) uint8."""
+    B = q.shape[0]
+    tau = np.full((B, model.dof), np.nan)
+    status = np.zeros(B, np.uint8)
+    for b in range(B):
+        try:
+            tau[b] = controller_step_single(model, tasks, q[b], dq[b], [g[b] for g in goals], **kw)
+        except Singular:
+            status[b] = 1
+    return tau, status
+
+
+# ------------------------------------------------------------------ workload synthesis
+def _expm_so3(w: np.ndarray) -> np.ndarray:
+    """(B,3) rotation vectors -> (B,3,3)"""
+    th = np.linalg.norm(w, axis=1)
+    out = np.empty((w.shape[0], 3, 3))
+    for b in range(w.shape[0]):
+        if th[b] < 1e-12:
+            out[b] = np.eye(3)
+        else:
+            K = _skew(w[b] / th[b])
+            out[b] = np.eye(3) + np.sin(th[b]) * K + (1 - np.cos(th[b])) * K @ K
+    return out
+
+
+CONFIGS = {
+    1: dict(robot="panda_arm", batch=1, desc="single Panda JointTask PD (example 01 scenario)"),
+    2: dict(robot="panda_arm", batch=4096, desc="Panda, full MotionForceTask + full JointTask"),
+    3: dict(robot="panda_arm", batch=4096, desc="Panda, 3-dof position MotionForceTask + partial JointTask rows {0,2,4,6}"),
+    4: dict(robot="panda_arm", batch=65536, desc="config-2 tasks, 8 shards"),
+    5: dict(robot="chain30", batch=4096, desc="30-DoF chain, MotionForce(link30) + MotionForce(link15) + posture JointTask"),
+    # extra parity scenarios (not BASELINE configs)
+    6: dict(robot="panda_sliding_base", batch=256, desc="8-DoF sliding-base Panda, partial JointTask {0,7} above a full MotionForceTask (examples/06)"),
+    7: dict(robot="panda_arm", batch=256, desc="Panda, orientation-only MotionForceTask (examples/09 style) + full JointTask, anisotropic gains, FULL_DYNAMIC_DECOUPLING"),
+    8: dict(robot="panda_arm", batch=256, desc="Panda, planar (2 translation + 1 rotation dirs, non axis-aligned) MotionForceTask + JointTask, IMPEDANCE"),
+}
+
+
+def config_tasks(cfg: int):
+    if cfg == 1:
+        return [joint_task("joint_task", kp=100.0, kv=20.0)]          # examples/01-joint_control:133
+    if cfg in (2, 4):
+        return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07)),  # examples/05:111-117
+                joint_task("joint_task")]
+    if cfg == 3:
+        return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07),
+                                  dirs_trans=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], dirs_rot=None),  # examples/09:114-121
+                joint_task("partial_joint_task", S=[0, 2, 4, 6])]
+    if cfg == 5:
+        return [motion_force_task("hand_task", "link30", (0, 0, 0.1)),
+                motion_force_task("elbow_task", "link15", (0, 0, 0.1)),
+                joint_task("posture_task")]
+    if cfg == 6:
+        return [joint_task("partial_joint_task", S=[0, 7]),                                   # examples/06:107-112
+                motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07))]
+    if cfg == 7:
+        return [motion_force_task("ori_task", "end-effector", (0, 0, 0.07), dirs_trans=None,
+                                  dirs_rot=[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                                  kp_ori=[150.0, 200.0, 250.0], kv_ori=[20.0, 28.3, 30.0], ki_ori=[0.0, 0.0, 0.0],
+                                  decoupling=FULL_DYNAMIC_DECOUPLING),
+                joint_task("joint_task", kp=[50, 60, 70, 80, 90, 100, 110], kv=[14, 15, 16, 17, 18, 19, 20],
+                           ki=[0, 0, 0, 0, 0, 0, 0], decoupling=FULL_DYNAMIC_DECOUPLING)]
+    if cfg == 8:
+        return [motion_force_task("planar_task", "link7", (0.05, 0.0, 0.1),
+                                  dirs_trans=[[1, 1, 0], [0, 0, 1], [2, 2, 1]], dirs_rot=[[1, -1, 0.5]],
+                                  decoupling=IMPEDANCE),
+                joint_task("joint_task", decoupling=IMPEDANCE)]
+    raise ValueError(cfg)
+
+
+def _task_sv_ratio(model, tasks, q):
+    """min over MotionForce tasks of s_min/s_0 of the projected task Jacobian (batched)."""
+    B, n = q.shape
+    frames = fk(model, q)
+    last_mf = max(i for i, t in enumerate(tasks) if t["type"] == "motion_force")
+    need_N = last_mf > 0
+    Minv = np.linalg.inv(mass_matrix(model, frames)) if need_N else None
+    N_prec = np.broadcast_to(np.eye(n), (B, n, n))
+    ratio = np.full(B, np.inf)
+    for ti, t in enumerate(tasks[:last_mf + 1]):
+        if t["type"] != "motion_force":
+            # joint task above a motion-force task: selection rows are full row rank under N_prec here
+            S = joint_selection(t, n)
+            Jh = S[None] @ N_prec
+            Lam = np.linalg.inv(Jh @ Minv @ np.swapaxes(Jh, 1, 2))
+            N_prec = (np.eye(n)[None] - Minv @ np.swapaxes(Jh, 1, 2) @ Lam @ Jh) @ N_prec
+            continue
+        li = model.link_index(t["link"])
+        R_l, o_l = frames[li]
+        p = o_l + R_l @ np.asarray(t["pos_in_link"])
+        _, Bm, pr, orr = mf_projection(t)
+        Jh = np.einsum("ik,bin->bkn", Bm, jacobian(model, frames, li, p)) @ N_prec
+        s = np.linalg.svd(Jh, compute_uv=False)
+        ratio = np.minimum(ratio, s[:, -1] / s[:, 0])
+        if need_N and ti < last_mf:
+            Lam = np.linalg.inv(Jh @ Minv @ np.swapaxes(Jh, 1, 2))
+            N = np.eye(n)[None] - Minv @ np.swapaxes(Jh, 1, 2) @ Lam @ Jh
+            N_prec = N @ N_prec
+    return ratio
+
+
+def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio: float = 0.10):
+    """Synthetic inputs of SURVEY.md 8(d). Returns dict(model, tasks, q, dq, goals).
+    `shard` offsets the instance index so that rank r of a sharded run draws instances
+    [r*batch, (r+1)*batch) of the same global stream."""
+    model = load_robot(CONFIGS[cfg]["robot"])
+    tasks = config_tasks(cfg)
+    B = CONFIGS[cfg]["batch"] if batch is None else batch
+    n = model.dof
+    seed = 0x5A10000 + (2 if cfg == 4 else cfg)
+    rng = SplitMix64Streams(seed, B * (shard + 1))
+    rng.state = rng.state[shard * B:]
+    if cfg == 1:
+        q = model.q_nominal[None].copy()
+        dq = np.zeros((1, n))
+        qg = q + np.array([[0, 0, 0.4, -0.6, 0, 0, 0]])             # mirrors examples/01:158-161
+        return dict(model=model, tasks=tasks, q=q, dq=dq,
+                    goals=[np.concatenate([qg, np.zeros((1, n)), np.zeros((1, n))], axis=1)])
+    rngq = model.q_upper - model.q_lower
+    lo, hi = model.q_lower + 0.15 * rngq, model.q_upper - 0.15 * rngq
+    q = lo + (hi - lo) * rng.uniform_range(0.0, 1.0, n)
+    has_mf = any(t["type"] == "motion_force" for t in tasks)
+    if has_mf:
+        for _ in range(200):
+            bad = _task_sv_ratio(model, tasks, q) < min_ratio
+            if not bad.any():
+                break
+            qn = lo + (hi - lo) * rng.uniform_range(0.0, 1.0, n, mask=bad)
+            q = np.where(bad[:, None], qn, q)
+        else:
+            raise RuntimeError("rejection sampling did not converge")
+    dq = rng.uniform_range(-0.5, 0.5, n)
+    frames = fk(model, q)
+    goals = []
+    for t in tasks:
+        if t["type"] == "motion_force":
+            li = model.link_index(t["link"])
+            R_l, o_l = frames[li]
+            x = o_l + R_l @ np.asarray(t["pos_in_link"])
+            Rc = R_l @ np.asarray(t["rot_in_link"])
+            xg = x + rng.uniform_range(-0.05, 0.05, 3)
+            Rg = _expm_so3(rng.uniform_range(-0.2, 0.2, 3)) @ Rc
+            vg = rng.uniform_range(-0.1, 0.1, 3)
+            wg = rng.uniform_range(-0.1, 0.1, 3)
+            ag = rng.uniform_range(-0.5, 0.5, 3)
+            alg = rng.uniform_range(-0.5, 0.5, 3)
+            goals.append(np.concatenate([xg, Rg.reshape(B, 9), vg, wg, ag, alg], axis=1))
+        else:
+            S = joint_selection(t, n)
+            m = S.shape[0]
+            qg = q @ S.T + rng.uniform_range(-0.3, 0.3, m)
+            dqg = rng.uniform_range(-0.1, 0.1, m)
+            ddqg = rng.uniform_range(-0.5, 0.5, m)
+            goals.append(np.concatenate([qg, dqg, ddqg], axis=1))
+    return dict(model=model, tasks=tasks, q=q, dq=dq, goals=goals)
+
+
+def torque_error(tau, tau_ref):
+    """max over instances/joints of |tau-tau_ref| / max(|tau_ref|, 1e-3*||tau_ref||_inf)."""
+    tau, tau_ref = np.asarray(tau), np.asarray(tau_ref)
+    scale = np.maximum(np.abs(tau_ref), 1e-3 * np.max(np.abs(tau_ref), axis=-1, keepdims=True))
+    return float(np.max(np.abs(tau - tau_ref) / scale))
