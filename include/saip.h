@@ -1,0 +1,189 @@
+/*
+ * saip.h -- C-ABI of the MI355X-native batched operational-space control engine.
+ *
+ * The reference (manips-sai-org/sai-primitives) has no FFI/plugin layer: its drop-in boundary for the
+ * hot path is the public C++ class API
+ *     TemplateTask        /root/reference/src/tasks/TemplateTask.h:43-116
+ *     MotionForceTask     /root/reference/src/tasks/MotionForceTask.h:96-110, 211-247, 272-300, 423, 670-736
+ *     JointTask           /root/reference/src/tasks/JointTask.h:56-75, 140-175, 237-257, 323, 363
+ *     RobotController     /root/reference/src/RobotController.h:47-90
+ * driven once per control cycle as  robot->updateModel(); updateControllerTaskModels(); <set goals>;
+ * computeControlTorques()  (/root/reference/examples/05-using_robot_controller/05-using_robot_controller.cpp:143-196).
+ * This header is what a binding for that path would bind: one entry point per reference call, in a batched
+ * flavour (B independent robot instances evaluated by one GPU launch).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - FP64 everywhere.  All per-instance arrays are struct-of-arrays: field component c of instance b lives
+ *     at  ptr[c * ld + b]  where ld = saip_batch_ld(batch) (>= B, padded for alignment) for DEVICE arrays and
+ *     ld = B for HOST arrays passed to the *_host setters/getters.
+ *   - batch-uniform configuration (gains, flags, task definitions) mirrors the reference setters 1:1.
+ *   - errors: status codes; saip_last_error() returns the text the reference would have thrown as
+ *     std::invalid_argument (thread-local).  Nothing is computed on the CPU: every compute entry point
+ *     fails with SAIP_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef SAIP_H_
+#define SAIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAIP_MAX_DOF 32
+#define SAIP_MAX_TASKS 8
+#define SAIP_NAME_LEN 48
+
+typedef struct saip_model saip_model;
+typedef struct saip_batch saip_batch;
+
+typedef enum {
+	SAIP_OK = 0,
+	SAIP_ERR_INVALID_ARGUMENT = 1, /* what the reference reports by throwing std::invalid_argument */
+	SAIP_ERR_UNSUPPORTED = 2,      /* valid in the reference, not (yet) implemented by the engine: fails loudly */
+	SAIP_ERR_NO_DEVICE = 3,
+	SAIP_ERR_DEVICE = 4,           /* HIP runtime error */
+	SAIP_ERR_ORDER = 5             /* call-order contract violated (e.g. compute before update) */
+} saip_status;
+
+typedef enum { SAIP_JOINT_FIXED = 0, SAIP_JOINT_REVOLUTE = 1, SAIP_JOINT_PRISMATIC = 2 } saip_joint_type;
+
+/* SaiPrimitives::TaskType, TemplateTask.h:19-24 */
+typedef enum { SAIP_TASK_UNDEFINED = 0, SAIP_TASK_JOINT_LIMIT_AVOIDANCE = 1, SAIP_TASK_JOINT = 2, SAIP_TASK_MOTION_FORCE = 3 } saip_task_type;
+
+/* SaiPrimitives::DynamicDecouplingType, helper_modules/SaiPrimitivesCommonDefinitions.h:14-20 (same values) */
+typedef enum { SAIP_FULL_DYNAMIC_DECOUPLING = 0, SAIP_BOUNDED_INERTIA_ESTIMATES = 1, SAIP_IMPEDANCE = 2 } saip_decoupling_type;
+
+/* per-instance status written by a cycle */
+enum { SAIP_INSTANCE_OK = 0, SAIP_INSTANCE_SINGULAR = 1 /* left SingularityHandler's non-singular branch: torques = NaN */ };
+
+/* One URDF link + the joint that attaches it to its parent (what sai-model/sai-urdfreader read from a URDF).
+ * Link i's parent is link i-1 (serial chain); link 0 hangs off the fixed base.  Fixed links are merged into
+ * their parent for dynamics (as RBDL does) and stay addressable by name for kinematics. */
+typedef struct saip_link_desc {
+	char name[SAIP_NAME_LEN];
+	int joint_type;        /* saip_joint_type */
+	double origin_xyz[3];  /* <origin xyz> of the joint: child frame in parent frame */
+	double origin_rpy[3];  /* <origin rpy>: fixed-axis roll, pitch, yaw */
+	double axis[3];        /* <axis xyz>, in the child frame */
+	double mass;
+	double com[3];         /* <inertial><origin xyz> */
+	double inertia[6];     /* ixx iyy izz ixy ixz iyz about the COM, link axes */
+	double q_lower, q_upper, velocity_limit, effort_limit; /* <limit> */
+} saip_link_desc;
+
+/* ---------------------------------------------------------------- robot model (constants only; replaces the
+ * SaiModel constructor + URDF parse; the per-cycle SaiModel::updateModel() is part of the GPU cycle) */
+saip_status saip_model_create_serial_chain(const saip_link_desc* links, int n_links, saip_model** out);
+void saip_model_destroy(saip_model* model);
+int saip_model_dof(const saip_model* model);                               /* SaiModel::dof() */
+int saip_model_link_index(const saip_model* model, const char* link_name); /* -1 when absent */
+saip_status saip_model_joint_limits(const saip_model* model, double* q_lower, double* q_upper, double* velocity,
+									double* effort);                       /* SaiModel::jointLimits() */
+
+/* ---------------------------------------------------------------- batch = B robots + one RobotController each */
+/* device: HIP device ordinal.  The engine owns one stream and all device buffers of the batch. */
+saip_status saip_batch_create(const saip_model* model, int batch_size, int device, saip_batch** out);
+void saip_batch_destroy(saip_batch* batch);
+int saip_batch_size(const saip_batch* batch);
+int saip_batch_ld(const saip_batch* batch); /* leading dimension (instances) of device SoA arrays */
+
+/* MotionForceTask constructors, MotionForceTask.h:96-110 / MotionForceTask.cpp:16-89.
+ * n_trans < 0 && n_rot < 0: full 6-dof task; otherwise dirs_* hold n_* controlled direction vectors (3 doubles
+ * each).  rot_in_link may be NULL (identity compliant frame rotation).  Task order = hierarchy order. */
+saip_status saip_batch_add_motion_force_task(saip_batch* batch, const char* task_name, const char* link_name,
+											 const double pos_in_link[3], const double rot_in_link[9],
+											 const double* dirs_trans, int n_trans, const double* dirs_rot, int n_rot,
+											 double loop_timestep, int* task_id);
+/* JointTask constructors, JointTask.h:56-75 / JointTask.cpp:14-43.  rows == 0: full joint task (S = I). */
+saip_status saip_batch_add_joint_task(saip_batch* batch, const char* task_name, const double* joint_selection /*rows x dof*/,
+									  int rows, double loop_timestep, int* task_id);
+/* RobotController constructor validation, RobotController.cpp:8-66 (>=1 task, equal loop timesteps, unique
+ * names, nothing after a full joint task); allocates the device arena.  Must precede any state/goal/cycle call. */
+saip_status saip_batch_finalize(saip_batch* batch);
+
+int saip_batch_task_count(const saip_batch* batch);
+int saip_batch_task_type(const saip_batch* batch, int task_id);   /* TemplateTask::getTaskType */
+const char* saip_batch_task_name(const saip_batch* batch, int task_id); /* TemplateTask::getTaskName / getTaskNames */
+int saip_batch_task_by_name(const saip_batch* batch, const char* name); /* get{Joint,MotionForce}TaskByName; -1 when absent */
+int saip_batch_task_dof(const saip_batch* batch, int task_id);    /* JointTask::getTaskDof (rows of S); 6-dof projector rank for motion-force */
+int saip_batch_goal_components(const saip_batch* batch, int task_id); /* 24 (x3,R9 row-major,v3,w3,a3,alpha3) or 3*m (q,dq,ddq) */
+/* MotionForceTask partial task projection P (6x6 row-major, MotionForceTask.cpp:55-87) and the orthonormal basis of
+ * range(P) the engine works in (6x6 row-major, first *rank columns valid; = _current_task_range, :162-168) */
+saip_status saip_batch_get_task_projection(const saip_batch* batch, int task_id, double* P36, double* basis36, int* rank);
+
+/* ---- batch-uniform task configuration (reference setters; defaults = the reference DefaultParameters) */
+/* MotionForceTask::setPosControlGains / setOriControlGains (.h:272-300): n_gains = 1 (isotropic) or 3 */
+saip_status saip_batch_set_pos_control_gains(saip_batch*, int task, const double* kp, const double* kv, const double* ki, int n_gains);
+saip_status saip_batch_set_ori_control_gains(saip_batch*, int task, const double* kp, const double* kv, const double* ki, int n_gains);
+/* JointTask::setGains (.h:237-257): n_gains = 1 or task dof */
+saip_status saip_batch_set_joint_gains(saip_batch*, int task, const double* kp, const double* kv, const double* ki, int n_gains);
+/* setDynamicDecouplingType (.h:670 / JointTask.h:363), setBoundedInertiaEstimateThreshold (.h:679 / JointTask.h:372) */
+saip_status saip_batch_set_dynamic_decoupling_type(saip_batch*, int task, int type);
+saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold);
+/* MotionForceTask::setSingularityHandlingBounds (.h:736) */
+saip_status saip_batch_set_singularity_bounds(saip_batch*, int task, double s_min, double s_max);
+/* disableInternalOtg / enableInternalOtg* (.h:423, JointTask.h:323).  The reference default is ENABLED; the engine
+ * has no on-device OTG yet, so a cycle with OTG enabled on any task fails with SAIP_ERR_UNSUPPORTED. */
+saip_status saip_batch_set_internal_otg(saip_batch*, int task, int enabled);
+/* velocity saturation (MotionForceTask.h enable/disableVelocitySaturation, JointTask.h): enabled -> SAIP_ERR_UNSUPPORTED */
+saip_status saip_batch_set_velocity_saturation(saip_batch*, int task, int enabled);
+/* RobotController::enable{GravityCompensation,JointLimitAvoidance,TorqueSaturation}, RobotController.h:64-75 */
+saip_status saip_batch_enable_gravity_compensation(saip_batch*, int enabled);
+saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* enabled -> SAIP_ERR_UNSUPPORTED (next row) */
+saip_status saip_batch_enable_torque_saturation(saip_batch*, int enabled);
+/* integrator state policy: 0 = advance the integral terms only while the task's ki != 0 (default; elides the
+ * state traffic), 1 = advance every cycle like the reference does (MotionForceTask.cpp:411-413,446; JointTask.cpp:323) */
+saip_status saip_batch_set_integrator_tracking(saip_batch*, int always);
+
+/* ---- per-instance inputs (host staging: H2D copies on the engine stream) */
+saip_status saip_batch_set_state_host(saip_batch*, const double* q /*[dof][B]*/, const double* dq /*[dof][B]*/); /* setQ/setDq */
+/* whole goal block of a task, [goal_components][B]: setGoalPosition/Orientation/LinearVelocity/AngularVelocity/
+ * LinearAcceleration/AngularAcceleration (MotionForceTask.h:211-247) or setGoalPosition/Velocity/Acceleration (JointTask.h:140-175) */
+saip_status saip_batch_set_goal_host(saip_batch*, int task, const double* goal);
+/* one goal field: component offset/count inside the goal block (e.g. position: 0,3; orientation: 3,9) */
+saip_status saip_batch_set_goal_field_host(saip_batch*, int task, int first_component, int n_components, const double* values);
+saip_status saip_batch_get_goal_host(saip_batch*, int task, double* goal);
+/* TemplateTask::reInitializeTask / RobotController::reinitializeTasks: goal := current pose of every instance,
+ * velocities/accelerations := 0, integrators := 0 (MotionForceTask.cpp:204-245, JointTask.cpp:91-107). GPU kernel. */
+saip_status saip_batch_reinitialize_tasks(saip_batch*);
+
+/* ---- zero-copy access for resident pipelines (simulator / rollout on the same GPU) */
+double* saip_batch_device_q(saip_batch*);
+double* saip_batch_device_dq(saip_batch*);
+double* saip_batch_device_goal(saip_batch*, int task);
+double* saip_batch_device_tau(saip_batch*);          /* [dof][ld] */
+uint8_t* saip_batch_device_status(saip_batch*);      /* [ld] */
+/* write torques to a caller-owned device buffer (e.g. a torch tensor used for the RCCL gather); NULL restores the internal one */
+saip_status saip_batch_bind_tau_device(saip_batch*, double* tau_dev /*[dof][ld]*/);
+void* saip_batch_stream(saip_batch*);                /* hipStream_t */
+
+/* ---- the control cycle */
+/* robot->updateModel() + RobotController::updateControllerTaskModels() (RobotController.cpp:68-77) */
+saip_status saip_batch_update_task_models(saip_batch*);
+/* RobotController::computeControlTorques() (RobotController.cpp:79-118); requires update_task_models since the last
+ * state change.  tau_host may be NULL (results stay on the device); status_host may be NULL. */
+saip_status saip_batch_compute_control_torques(saip_batch*, double* tau_host /*[dof][B]*/, uint8_t* status_host /*[B]*/);
+/* both of the above as ONE asynchronous launch on the engine stream; no host synchronisation */
+saip_status saip_batch_step_async(saip_batch*);
+saip_status saip_batch_synchronize(saip_batch*);
+saip_status saip_batch_get_torques_host(saip_batch*, double* tau_host, uint8_t* status_host);
+/* per-task diagnostics of the last cycle, for parity tests of the task models: TemplateTask::getTaskNullspace()
+ * ([dof*dof][B] row-major per instance). Re-runs the cycle with the diagnostic kernel variant. */
+saip_status saip_batch_get_task_nullspace_host(saip_batch*, int task, double* N /*[dof*dof][B]*/);
+
+/* kernel selection: 0 = auto, 1 = general workgroup-per-instance kernel, 2 = lane-per-instance register kernel (dof <= 8) */
+saip_status saip_batch_set_kernel(saip_batch*, int which);
+const char* saip_batch_kernel_name(saip_batch*);
+/* HIP-event timing of `steps` back-to-back cycles on the engine stream (after `warmup` untimed ones):
+ * total elapsed ms over the timed region.  Used by bench.py for the live roofline figure. */
+saip_status saip_batch_time_steps(saip_batch*, int steps, int warmup, double* elapsed_ms);
+
+const char* saip_last_error(void);
+const char* saip_version(void);
+int saip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAIP_H_ */

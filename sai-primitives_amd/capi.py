@@ -1,0 +1,142 @@
+"""ctypes binding of include/saip.h.  Fails loudly when libsaip.so has not been built."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libsaip.so")
+SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip"]
+HEADERS = ["csrc/saip_device.h", "../include/saip.h"]
+
+SAIP_OK, SAIP_ERR_INVALID_ARGUMENT, SAIP_ERR_UNSUPPORTED, SAIP_ERR_NO_DEVICE, SAIP_ERR_DEVICE, SAIP_ERR_ORDER = range(6)
+NAME_LEN = 48
+
+
+class SaipError(RuntimeError):
+    pass
+
+
+class SaipUnsupported(NotImplementedError):
+    pass
+
+
+class SaipNoDevice(RuntimeError):
+    pass
+
+
+class LinkDesc(C.Structure):
+    _fields_ = [("name", C.c_char * NAME_LEN), ("joint_type", C.c_int), ("origin_xyz", C.c_double * 3),
+                ("origin_rpy", C.c_double * 3), ("axis", C.c_double * 3), ("mass", C.c_double), ("com", C.c_double * 3),
+                ("inertia", C.c_double * 6), ("q_lower", C.c_double), ("q_upper", C.c_double),
+                ("velocity_limit", C.c_double), ("effort_limit", C.c_double)]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compiles for gfx950 (works without a GPU). Output stays in-tree: sai-primitives_amd/libsaip.so"""
+    srcs = [os.path.join(_DIR, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_DIR, h) for h in HEADERS]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SaipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(the engine has no CPU path)")
+    L = C.CDLL(LIB_PATH)
+    dp, vp, ip = C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)
+    u8p = C.POINTER(C.c_ubyte)
+    sig = {
+        "saip_model_create_serial_chain": (C.c_int, [C.POINTER(LinkDesc), C.c_int, C.POINTER(vp)]),
+        "saip_model_destroy": (None, [vp]),
+        "saip_model_dof": (C.c_int, [vp]),
+        "saip_model_link_index": (C.c_int, [vp, C.c_char_p]),
+        "saip_model_joint_limits": (C.c_int, [vp, dp, dp, dp, dp]),
+        "saip_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "saip_batch_destroy": (None, [vp]),
+        "saip_batch_size": (C.c_int, [vp]),
+        "saip_batch_ld": (C.c_int, [vp]),
+        "saip_batch_add_motion_force_task": (C.c_int, [vp, C.c_char_p, C.c_char_p, dp, dp, dp, C.c_int, dp, C.c_int, C.c_double, ip]),
+        "saip_batch_add_joint_task": (C.c_int, [vp, C.c_char_p, dp, C.c_int, C.c_double, ip]),
+        "saip_batch_finalize": (C.c_int, [vp]),
+        "saip_batch_task_count": (C.c_int, [vp]),
+        "saip_batch_task_type": (C.c_int, [vp, C.c_int]),
+        "saip_batch_task_name": (C.c_char_p, [vp, C.c_int]),
+        "saip_batch_task_by_name": (C.c_int, [vp, C.c_char_p]),
+        "saip_batch_task_dof": (C.c_int, [vp, C.c_int]),
+        "saip_batch_goal_components": (C.c_int, [vp, C.c_int]),
+        "saip_batch_get_task_projection": (C.c_int, [vp, C.c_int, dp, dp, ip]),
+        "saip_batch_set_pos_control_gains": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int]),
+        "saip_batch_set_ori_control_gains": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int]),
+        "saip_batch_set_joint_gains": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int]),
+        "saip_batch_set_dynamic_decoupling_type": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_bie_threshold": (C.c_int, [vp, C.c_int, C.c_double]),
+        "saip_batch_set_singularity_bounds": (C.c_int, [vp, C.c_int, C.c_double, C.c_double]),
+        "saip_batch_set_internal_otg": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_velocity_saturation": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_enable_gravity_compensation": (C.c_int, [vp, C.c_int]),
+        "saip_batch_enable_joint_limit_avoidance": (C.c_int, [vp, C.c_int]),
+        "saip_batch_enable_torque_saturation": (C.c_int, [vp, C.c_int]),
+        "saip_batch_set_integrator_tracking": (C.c_int, [vp, C.c_int]),
+        "saip_batch_set_state_host": (C.c_int, [vp, dp, dp]),
+        "saip_batch_set_goal_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_set_goal_field_host": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp]),
+        "saip_batch_get_goal_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_reinitialize_tasks": (C.c_int, [vp]),
+        "saip_batch_device_q": (vp, [vp]),
+        "saip_batch_device_dq": (vp, [vp]),
+        "saip_batch_device_goal": (vp, [vp, C.c_int]),
+        "saip_batch_device_tau": (vp, [vp]),
+        "saip_batch_device_status": (vp, [vp]),
+        "saip_batch_bind_tau_device": (C.c_int, [vp, vp]),
+        "saip_batch_stream": (vp, [vp]),
+        "saip_batch_update_task_models": (C.c_int, [vp]),
+        "saip_batch_compute_control_torques": (C.c_int, [vp, dp, u8p]),
+        "saip_batch_step_async": (C.c_int, [vp]),
+        "saip_batch_synchronize": (C.c_int, [vp]),
+        "saip_batch_get_torques_host": (C.c_int, [vp, dp, u8p]),
+        "saip_batch_get_task_nullspace_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_set_kernel": (C.c_int, [vp, C.c_int]),
+        "saip_batch_kernel_name": (C.c_char_p, [vp]),
+        "saip_batch_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp]),
+        "saip_last_error": (C.c_char_p, []),
+        "saip_version": (C.c_char_p, []),
+        "saip_device_count": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    L._declared = sorted(sig)
+    _LIB = L
+    return L
+
+
+def check(status: int):
+    if status == SAIP_OK:
+        return
+    msg = lib().saip_last_error().decode()
+    if status == SAIP_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)  # the reference throws std::invalid_argument
+    if status == SAIP_ERR_UNSUPPORTED:
+        raise SaipUnsupported(msg)
+    if status == SAIP_ERR_NO_DEVICE:
+        raise SaipNoDevice(msg)
+    raise SaipError(f"[status {status}] {msg}")
+
+
+def device_count() -> int:
+    return lib().saip_device_count()

@@ -1,0 +1,512 @@
+"""Batched mirror of the reference's task/controller interface on top of the C-ABI.
+
+Same class and method names as the reference (camelCase kept on purpose so that call sequences read like
+/root/reference/examples/05-using_robot_controller/05-using_robot_controller.cpp:103-196), with every
+per-robot Eigen vector replaced by a (B, size) NumPy array.  Differences from the reference, all loud:
+  * one SaiModel object = B robot instances of the same robot (state arrays are (B, dof));
+  * the internal OTG is ENABLED by default like in the reference, but not implemented on the device:
+    computeControlTorques raises until disableInternalOtg() is called on every task;
+  * singular / blended SingularityHandler branches, velocity saturation, closed-loop force control and the
+    JointLimitAvoidance torques are "next" rows: requesting them raises SaipUnsupported; instances that
+    leave the non-singular branch get status 1 and NaN torques.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import json
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+_ROBOT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
+_JT = {"fixed": 0, "revolute": 1, "prismatic": 2}
+
+
+class TaskType(enum.IntEnum):  # TemplateTask.h:19-24
+    UNDEFINED = 0
+    JOINT_LIMIT_AVOIDANCE_TASK = 1
+    JOINT_TASK = 2
+    MOTION_FORCE_TASK = 3
+
+
+class DynamicDecouplingType(enum.IntEnum):  # SaiPrimitivesCommonDefinitions.h:14-20
+    FULL_DYNAMIC_DECOUPLING = 0
+    BOUNDED_INERTIA_ESTIMATES = 1
+    IMPEDANCE = 2
+
+
+@dataclass
+class PIDGains:  # SaiPrimitivesCommonDefinitions.h:26-32
+    kp: float
+    kv: float
+    ki: float
+
+
+def load_robot_description(name_or_path: str) -> dict:
+    path = name_or_path if os.path.exists(name_or_path) else os.path.join(_ROBOT_DIR, name_or_path + ".json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _soa(a, B, comps, what):
+    """(B, comps) user array -> contiguous [comps][B] host staging array"""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1 and comps == a.shape[0]:
+        a = np.broadcast_to(a, (B, comps))
+    if a.shape != (B, comps):
+        raise ValueError(f"{what}: expected shape ({B}, {comps}), got {a.shape}")
+    return np.ascontiguousarray(a.T)
+
+
+class SaiModel:
+    """B instances of one robot (batched stand-in for SaiModel::SaiModel: constants + q/dq state)."""
+
+    def __init__(self, description, batch_size: int, device: int = 0):
+        desc = load_robot_description(description) if isinstance(description, str) else description
+        self.description = desc
+        links = desc["links"]
+        arr = (capi.LinkDesc * len(links))()
+        for d, l in zip(arr, links):
+            d.name = l["name"].encode()
+            d.joint_type = _JT[l["joint_type"]]
+            d.origin_xyz[:] = l["origin_xyz"]
+            d.origin_rpy[:] = l["origin_rpy"]
+            d.axis[:] = l["axis"]
+            d.mass = l["mass"]
+            d.com[:] = l["com"]
+            d.inertia[:] = l["inertia"]
+            d.q_lower, d.q_upper = l["q_lower"], l["q_upper"]
+            d.velocity_limit, d.effort_limit = l["velocity_limit"], l["effort_limit"]
+        L = capi.lib()
+        h = C.c_void_p()
+        capi.check(L.saip_model_create_serial_chain(arr, len(links), C.byref(h)))
+        self._h = h
+        self._n = L.saip_model_dof(h)
+        self.batch_size = int(batch_size)
+        self.device = int(device)
+        self._q = np.zeros((self.batch_size, self._n))
+        self._dq = np.zeros((self.batch_size, self._n))
+        self._controller = None
+        self._state_version = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().saip_model_destroy(self._h)
+            self._h = None
+
+    def dof(self) -> int:
+        return self._n
+
+    def q(self):
+        return self._q
+
+    def dq(self):
+        return self._dq
+
+    def setQ(self, q):
+        q = np.asarray(q, float)
+        if q.shape != (self.batch_size, self._n):
+            raise ValueError(f"setQ: expected shape ({self.batch_size}, {self._n})")
+        self._q = q.copy()
+        self._state_version += 1
+
+    def setDq(self, dq):
+        dq = np.asarray(dq, float)
+        if dq.shape != (self.batch_size, self._n):
+            raise ValueError(f"setDq: expected shape ({self.batch_size}, {self._n})")
+        self._dq = dq.copy()
+        self._state_version += 1
+
+    def updateModel(self):
+        """pushes q/dq to the device; kinematics and dynamics are evaluated inside the cycle kernel"""
+        if self._controller is not None:
+            self._controller._push_state()
+
+    def jointLimits(self):
+        n = self._n
+        out = [np.zeros(n) for _ in range(4)]
+        capi.check(capi.lib().saip_model_joint_limits(self._h, *[_dptr(a) for a in out]))
+        return dict(position_lower=out[0], position_upper=out[1], velocity=out[2], effort=out[3])
+
+    def linkIndex(self, name: str) -> int:
+        return capi.lib().saip_model_link_index(self._h, name.encode())
+
+
+class _Task:
+    """common part of TemplateTask (TemplateTask.h:26-124)"""
+    _type = TaskType.UNDEFINED
+
+    def __init__(self, robot: SaiModel, task_name: str, loop_timestep: float):
+        self._robot, self._name, self._dt = robot, task_name, float(loop_timestep)
+        self._ctrl = None
+        self._id = -1
+        self._pending = []  # configuration calls issued before the controller exists
+        self._keepalive = []
+
+    # -- TemplateTask accessors
+    def getConstRobotModel(self):
+        return self._robot
+
+    def getLoopTimestep(self):
+        return self._dt
+
+    def getTaskType(self):
+        return self._type
+
+    def getTaskName(self):
+        return self._name
+
+    def _cfg(self, fn_name, *args):
+        if self._ctrl is None:
+            self._pending.append((fn_name, args))
+        else:
+            self._ctrl._call(fn_name, self._id, *args)
+
+    def _gains(self, fn, kp, kv, ki):
+        kp, kv, ki = (np.atleast_1d(np.asarray(x, float)) for x in (kp, kv, ki))
+        size = max(kp.shape[0], kv.shape[0], ki.shape[0])
+        for x in (kp, kv, ki):
+            if x.ndim != 1 or x.shape[0] not in (1, size):
+                raise ValueError("kp, kv and ki must be scalars or vectors of the same size")
+        k = [np.ascontiguousarray(np.broadcast_to(x, (size,))) for x in (kp, kv, ki)]
+        self._keepalive.append(k)
+        self._cfg(fn, _dptr(k[0]), _dptr(k[1]), _dptr(k[2]), size)
+
+    def setDynamicDecouplingType(self, t):
+        self._cfg("saip_batch_set_dynamic_decoupling_type", int(t))
+
+    def setBoundedInertiaEstimateThreshold(self, thr: float):
+        self._cfg("saip_batch_set_bie_threshold", float(thr))
+
+    def disableInternalOtg(self):
+        self._cfg("saip_batch_set_internal_otg", 0)
+
+    def enableInternalOtgAccelerationLimited(self, *a):
+        self._cfg("saip_batch_set_internal_otg", 1)
+
+    def enableInternalOtgJerkLimited(self, *a):
+        self._cfg("saip_batch_set_internal_otg", 1)
+
+    def enableVelocitySaturation(self, *a):
+        self._cfg("saip_batch_set_velocity_saturation", 1)
+
+    def disableVelocitySaturation(self):
+        self._cfg("saip_batch_set_velocity_saturation", 0)
+
+    def _need_ctrl(self):
+        if self._ctrl is None:
+            raise capi.SaipError(f"task [{self._name}] is not part of a RobotController yet")
+        return self._ctrl
+
+    def _set_field(self, first, comps, value, what):
+        ctrl = self._need_ctrl()
+        a = _soa(value, ctrl.batch_size, comps, what)
+        capi.check(capi.lib().saip_batch_set_goal_field_host(ctrl._h, self._id, first, comps, _dptr(a)))
+
+    def _get_goal(self):
+        ctrl = self._need_ctrl()
+        gs = capi.lib().saip_batch_goal_components(ctrl._h, self._id)
+        out = np.empty((gs, ctrl.batch_size))
+        capi.check(capi.lib().saip_batch_get_goal_host(ctrl._h, self._id, _dptr(out)))
+        return out.T.copy()
+
+    def getTaskNullspace(self):
+        """(B, dof, dof) nullspace projector N of this task for the current state (TemplateTask.h:71-77)"""
+        ctrl = self._need_ctrl()
+        n = self._robot.dof()
+        out = np.empty((n * n, ctrl.batch_size))
+        capi.check(capi.lib().saip_batch_get_task_nullspace_host(ctrl._h, self._id, _dptr(out)))
+        return out.T.reshape(ctrl.batch_size, n, n).copy()
+
+
+class MotionForceTask(_Task):
+    """MotionForceTask.h:96-110.  controlled_directions_* = None -> full 6-dof task."""
+    _type = TaskType.MOTION_FORCE_TASK
+
+    def __init__(self, robot, link_name, compliant_frame_pos=(0.0, 0.0, 0.0), compliant_frame_rot=None,
+                 controlled_directions_translation=None, controlled_directions_rotation=None,
+                 task_name="motion_force_task", loop_timestep=0.001):
+        super().__init__(robot, task_name, loop_timestep)
+        self.link_name = link_name
+        self.pos = np.asarray(compliant_frame_pos, float).reshape(3).copy()
+        self.rot = None if compliant_frame_rot is None else np.ascontiguousarray(np.asarray(compliant_frame_rot, float).reshape(9))
+        self.partial = controlled_directions_translation is not None or controlled_directions_rotation is not None
+        self.dt_ = np.ascontiguousarray(np.asarray(controlled_directions_translation or np.zeros((0, 3)), float).reshape(-1, 3))
+        self.dr_ = np.ascontiguousarray(np.asarray(controlled_directions_rotation or np.zeros((0, 3)), float).reshape(-1, 3))
+        if self.partial and len(self.dt_) == 0 and len(self.dr_) == 0:  # MotionForceTask.cpp:47-53
+            raise ValueError("controlled_directions_translation and controlled_directions_rotation cannot both be empty "
+                             "in MotionForceTask::MotionForceTask")
+
+    def _add(self, L, h):
+        tid = C.c_int(-1)
+        capi.check(L.saip_batch_add_motion_force_task(
+            h, self._name.encode(), self.link_name.encode(), _dptr(self.pos), None if self.rot is None else _dptr(self.rot),
+            _dptr(self.dt_) if len(self.dt_) else None, len(self.dt_) if self.partial else -1,
+            _dptr(self.dr_) if len(self.dr_) else None, len(self.dr_) if self.partial else -1, self._dt, C.byref(tid)))
+        return tid.value
+
+    # goals, MotionForceTask.h:211-247
+    def setGoalPosition(self, x):
+        self._set_field(0, 3, x, "setGoalPosition")
+
+    def setGoalOrientation(self, R):
+        R = np.asarray(R, float)
+        B = self._need_ctrl().batch_size
+        if R.shape == (3, 3):
+            R = np.broadcast_to(R, (B, 3, 3))
+        self._set_field(3, 9, R.reshape(B, 9), "setGoalOrientation")
+
+    def setGoalLinearVelocity(self, v):
+        self._set_field(12, 3, v, "setGoalLinearVelocity")
+
+    def setGoalAngularVelocity(self, w):
+        self._set_field(15, 3, w, "setGoalAngularVelocity")
+
+    def setGoalLinearAcceleration(self, a):
+        self._set_field(18, 3, a, "setGoalLinearAcceleration")
+
+    def setGoalAngularAcceleration(self, a):
+        self._set_field(21, 3, a, "setGoalAngularAcceleration")
+
+    def getGoalPosition(self):
+        return self._get_goal()[:, 0:3]
+
+    def getGoalOrientation(self):
+        return self._get_goal()[:, 3:12].reshape(-1, 3, 3)
+
+    # gains, MotionForceTask.h:272-300
+    def setPosControlGains(self, kp, kv, ki=0.0):
+        self._gains("saip_batch_set_pos_control_gains", kp, kv, ki)
+
+    def setOriControlGains(self, kp, kv, ki=0.0):
+        self._gains("saip_batch_set_ori_control_gains", kp, kv, ki)
+
+    def setSingularityHandlingBounds(self, s_min, s_max):  # MotionForceTask.h:736
+        self._cfg("saip_batch_set_singularity_bounds", float(s_min), float(s_max))
+
+    def getTaskProjection(self):
+        ctrl = self._need_ctrl()
+        P, Bm, k = np.zeros(36), np.zeros(36), C.c_int(0)
+        capi.check(capi.lib().saip_batch_get_task_projection(ctrl._h, self._id, _dptr(P), _dptr(Bm), C.byref(k)))
+        return P.reshape(6, 6), Bm.reshape(6, 6)[:, :k.value].copy()
+
+
+class JointTask(_Task):
+    """JointTask.h:56-75.  joint_selection_matrix = None -> full joint task."""
+    _type = TaskType.JOINT_TASK
+
+    def __init__(self, robot, joint_selection_matrix=None, task_name="joint_task", loop_timestep=0.001):
+        super().__init__(robot, task_name, loop_timestep)
+        self.S = None
+        if joint_selection_matrix is not None:
+            S = np.ascontiguousarray(np.asarray(joint_selection_matrix, float))
+            if S.ndim != 2 or S.shape[1] != robot.dof():  # JointTask.cpp:28-32
+                raise ValueError("joint selection matrix size not consistent with robot dof in JointTask constructor")
+            self.S = S
+
+    def _add(self, L, h):
+        tid = C.c_int(-1)
+        if self.S is None:
+            capi.check(L.saip_batch_add_joint_task(h, self._name.encode(), None, 0, self._dt, C.byref(tid)))
+        else:
+            capi.check(L.saip_batch_add_joint_task(h, self._name.encode(), _dptr(self.S), self.S.shape[0], self._dt, C.byref(tid)))
+        return tid.value
+
+    def getTaskDof(self):
+        return self._robot.dof() if self.S is None else self.S.shape[0]
+
+    def isFullJointTask(self):
+        return self.getTaskDof() == self._robot.dof()
+
+    # goals, JointTask.h:140-175
+    def setGoalPosition(self, q):
+        self._set_field(0, self.getTaskDof(), q, "goal position vector size not consistent with task dof in JointTask::setGoalPosition")
+
+    def setGoalVelocity(self, dq):
+        m = self.getTaskDof()
+        self._set_field(m, m, dq, "goal velocity vector size not consistent with task dof in JointTask::setGoalVelocity")
+
+    def setGoalAcceleration(self, ddq):
+        m = self.getTaskDof()
+        self._set_field(2 * m, m, ddq, "goal acceleration vector size not consistent with task dof in JointTask::setGoalAcceleration")
+
+    def getGoalPosition(self):
+        return self._get_goal()[:, :self.getTaskDof()]
+
+    def setGains(self, kp, kv, ki=0.0):  # JointTask.h:237-257
+        self._gains("saip_batch_set_joint_gains", kp, kv, ki)
+
+
+class RobotController:
+    """RobotController.h:47-90 for B robots at once."""
+
+    def __init__(self, robot: SaiModel, tasks):
+        L = capi.lib()
+        if len(tasks) == 0:  # RobotController.cpp:11-14
+            raise ValueError("RobotController must have at least one task")
+        for t in tasks:
+            if t.getConstRobotModel() is not robot:  # :28-31
+                raise ValueError("All tasks must have the same robot model in RobotController")
+        h = C.c_void_p()
+        capi.check(L.saip_batch_create(robot._h, robot.batch_size, robot.device, C.byref(h)))
+        self._h = h
+        self._robot = robot
+        self.batch_size = robot.batch_size
+        self._tasks = list(tasks)
+        try:
+            for t in tasks:
+                t._id = t._add(L, h)
+            capi.check(L.saip_batch_finalize(h))  # remaining constructor checks, :32-58
+        except Exception:
+            L.saip_batch_destroy(h)
+            self._h = None
+            raise
+        for t in tasks:
+            t._ctrl = self
+            for fn, args in t._pending:
+                self._call(fn, t._id, *args)
+            t._pending = []
+        robot._controller = self
+        self._pushed_version = -1
+        self._has_device = robot.device >= 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().saip_batch_destroy(self._h)
+            self._h = None
+
+    def _call(self, fn_name, *args):
+        capi.check(getattr(capi.lib(), fn_name)(self._h, *args))
+
+    def _push_state(self):
+        r = self._robot
+        if self._pushed_version != r._state_version:
+            q, dq = np.ascontiguousarray(r._q.T), np.ascontiguousarray(r._dq.T)
+            capi.check(capi.lib().saip_batch_set_state_host(self._h, _dptr(q), _dptr(dq)))
+            self._pushed_version = r._state_version
+
+    # -- reference API
+    def updateControllerTaskModels(self):
+        self._push_state()
+        self._call("saip_batch_update_task_models")
+
+    def computeControlTorques(self):
+        """returns (B, dof) joint torques; per-instance status in self.status (0 ok, 1 singular -> NaN row)"""
+        n, B = self._robot.dof(), self.batch_size
+        tau = np.empty((n, B))
+        st = np.zeros(B, np.uint8)
+        capi.check(capi.lib().saip_batch_compute_control_torques(self._h, _dptr(tau), st.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        self.status = st
+        return tau.T.copy()
+
+    def enableGravityCompensation(self, e: bool):
+        self._call("saip_batch_enable_gravity_compensation", int(e))
+
+    def enableJointLimitAvoidance(self, e: bool):
+        self._call("saip_batch_enable_joint_limit_avoidance", int(e))
+
+    def enableTorqueSaturation(self, e: bool):
+        self._call("saip_batch_enable_torque_saturation", int(e))
+
+    def reinitializeTasks(self):
+        self._push_state()
+        self._call("saip_batch_reinitialize_tasks")
+
+    def getTaskNames(self):
+        return [t.getTaskName() for t in self._tasks]
+
+    def _by_name(self, name, typ, what):
+        for t in self._tasks:
+            if t.getTaskName() == name:
+                if t.getTaskType() != typ:  # RobotController.cpp:124-158
+                    raise ValueError(f"Task {name} is not a {what}, and cannot be casted as such in RobotController::GetTaskByName")
+                return t
+        raise ValueError(f"Task {name} not found in RobotController::GetTaskByName")
+
+    def getJointTaskByName(self, name):
+        return self._by_name(name, TaskType.JOINT_TASK, "JointTask")
+
+    def getMotionForceTaskByName(self, name):
+        return self._by_name(name, TaskType.MOTION_FORCE_TASK, "MotionForceTask")
+
+    # -- engine extras (resident pipelines, benchmarking)
+    def setIntegratorTracking(self, always: bool):
+        self._call("saip_batch_set_integrator_tracking", int(always))
+
+    def setKernel(self, which: int):
+        self._call("saip_batch_set_kernel", int(which))
+
+    def kernelName(self) -> str:
+        return capi.lib().saip_batch_kernel_name(self._h).decode()
+
+    def setGoals(self, goals):
+        """goals[t]: (B, goal_components) whole goal block per task, controller order"""
+        for t, g in zip(self._tasks, goals):
+            gs = capi.lib().saip_batch_goal_components(self._h, t._id)
+            a = _soa(g, self.batch_size, gs, f"goal of task {t.getTaskName()}")
+            capi.check(capi.lib().saip_batch_set_goal_host(self._h, t._id, _dptr(a)))
+
+    def stepAsync(self):
+        self._call("saip_batch_step_async")
+
+    def synchronize(self):
+        self._call("saip_batch_synchronize")
+
+    def getTorques(self):
+        n, B = self._robot.dof(), self.batch_size
+        tau = np.empty((n, B))
+        st = np.zeros(B, np.uint8)
+        capi.check(capi.lib().saip_batch_get_torques_host(self._h, _dptr(tau), st.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        self.status = st
+        return tau.T.copy()
+
+    def timeSteps(self, steps: int, warmup: int = 0) -> float:
+        ms = C.c_double(0)
+        capi.check(capi.lib().saip_batch_time_steps(self._h, steps, warmup, C.byref(ms)))
+        return ms.value
+
+    def devicePointers(self):
+        L = capi.lib()
+        return dict(q=L.saip_batch_device_q(self._h), dq=L.saip_batch_device_dq(self._h), tau=L.saip_batch_device_tau(self._h),
+                    status=L.saip_batch_device_status(self._h), ld=L.saip_batch_ld(self._h), stream=L.saip_batch_stream(self._h))
+
+    def bindTauDevice(self, ptr):
+        self._call("saip_batch_bind_tau_device", C.c_void_p(ptr))
+
+
+def controller_from_specs(description, tasks, batch_size, device=0, *, disable_otg=True):
+    """Build (robot, controller, task objects) from workloads.py-style task specs (used by tests and bench)."""
+    robot = SaiModel(description, batch_size, device)
+    objs = []
+    for t in tasks:
+        if t["type"] == "motion_force":
+            o = MotionForceTask(robot, t["link"], t["pos_in_link"], t.get("rot_in_link"), t.get("dirs_trans"), t.get("dirs_rot"),
+                                task_name=t["name"], loop_timestep=t.get("dt", 0.001))
+            o.setPosControlGains(t["kp_pos"], t["kv_pos"], t["ki_pos"])
+            o.setOriControlGains(t["kp_ori"], t["kv_ori"], t["ki_ori"])
+            o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
+        else:
+            S = t["S"]
+            if S is not None:
+                S = np.asarray(S, float)
+                if S.ndim == 1:
+                    rows = [int(i) for i in S]
+                    S = np.zeros((len(rows), robot.dof()))
+                    S[np.arange(len(rows)), rows] = 1.0
+            o = JointTask(robot, S, task_name=t["name"], loop_timestep=t.get("dt", 0.001))
+            o.setGains(t["kp"], t["kv"], t["ki"])
+        o.setDynamicDecouplingType(t["decoupling"])
+        o.setBoundedInertiaEstimateThreshold(t["bie_threshold"])
+        if disable_otg:
+            o.disableInternalOtg()
+        objs.append(o)
+    ctrl = RobotController(robot, objs)
+    return robot, ctrl, objs

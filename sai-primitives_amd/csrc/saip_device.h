@@ -1,0 +1,63 @@
+// Device-visible constant blocks shared by the host engine and the HIP kernels.
+// Layout notes: everything here is batch-uniform (wave-uniform), read through scalar loads.
+#pragma once
+#include <stdint.h>
+
+#define SAIP_MAXN 32
+#define SAIP_MAXT 8
+
+namespace saip {
+
+// one movable body of the serial chain (fixed links already merged on the host, engine.cpp: merge_fixed_links)
+struct ModelDev {
+	int n;
+	int pad_;
+	int jtype[SAIP_MAXN];        // 1 revolute, 2 prismatic
+	double R0[SAIP_MAXN][9];     // joint origin rotation (parent body frame -> joint frame at q=0), row-major
+	double p0[SAIP_MAXN][3];     // joint origin translation in the parent body frame
+	double axis[SAIP_MAXN][3];   // unit joint axis in the body frame
+	double mass[SAIP_MAXN];
+	double com[SAIP_MAXN][3];    // body frame
+	double inertia[SAIP_MAXN][6];// about the COM, body axes: xx yy zz xy xz yz
+	double effort[SAIP_MAXN];
+	double gravity[3];
+};
+
+enum { TASK_JOINT = 2, TASK_MOTION_FORCE = 3 };
+enum { DEC_FULL = 0, DEC_BIE = 1, DEC_IMPEDANCE = 2 };
+
+struct TaskDev {
+	int type;
+	int body;          // motion force: movable body the control frame is attached to
+	int k;             // motion force: task rank = pos_range + ori_range
+	int m;             // joint: rows of S
+	int decoupling;
+	int s_identity;    // joint: S == I
+	int has_ki;        // any integral gain != 0
+	int goal_comps;
+	double dt, bie_threshold, s_min, s_max, s_abs_tol;
+	double pos[3];     // control point in the body frame
+	double rot[9];     // control frame rotation in the body frame
+	double Bm[36];     // 6 x 6 row-major, first k columns = orthonormal basis of range(P)
+	double Ppos[9], Pori[9];   // diagonal blocks of the partial task projection P
+	double sig_p[9], sig_o[9]; // sigmaPosition / sigmaOrientation (force & moment space dimension 0)
+	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
+	double kp[SAIP_MAXN], kv[SAIP_MAXN], ki[SAIP_MAXN];
+	double S[SAIP_MAXN * SAIP_MAXN]; // m x n row-major
+	double* goal;      // [goal_comps][ld]
+	double* integ;     // [6 or m][ld]
+	double* diag_N;    // optional [n*n][ld] task nullspace dump (diagnostic variant), else nullptr
+};
+
+struct CycleParams {
+	int B, ld, n, nt;
+	int gravity_comp, torque_sat, integ_always, diag;
+	const double* q;   // [n][ld]
+	const double* dq;  // [n][ld]
+	double* tau;       // [n][ld]
+	uint8_t* status;   // [ld]
+	const ModelDev* model;
+	const TaskDev* tasks;
+};
+
+}  // namespace saip

@@ -1,0 +1,928 @@
+// Host side of the engine behind include/saip.h: robot constants, task stacks, device arena, launches.
+// C++ (the reference is a C++ library), HIP runtime only -- no PyTorch, no Eigen.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/saip.h"
+#include "saip_device.h"
+
+namespace saip {
+hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
+hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
+hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
+}  // namespace saip
+
+using saip::CycleParams;
+using saip::ModelDev;
+using saip::TaskDev;
+
+static thread_local std::string g_err;
+static saip_status fail(saip_status st, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return st;
+}
+#define HIP_TRY(expr)                                                                                        \
+	do {                                                                                                     \
+		hipError_t e_ = (expr);                                                                              \
+		if (e_ != hipSuccess) return fail(SAIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+// ------------------------------------------------------------------ tiny 3x3 helpers (row-major)
+static void m3_mul(const double* A, const double* B, double* C) {
+	double T[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+	memcpy(C, T, sizeof(T));
+}
+static void m3_vec(const double* A, const double* v, double* o) {
+	double t[3];
+	for (int i = 0; i < 3; i++) t[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+	memcpy(o, t, sizeof(t));
+}
+static void m3_T(const double* A, double* B) {
+	double T[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) T[3 * i + j] = A[3 * j + i];
+	memcpy(B, T, sizeof(T));
+}
+static void m3_eye(double* A) {
+	memset(A, 0, 9 * sizeof(double));
+	A[0] = A[4] = A[8] = 1.0;
+}
+static void rpy_to_R(const double* rpy, double* R) {  // URDF fixed-axis rpy: R = Rz(yaw) Ry(pitch) Rx(roll)
+	double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
+	double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr}, Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp}, Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1}, T[9];
+	m3_mul(Ry, Rx, T);
+	m3_mul(Rz, T, R);
+}
+// eigen-decomposition of a symmetric 3x3 (cyclic Jacobi); eigenvalues descending, eigenvectors in columns of V
+static void sym3_eig(const double* A_in, double* lam, double* V) {
+	double A[9];
+	memcpy(A, A_in, sizeof(A));
+	m3_eye(V);
+	for (int sweep = 0; sweep < 50; sweep++) {
+		double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+		if (off < 1e-300) break;
+		for (int p = 0; p < 2; p++)
+			for (int q = p + 1; q < 3; q++) {
+				double apq = A[3 * p + q];
+				if (fabs(apq) < 1e-300) continue;
+				double theta = (A[3 * q + q] - A[3 * p + p]) / (2 * apq);
+				double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+				double c = 1 / sqrt(t * t + 1), s = t * c;
+				for (int i = 0; i < 3; i++) {
+					double a = A[3 * i + p], b = A[3 * i + q];
+					A[3 * i + p] = c * a - s * b;
+					A[3 * i + q] = s * a + c * b;
+				}
+				for (int j = 0; j < 3; j++) {
+					double a = A[3 * p + j], b = A[3 * q + j];
+					A[3 * p + j] = c * a - s * b;
+					A[3 * q + j] = s * a + c * b;
+				}
+				for (int i = 0; i < 3; i++) {
+					double a = V[3 * i + p], b = V[3 * i + q];
+					V[3 * i + p] = c * a - s * b;
+					V[3 * i + q] = s * a + c * b;
+				}
+			}
+	}
+	int idx[3] = {0, 1, 2};
+	for (int a = 0; a < 3; a++)
+		for (int b = a + 1; b < 3; b++)
+			if (A[4 * idx[b]] > A[4 * idx[a]]) std::swap(idx[a], idx[b]);
+	double Vs[9];
+	for (int j = 0; j < 3; j++) {
+		lam[j] = A[4 * idx[j]];
+		for (int i = 0; i < 3; i++) Vs[3 * i + j] = V[3 * i + idx[j]];
+	}
+	memcpy(V, Vs, sizeof(Vs));
+}
+// SaiModel::matrixRangeBasis for a 3 x cnt matrix whose columns are `dirs` (cnt vectors of 3): orthonormal basis of
+// the column space with the reference's tolerance semantics (sigma_i/sigma_0 >= 1e-3; identity when rank 3).
+// Returns the rank (0 = empty range); basis (3 x rank) row-major with leading dimension 3.
+static int range_basis_3(const double* dirs, int cnt, double* basis) {
+	double G[9] = {0};
+	for (int c = 0; c < cnt; c++)
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) G[3 * i + j] += dirs[3 * c + i] * dirs[3 * c + j];
+	const double tol = 1e-3;
+	memset(basis, 0, 9 * sizeof(double));
+	if (cnt <= 0 || sqrt(G[0] + G[4] + G[8]) < tol) return 0;
+	double lam[3], V[9];
+	sym3_eig(G, lam, V);
+	double s0 = sqrt(fmax(lam[0], 0.0));
+	if (s0 < tol) return 0;
+	int maxr = cnt < 3 ? cnt : 3, rank = maxr;
+	for (int i = maxr - 1; i > 0; i--) {
+		if (sqrt(fmax(lam[i], 0.0)) / s0 < tol) rank--;
+		else break;
+	}
+	if (rank == 3) {
+		m3_eye(basis);
+		return 3;
+	}
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < rank; j++) basis[3 * i + j] = V[3 * i + j];
+	return rank;
+}
+
+// ------------------------------------------------------------------ model
+struct LinkInfo {
+	std::string name;
+	int body;        // movable body this link is rigidly attached to (-1: attached to the fixed base)
+	double R[9], p[3];  // link frame in the body frame
+};
+struct saip_model {
+	int n = 0;
+	std::vector<LinkInfo> links;
+	ModelDev dev;
+	double q_lower[SAIP_MAXN], q_upper[SAIP_MAXN], vel[SAIP_MAXN], effort[SAIP_MAXN];
+};
+
+// combine rigid-body inertials expressed in one frame
+struct Inertial {
+	double m = 0, c[3] = {0, 0, 0}, I[9] = {0};  // I about the COM
+};
+static void inertial_add(Inertial& a, double m2, const double* c2, const double* I2) {
+	double m = a.m + m2;
+	if (m <= 0) return;
+	double c[3];
+	for (int i = 0; i < 3; i++) c[i] = (a.m * a.c[i] + m2 * c2[i]) / m;
+	double I[9] = {0};
+	auto shift = [&](double mm, const double* cc, const double* II) {
+		double d[3] = {cc[0] - c[0], cc[1] - c[1], cc[2] - c[2]}, dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+		for (int i = 0; i < 3; i++)
+			for (int j = 0; j < 3; j++) I[3 * i + j] += II[3 * i + j] + mm * ((i == j ? dd : 0.0) - d[i] * d[j]);
+	};
+	shift(a.m, a.c, a.I);
+	shift(m2, c2, I2);
+	a.m = m;
+	memcpy(a.c, c, sizeof(c));
+	memcpy(a.I, I, sizeof(I));
+}
+
+extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* links, int n_links, saip_model** out) {
+	if (!links || !out || n_links <= 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_model_create_serial_chain: null or empty link list");
+	auto* M = new saip_model();
+	memset(&M->dev, 0, sizeof(ModelDev));
+	// pending fixed transform between the last movable body frame (or the base) and the current link
+	double Rp[9], pp[3] = {0, 0, 0};
+	m3_eye(Rp);
+	int body = -1;
+	std::vector<Inertial> inertials;
+	for (int l = 0; l < n_links; l++) {
+		const saip_link_desc& L = links[l];
+		double R0[9], Rl[9], pl[3], t[3];
+		rpy_to_R(L.origin_rpy, R0);
+		m3_vec(Rp, L.origin_xyz, t);
+		for (int i = 0; i < 3; i++) pl[i] = pp[i] + t[i];
+		m3_mul(Rp, R0, Rl);  // link frame (at q = 0) in the frame of the last movable body
+		double Il[9] = {L.inertia[0], L.inertia[3], L.inertia[4], L.inertia[3], L.inertia[1], L.inertia[5], L.inertia[4], L.inertia[5], L.inertia[2]};
+		if (L.joint_type == SAIP_JOINT_FIXED) {
+			if (body >= 0) {  // merge the inertial into the parent movable body (links welded to the base carry no dynamics)
+				double c2[3], T[9], I2[9], RlT[9];
+				m3_vec(Rl, L.com, c2);
+				for (int i = 0; i < 3; i++) c2[i] += pl[i];
+				m3_mul(Rl, Il, T);
+				m3_T(Rl, RlT);
+				m3_mul(T, RlT, I2);
+				inertial_add(inertials[body], L.mass, c2, I2);
+			}
+			memcpy(Rp, Rl, sizeof(Rl));
+			memcpy(pp, pl, sizeof(pl));
+		} else if (L.joint_type == SAIP_JOINT_REVOLUTE || L.joint_type == SAIP_JOINT_PRISMATIC) {
+			if (M->n >= SAIP_MAXN) {
+				delete M;
+				return fail(SAIP_ERR_UNSUPPORTED, "robot has more than %d degrees of freedom", SAIP_MAXN);
+			}
+			double an = sqrt(L.axis[0] * L.axis[0] + L.axis[1] * L.axis[1] + L.axis[2] * L.axis[2]);
+			if (an < 1e-12) {
+				delete M;
+				return fail(SAIP_ERR_INVALID_ARGUMENT, "joint of link %s has a zero axis", L.name);
+			}
+			int j = M->n++;
+			body = j;
+			M->dev.jtype[j] = L.joint_type;
+			memcpy(M->dev.R0[j], Rl, sizeof(Rl));
+			memcpy(M->dev.p0[j], pl, sizeof(pl));
+			for (int i = 0; i < 3; i++) M->dev.axis[j][i] = L.axis[i] / an;
+			Inertial in;
+			inertial_add(in, L.mass, L.com, Il);
+			if (L.mass <= 0) memcpy(in.c, L.com, sizeof(in.c));
+			inertials.push_back(in);
+			M->q_lower[j] = L.q_lower;
+			M->q_upper[j] = L.q_upper;
+			M->vel[j] = L.velocity_limit;
+			M->effort[j] = L.effort_limit;
+			M->dev.effort[j] = L.effort_limit;
+			m3_eye(Rp);
+			pp[0] = pp[1] = pp[2] = 0;
+		} else {
+			delete M;
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "link %s: unknown joint type %d", L.name, L.joint_type);
+		}
+		LinkInfo li;
+		li.name = std::string(L.name, strnlen(L.name, SAIP_NAME_LEN));
+		li.body = body;
+		memcpy(li.R, Rp, sizeof(Rp));
+		memcpy(li.p, pp, sizeof(pp));
+		M->links.push_back(li);
+	}
+	if (M->n == 0) {
+		delete M;
+		return fail(SAIP_ERR_INVALID_ARGUMENT, "robot has no movable joint");
+	}
+	M->dev.n = M->n;
+	for (int j = 0; j < M->n; j++) {
+		const Inertial& in = inertials[j];
+		M->dev.mass[j] = in.m;
+		memcpy(M->dev.com[j], in.c, sizeof(in.c));
+		M->dev.inertia[j][0] = in.I[0];
+		M->dev.inertia[j][1] = in.I[4];
+		M->dev.inertia[j][2] = in.I[8];
+		M->dev.inertia[j][3] = in.I[1];
+		M->dev.inertia[j][4] = in.I[2];
+		M->dev.inertia[j][5] = in.I[5];
+	}
+	M->dev.gravity[0] = 0;
+	M->dev.gravity[1] = 0;
+	M->dev.gravity[2] = -9.81;
+	*out = M;
+	return SAIP_OK;
+}
+extern "C" void saip_model_destroy(saip_model* m) { delete m; }
+extern "C" int saip_model_dof(const saip_model* m) { return m ? m->n : 0; }
+extern "C" int saip_model_link_index(const saip_model* m, const char* name) {
+	if (!m || !name) return -1;
+	for (size_t i = 0; i < m->links.size(); i++)
+		if (m->links[i].name == name) return (int)i;
+	return -1;
+}
+extern "C" saip_status saip_model_joint_limits(const saip_model* m, double* lo, double* hi, double* vel, double* eff) {
+	if (!m) return fail(SAIP_ERR_INVALID_ARGUMENT, "null model");
+	for (int j = 0; j < m->n; j++) {
+		if (lo) lo[j] = m->q_lower[j];
+		if (hi) hi[j] = m->q_upper[j];
+		if (vel) vel[j] = m->vel[j];
+		if (eff) eff[j] = m->effort[j];
+	}
+	return SAIP_OK;
+}
+
+// ------------------------------------------------------------------ batch
+struct TaskHost {
+	std::string name;
+	TaskDev dev;
+	double P[36];
+	bool otg_enabled = true;  // reference default (MotionForceTask.h:67, JointTask.h:38)
+	bool vel_sat = false;
+	bool full_joint = false;
+	double* goal_dev = nullptr;
+	double* integ_dev = nullptr;
+	double* diag_dev = nullptr;
+	int integ_rows = 0;
+};
+struct saip_batch {
+	const saip_model* model = nullptr;
+	int B = 0, ld = 0, device = -1;
+	bool finalized = false, models_valid = false, config_dirty = true;
+	bool gravity_comp = false, torque_sat = false, integ_always = false;
+	int kernel_choice = 0;
+	std::string kernel_name = "none";
+	std::vector<TaskHost> tasks;
+	hipStream_t stream = nullptr;
+	double *q = nullptr, *dq = nullptr, *tau = nullptr, *tau_bound = nullptr;
+	uint8_t* status = nullptr;
+	ModelDev* model_dev = nullptr;
+	TaskDev* tasks_dev = nullptr;
+	std::vector<void*> allocs;
+};
+
+static bool has_device(const saip_batch* b) { return b->device >= 0; }
+
+extern "C" int saip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" saip_status saip_batch_create(const saip_model* model, int batch_size, int device, saip_batch** out) {
+	if (!model || !out) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_create: null argument");
+	if (batch_size <= 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_create: batch size must be positive");
+	if (device >= 0) {
+		int cnt = saip_device_count();
+		if (cnt <= 0) return fail(SAIP_ERR_NO_DEVICE, "no HIP device available: the engine has no CPU path");
+		if (device >= cnt) return fail(SAIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, cnt);
+	}
+	auto* b = new saip_batch();
+	b->model = model;
+	b->B = batch_size;
+	b->ld = (batch_size + 31) / 32 * 32;
+	b->device = device;  // < 0: configuration-only batch (host logic can be exercised; every compute call fails)
+	*out = b;
+	return SAIP_OK;
+}
+extern "C" void saip_batch_destroy(saip_batch* b) {
+	if (!b) return;
+	if (has_device(b)) {
+		(void)hipSetDevice(b->device);
+		for (void* p : b->allocs) (void)hipFree(p);
+		if (b->stream) (void)hipStreamDestroy(b->stream);
+	}
+	delete b;
+}
+extern "C" int saip_batch_size(const saip_batch* b) { return b ? b->B : 0; }
+extern "C" int saip_batch_ld(const saip_batch* b) { return b ? b->ld : 0; }
+
+static saip_status check_batch(const saip_batch* b, int task, const char* fn) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: null batch", fn);
+	if (task >= (int)b->tasks.size() || task < -1) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: task id %d out of range", fn, task);
+	return SAIP_OK;
+}
+static void task_defaults(TaskDev& d, double dt) {
+	memset(&d, 0, sizeof(TaskDev));
+	d.dt = dt;
+	d.decoupling = SAIP_BOUNDED_INERTIA_ESTIMATES;  // MotionForceTask.h:41-43, JointTask.h:35-37
+	d.bie_threshold = 0.1;
+}
+
+extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const char* task_name, const char* link_name,
+														const double pos_in_link[3], const double rot_in_link[9],
+														const double* dirs_trans, int n_trans, const double* dirs_rot, int n_rot,
+														double loop_timestep, int* task_id) {
+	if (!b || !task_name || !link_name || !pos_in_link) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_add_motion_force_task: null argument");
+	if (b->finalized) return fail(SAIP_ERR_ORDER, "tasks cannot be added after saip_batch_finalize");
+	if ((int)b->tasks.size() >= SAIP_MAX_TASKS) return fail(SAIP_ERR_UNSUPPORTED, "more than %d tasks", SAIP_MAX_TASKS);
+	int li = saip_model_link_index(b->model, link_name);
+	if (li < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "link %s does not exist in the robot model", link_name);
+	const LinkInfo& L = b->model->links[li];
+	if (L.body < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "link %s is welded to the base: no controllable degree of freedom", link_name);
+	TaskHost T;
+	T.name = task_name;
+	task_defaults(T.dev, loop_timestep);
+	T.dev.type = saip::TASK_MOTION_FORCE;
+	T.dev.body = L.body;
+	double I3[9];
+	m3_eye(I3);
+	const double* Rin = rot_in_link ? rot_in_link : I3;
+	double t[3];
+	m3_vec(L.R, pos_in_link, t);
+	for (int i = 0; i < 3; i++) T.dev.pos[i] = L.p[i] + t[i];
+	m3_mul(L.R, Rin, T.dev.rot);
+	double bt[9], br[9];
+	int pr, orr;
+	if (n_trans < 0 && n_rot < 0) {  // full task, MotionForceTask.cpp:28
+		m3_eye(bt);
+		m3_eye(br);
+		pr = orr = 3;
+	} else {
+		if (n_trans <= 0 && n_rot <= 0)  // MotionForceTask.cpp:47-53
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "controlled_directions_translation and controlled_directions_rotation cannot both be empty in MotionForceTask::MotionForceTask");
+		if ((n_trans > 0 && !dirs_trans) || (n_rot > 0 && !dirs_rot)) return fail(SAIP_ERR_INVALID_ARGUMENT, "null direction array");
+		pr = range_basis_3(dirs_trans, n_trans > 0 ? n_trans : 0, bt);   // :55-87
+		orr = range_basis_3(dirs_rot, n_rot > 0 ? n_rot : 0, br);
+	}
+	if (pr + orr == 0)  // :154-160
+		return fail(SAIP_ERR_INVALID_ARGUMENT, "controlled_directions_translation and controlled_directions_rotation cannot both be empty in MotionForceTask::MotionForceTask");
+	if (pr + orr == 1)
+		return fail(SAIP_ERR_UNSUPPORTED, "rank-1 MotionForceTask: the reference's SingularityHandler never initialises its model for task_rank == 1 (SingularityHandler.cpp:100), refusing");
+	memset(T.P, 0, sizeof(T.P));
+	memset(T.dev.Bm, 0, sizeof(T.dev.Bm));
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			double sp = 0, so = 0;
+			for (int c = 0; c < pr; c++) sp += bt[3 * i + c] * bt[3 * j + c];
+			for (int c = 0; c < orr; c++) so += br[3 * i + c] * br[3 * j + c];
+			T.P[6 * i + j] = sp;
+			T.P[6 * (3 + i) + 3 + j] = so;
+			T.dev.Ppos[3 * i + j] = sp;
+			T.dev.Pori[3 * i + j] = so;
+		}
+	for (int i = 0; i < 3; i++) {
+		for (int c = 0; c < pr; c++) T.dev.Bm[6 * i + c] = bt[3 * i + c];
+		for (int c = 0; c < orr; c++) T.dev.Bm[6 * (3 + i) + pr + c] = br[3 * i + c];
+	}
+	// sigmaPosition = Ppos (I - sigmaForce) Ppos^T with force space dimension 0 (MotionForceTask.cpp:927-930), same for orientation
+	double PT[9];
+	m3_T(T.dev.Ppos, PT);
+	m3_mul(T.dev.Ppos, PT, T.dev.sig_p);
+	m3_T(T.dev.Pori, PT);
+	m3_mul(T.dev.Pori, PT, T.dev.sig_o);
+	T.dev.k = pr + orr;
+	T.dev.goal_comps = 24;
+	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:44-49
+		T.dev.kp_pos[i] = 100.0; T.dev.kv_pos[i] = 20.0; T.dev.ki_pos[i] = 0.0;
+		T.dev.kp_ori[i] = 200.0; T.dev.kv_ori[i] = 28.3; T.dev.ki_ori[i] = 0.0;
+	}
+	T.dev.s_min = 6e-3;   // MotionForceTask.cpp:197
+	T.dev.s_max = 6e-2;
+	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
+	T.integ_rows = 6;
+	b->tasks.push_back(T);
+	b->config_dirty = true;
+	if (task_id) *task_id = (int)b->tasks.size() - 1;
+	return SAIP_OK;
+}
+
+extern "C" saip_status saip_batch_add_joint_task(saip_batch* b, const char* task_name, const double* S, int rows, double loop_timestep, int* task_id) {
+	if (!b || !task_name) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_add_joint_task: null argument");
+	if (b->finalized) return fail(SAIP_ERR_ORDER, "tasks cannot be added after saip_batch_finalize");
+	if ((int)b->tasks.size() >= SAIP_MAX_TASKS) return fail(SAIP_ERR_UNSUPPORTED, "more than %d tasks", SAIP_MAX_TASKS);
+	const int n = b->model->n;
+	TaskHost T;
+	T.name = task_name;
+	task_defaults(T.dev, loop_timestep);
+	T.dev.type = saip::TASK_JOINT;
+	if (rows <= 0 || !S) {  // JointTask.cpp:18-19
+		T.dev.m = n;
+		T.dev.s_identity = 1;
+		for (int i = 0; i < n; i++) T.dev.S[i * n + i] = 1.0;
+		T.full_joint = true;
+	} else {
+		if (rows > n)  // a rows x n matrix with rows > n cannot have full row rank (JointTask.cpp:34-39)
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "joint selection matrix is not full rank in JointTask constructor");
+		// full row rank check (the reference uses FullPivLU, JointTask.cpp:34-39): Gaussian elimination with full pivoting
+		std::vector<double> A(S, S + (size_t)rows * n);
+		double amax = 0;
+		for (double v : A) amax = fmax(amax, fabs(v));
+		int rank = 0;
+		std::vector<char> rused(rows, 0), cused(n, 0);
+		for (int step = 0; step < rows; step++) {
+			int pi = -1, pj = -1;
+			double best = 0;
+			for (int i = 0; i < rows; i++)
+				if (!rused[i])
+					for (int j = 0; j < n; j++)
+						if (!cused[j] && fabs(A[(size_t)i * n + j]) > best) {
+							best = fabs(A[(size_t)i * n + j]);
+							pi = i;
+							pj = j;
+						}
+			if (pi < 0 || best <= amax * 1e-12 * (rows > n ? rows : n)) break;
+			rank++;
+			rused[pi] = cused[pj] = 1;
+			for (int i = 0; i < rows; i++)
+				if (!rused[i]) {
+					double f = A[(size_t)i * n + pj] / A[(size_t)pi * n + pj];
+					for (int j = 0; j < n; j++) A[(size_t)i * n + j] -= f * A[(size_t)pi * n + j];
+				}
+		}
+		if (rank != rows) return fail(SAIP_ERR_INVALID_ARGUMENT, "joint selection matrix is not full rank in JointTask constructor");
+		T.dev.m = rows;
+		memcpy(T.dev.S, S, sizeof(double) * rows * n);
+		bool ident = (rows == n);
+		for (int i = 0; i < rows && ident; i++)
+			for (int j = 0; j < n; j++)
+				if (S[i * n + j] != (i == j ? 1.0 : 0.0)) ident = false;
+		T.dev.s_identity = ident;
+		T.full_joint = (rows == n);  // JointTask::isFullJointTask(): task dof == robot dof
+	}
+	for (int i = 0; i < T.dev.m; i++) {  // JointTask.h:32-34
+		T.dev.kp[i] = 50.0;
+		T.dev.kv[i] = 14.0;
+		T.dev.ki[i] = 0.0;
+	}
+	T.dev.goal_comps = 3 * T.dev.m;
+	T.integ_rows = T.dev.m;
+	b->tasks.push_back(T);
+	b->config_dirty = true;
+	if (task_id) *task_id = (int)b->tasks.size() - 1;
+	return SAIP_OK;
+}
+
+template <typename Tp>
+static saip_status dev_alloc(saip_batch* b, Tp** p, size_t count) {
+	void* v = nullptr;
+	HIP_TRY(hipMalloc(&v, count * sizeof(Tp)));
+	HIP_TRY(hipMemset(v, 0, count * sizeof(Tp)));
+	b->allocs.push_back(v);
+	*p = (Tp*)v;
+	return SAIP_OK;
+}
+
+extern "C" saip_status saip_batch_finalize(saip_batch* b) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	if (b->finalized) return SAIP_OK;
+	// RobotController constructor checks, RobotController.cpp:8-66
+	if (b->tasks.empty()) return fail(SAIP_ERR_INVALID_ARGUMENT, "RobotController must have at least one task");
+	bool closed = false;
+	for (size_t i = 0; i < b->tasks.size(); i++) {
+		if (b->tasks[i].dev.dt != b->tasks[0].dev.dt) return fail(SAIP_ERR_INVALID_ARGUMENT, "All tasks must have the same loop timestep in RobotController");
+		for (size_t j = 0; j < i; j++)
+			if (b->tasks[j].name == b->tasks[i].name) return fail(SAIP_ERR_INVALID_ARGUMENT, "Tasks in RobotController must have unique names");
+		if (closed)
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "task [%s] cannot be added to the controller because it is in the nullspace of a full joint task", b->tasks[i].name.c_str());
+		if (b->tasks[i].dev.type == saip::TASK_JOINT && b->tasks[i].full_joint) closed = true;
+	}
+	if (has_device(b)) {
+		HIP_TRY(hipSetDevice(b->device));
+		HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+		const size_t n = b->model->n, ld = b->ld;
+		saip_status st;
+		if ((st = dev_alloc(b, &b->q, n * ld)) || (st = dev_alloc(b, &b->dq, n * ld)) || (st = dev_alloc(b, &b->tau, n * ld)) ||
+			(st = dev_alloc(b, &b->status, ld)) || (st = dev_alloc(b, &b->model_dev, 1)) || (st = dev_alloc(b, &b->tasks_dev, b->tasks.size())))
+			return st;
+		for (auto& T : b->tasks) {
+			if ((st = dev_alloc(b, &T.goal_dev, (size_t)T.dev.goal_comps * ld)) || (st = dev_alloc(b, &T.integ_dev, (size_t)T.integ_rows * ld))) return st;
+			T.dev.goal = T.goal_dev;
+			T.dev.integ = T.integ_dev;
+		}
+		HIP_TRY(hipMemcpy(b->model_dev, &b->model->dev, sizeof(ModelDev), hipMemcpyHostToDevice));
+	}
+	b->finalized = true;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+
+extern "C" int saip_batch_task_count(const saip_batch* b) { return b ? (int)b->tasks.size() : 0; }
+extern "C" int saip_batch_task_type(const saip_batch* b, int t) {
+	if (!b || t < 0 || t >= (int)b->tasks.size()) return SAIP_TASK_UNDEFINED;
+	return b->tasks[t].dev.type;
+}
+extern "C" const char* saip_batch_task_name(const saip_batch* b, int t) {
+	if (!b || t < 0 || t >= (int)b->tasks.size()) return nullptr;
+	return b->tasks[t].name.c_str();
+}
+extern "C" int saip_batch_task_by_name(const saip_batch* b, const char* name) {
+	if (!b || !name) return -1;
+	for (size_t i = 0; i < b->tasks.size(); i++)
+		if (b->tasks[i].name == name) return (int)i;
+	return -1;
+}
+extern "C" int saip_batch_task_dof(const saip_batch* b, int t) {
+	if (!b || t < 0 || t >= (int)b->tasks.size()) return 0;
+	return b->tasks[t].dev.type == saip::TASK_JOINT ? b->tasks[t].dev.m : b->tasks[t].dev.k;
+}
+extern "C" int saip_batch_goal_components(const saip_batch* b, int t) {
+	if (!b || t < 0 || t >= (int)b->tasks.size()) return 0;
+	return b->tasks[t].dev.goal_comps;
+}
+// projection of a motion-force task (parity tests): P 6x6 row-major, basis 6x6 row-major (first *rank columns valid)
+extern "C" saip_status saip_batch_get_task_projection(const saip_batch* b, int t, double* P36, double* basis36, int* rank) {
+	saip_status st = check_batch(b, t, "saip_batch_get_task_projection");
+	if (st) return st;
+	if (t < 0 || b->tasks[t].dev.type != saip::TASK_MOTION_FORCE) return fail(SAIP_ERR_INVALID_ARGUMENT, "task %d is not a MotionForceTask", t);
+	if (P36) memcpy(P36, b->tasks[t].P, sizeof(double) * 36);
+	if (basis36) memcpy(basis36, b->tasks[t].dev.Bm, sizeof(double) * 36);
+	if (rank) *rank = b->tasks[t].dev.k;
+	return SAIP_OK;
+}
+
+static saip_status set_gain3(double* kp, double* kv, double* ki, const double* p, const double* v, const double* i, int n_gains, const char* who) {
+	if (!p || !v || !i) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: null gain pointer", who);
+	if (n_gains != 1 && n_gains != 3) return fail(SAIP_ERR_INVALID_ARGUMENT, "kp, kv and ki should be of size 1 or 3 in %s", who);
+	for (int c = 0; c < n_gains; c++)
+		if (p[c] < 0 || v[c] < 0 || i[c] < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "all gains should be positive or zero in %s", who);
+	for (int c = 0; c < 3; c++) {
+		kp[c] = p[n_gains == 1 ? 0 : c];
+		kv[c] = v[n_gains == 1 ? 0 : c];
+		ki[c] = i[n_gains == 1 ? 0 : c];
+	}
+	return SAIP_OK;
+}
+static void refresh_has_ki(TaskDev& d) {
+	d.has_ki = 0;
+	if (d.type == saip::TASK_MOTION_FORCE) {
+		for (int c = 0; c < 3; c++)
+			if (d.ki_pos[c] != 0 || d.ki_ori[c] != 0) d.has_ki = 1;
+	} else {
+		for (int c = 0; c < d.m; c++)
+			if (d.ki[c] != 0) d.has_ki = 1;
+	}
+}
+static saip_status need_type(saip_batch* b, int t, int type, const char* fn) {
+	saip_status st = check_batch(b, t, fn);
+	if (st) return st;
+	if (t < 0 || b->tasks[t].dev.type != type) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: task %d has the wrong type", fn, t);
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_pos_control_gains(saip_batch* b, int t, const double* kp, const double* kv, const double* ki, int ng) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_pos_control_gains");
+	if (st) return st;
+	TaskDev& d = b->tasks[t].dev;
+	st = set_gain3(d.kp_pos, d.kv_pos, d.ki_pos, kp, kv, ki, ng, "MotionForceTask::setPosControlGains");
+	refresh_has_ki(d);
+	b->config_dirty = true;
+	return st;
+}
+extern "C" saip_status saip_batch_set_ori_control_gains(saip_batch* b, int t, const double* kp, const double* kv, const double* ki, int ng) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_ori_control_gains");
+	if (st) return st;
+	TaskDev& d = b->tasks[t].dev;
+	st = set_gain3(d.kp_ori, d.kv_ori, d.ki_ori, kp, kv, ki, ng, "MotionForceTask::setOriControlGains");
+	refresh_has_ki(d);
+	b->config_dirty = true;
+	return st;
+}
+extern "C" saip_status saip_batch_set_joint_gains(saip_batch* b, int t, const double* kp, const double* kv, const double* ki, int ng) {
+	saip_status st = need_type(b, t, saip::TASK_JOINT, "saip_batch_set_joint_gains");
+	if (st) return st;
+	TaskDev& d = b->tasks[t].dev;
+	if (!kp || !kv || !ki) return fail(SAIP_ERR_INVALID_ARGUMENT, "JointTask::setGains: null gain pointer");
+	if (ng != 1 && ng != d.m) return fail(SAIP_ERR_INVALID_ARGUMENT, "size of gain vectors inconsistent with number of task dofs in JointTask::setGains");
+	for (int c = 0; c < ng; c++)
+		if (kp[c] < 0 || kv[c] < 0 || ki[c] < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "gains must be positive or zero in JointTask::setGains");
+	for (int c = 0; c < d.m; c++) {
+		d.kp[c] = kp[ng == 1 ? 0 : c];
+		d.kv[c] = kv[ng == 1 ? 0 : c];
+		d.ki[c] = ki[ng == 1 ? 0 : c];
+	}
+	refresh_has_ki(d);
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_dynamic_decoupling_type(saip_batch* b, int t, int type) {
+	saip_status st = check_batch(b, t, "saip_batch_set_dynamic_decoupling_type");
+	if (st) return st;
+	if (t < 0 || type < 0 || type > 2) return fail(SAIP_ERR_INVALID_ARGUMENT, "Dynamic decoupling type not recognized");
+	b->tasks[t].dev.decoupling = type;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_bie_threshold(saip_batch* b, int t, double thr) {
+	saip_status st = check_batch(b, t, "saip_batch_set_bie_threshold");
+	if (st) return st;
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
+	// JointTask clamps negative thresholds to 0 (JointTask.h:372-378); SingularityHandler stores them as-is (SingularityHandler.h:81-86)
+	if (thr < 0 && b->tasks[t].dev.type == saip::TASK_JOINT) thr = 0;
+	b->tasks[t].dev.bie_threshold = thr;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_singularity_bounds(saip_batch* b, int t, double s_min, double s_max) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_singularity_bounds");
+	if (st) return st;
+	if (s_min < 0 || s_max < s_min) return fail(SAIP_ERR_INVALID_ARGUMENT, "singularity bounds must satisfy 0 <= s_min <= s_max");
+	b->tasks[t].dev.s_min = s_min;
+	b->tasks[t].dev.s_max = s_max;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_internal_otg(saip_batch* b, int t, int enabled) {
+	saip_status st = check_batch(b, t, "saip_batch_set_internal_otg");
+	if (st) return st;
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
+	b->tasks[t].otg_enabled = enabled != 0;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_velocity_saturation(saip_batch* b, int t, int enabled) {
+	saip_status st = check_batch(b, t, "saip_batch_set_velocity_saturation");
+	if (st) return st;
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
+	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "velocity saturation is not implemented on the device yet");
+	b->tasks[t].vel_sat = false;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_enable_gravity_compensation(saip_batch* b, int e) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->gravity_comp = e != 0;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_enable_joint_limit_avoidance(saip_batch* b, int e) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	if (e) return fail(SAIP_ERR_UNSUPPORTED, "joint limit avoidance torques (JointLimitAvoidanceTask.cpp:258-421) are not implemented on the device yet");
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_enable_torque_saturation(saip_batch* b, int e) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->torque_sat = e != 0;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_integrator_tracking(saip_batch* b, int always) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->integ_always = always != 0;
+	return SAIP_OK;
+}
+
+static saip_status need_ready(saip_batch* b, const char* fn) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: null batch", fn);
+	if (!b->finalized) return fail(SAIP_ERR_ORDER, "%s: call saip_batch_finalize first", fn);
+	if (!has_device(b)) return fail(SAIP_ERR_NO_DEVICE, "%s: configuration-only batch (no HIP device): the engine has no CPU path", fn);
+	if (hipSetDevice(b->device) != hipSuccess) return fail(SAIP_ERR_DEVICE, "hipSetDevice(%d) failed", b->device);
+	return SAIP_OK;
+}
+// host [comps][B] <-> device [comps][ld]
+static saip_status copy_h2d(saip_batch* b, double* dev, const double* host, int comps) {
+	HIP_TRY(hipMemcpy2DAsync(dev, (size_t)b->ld * sizeof(double), host, (size_t)b->B * sizeof(double), (size_t)b->B * sizeof(double), comps,
+							 hipMemcpyHostToDevice, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));  // the host buffer may be reused by the caller right away
+	return SAIP_OK;
+}
+static saip_status copy_d2h(saip_batch* b, double* host, const double* dev, int comps) {
+	HIP_TRY(hipMemcpy2DAsync(host, (size_t)b->B * sizeof(double), dev, (size_t)b->ld * sizeof(double), (size_t)b->B * sizeof(double), comps,
+							 hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+
+extern "C" saip_status saip_batch_set_state_host(saip_batch* b, const double* q, const double* dq) {
+	saip_status st = need_ready(b, "saip_batch_set_state_host");
+	if (st) return st;
+	if (!q || !dq) return fail(SAIP_ERR_INVALID_ARGUMENT, "null state pointer");
+	b->models_valid = false;
+	if ((st = copy_h2d(b, b->q, q, b->model->n))) return st;
+	return copy_h2d(b, b->dq, dq, b->model->n);
+}
+extern "C" saip_status saip_batch_set_goal_host(saip_batch* b, int t, const double* goal) {
+	saip_status st = need_ready(b, "saip_batch_set_goal_host");
+	if (st) return st;
+	if (t < 0 || t >= (int)b->tasks.size() || !goal) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task id or null goal");
+	return copy_h2d(b, b->tasks[t].goal_dev, goal, b->tasks[t].dev.goal_comps);
+}
+extern "C" saip_status saip_batch_set_goal_field_host(saip_batch* b, int t, int first, int count, const double* values) {
+	saip_status st = need_ready(b, "saip_batch_set_goal_field_host");
+	if (st) return st;
+	if (t < 0 || t >= (int)b->tasks.size() || !values) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task id or null values");
+	if (first < 0 || count <= 0 || first + count > b->tasks[t].dev.goal_comps)  // e.g. JointTask.cpp:110-114
+		return fail(SAIP_ERR_INVALID_ARGUMENT, "goal vector size not consistent with task dof");
+	return copy_h2d(b, b->tasks[t].goal_dev + (size_t)first * b->ld, values, count);
+}
+extern "C" saip_status saip_batch_get_goal_host(saip_batch* b, int t, double* goal) {
+	saip_status st = need_ready(b, "saip_batch_get_goal_host");
+	if (st) return st;
+	if (t < 0 || t >= (int)b->tasks.size() || !goal) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task id or null goal");
+	return copy_d2h(b, goal, b->tasks[t].goal_dev, b->tasks[t].dev.goal_comps);
+}
+
+extern "C" double* saip_batch_device_q(saip_batch* b) { return b ? b->q : nullptr; }
+extern "C" double* saip_batch_device_dq(saip_batch* b) { return b ? b->dq : nullptr; }
+extern "C" double* saip_batch_device_goal(saip_batch* b, int t) { return (b && t >= 0 && t < (int)b->tasks.size()) ? b->tasks[t].goal_dev : nullptr; }
+extern "C" double* saip_batch_device_tau(saip_batch* b) { return b ? (b->tau_bound ? b->tau_bound : b->tau) : nullptr; }
+extern "C" uint8_t* saip_batch_device_status(saip_batch* b) { return b ? b->status : nullptr; }
+extern "C" saip_status saip_batch_bind_tau_device(saip_batch* b, double* tau_dev) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->tau_bound = tau_dev;
+	return SAIP_OK;
+}
+extern "C" void* saip_batch_stream(saip_batch* b) { return b ? (void*)b->stream : nullptr; }
+
+static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
+	for (auto& T : b->tasks) {
+		if (T.otg_enabled)  // reference default; the device has no OTG
+			return fail(SAIP_ERR_UNSUPPORTED, "task [%s]: internal OTG is enabled (reference default) but not implemented on the device; call saip_batch_set_internal_otg(batch, task, 0) (disableInternalOtg)", T.name.c_str());
+	}
+	if (b->config_dirty || diag) {
+		std::vector<TaskDev> tmp;
+		for (auto& T : b->tasks) {
+			TaskDev d = T.dev;
+			d.diag_N = diag ? T.diag_dev : nullptr;
+			tmp.push_back(d);
+		}
+		HIP_TRY(hipMemcpyAsync(b->tasks_dev, tmp.data(), tmp.size() * sizeof(TaskDev), hipMemcpyHostToDevice, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));  // tmp is a stack object
+		b->config_dirty = diag;  // a diagnostic upload must be replaced before the next normal launch
+	}
+	P.B = b->B;
+	P.ld = b->ld;
+	P.n = b->model->n;
+	P.nt = (int)b->tasks.size();
+	P.gravity_comp = b->gravity_comp;
+	P.torque_sat = b->torque_sat;
+	P.integ_always = b->integ_always;
+	P.diag = diag;
+	P.q = b->q;
+	P.dq = b->dq;
+	P.tau = b->tau_bound ? b->tau_bound : b->tau;
+	P.status = b->status;
+	P.model = b->model_dev;
+	P.tasks = b->tasks_dev;
+	return SAIP_OK;
+}
+static saip_status launch_cycle(saip_batch* b, bool diag) {
+	CycleParams P;
+	saip_status st = make_params(b, P, diag);
+	if (st) return st;
+	bool lane_ok = false;
+	if (!diag && b->kernel_choice != 1) {
+		hipError_t e = saip::launch_cycle_lane(P, b->stream, &lane_ok);
+		if (lane_ok) {
+			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
+			b->kernel_name = "saip_cycle_lane";
+			return SAIP_OK;
+		}
+		if (b->kernel_choice == 2) return fail(SAIP_ERR_UNSUPPORTED, "the lane-per-instance kernel does not cover this robot/task stack");
+	}
+	hipError_t e = saip::launch_cycle_wg(P, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+	b->kernel_name = P.n <= 8 ? "saip_cycle_wg<8,64>" : "saip_cycle_wg<32,256>";
+	return SAIP_OK;
+}
+
+extern "C" saip_status saip_batch_reinitialize_tasks(saip_batch* b) {
+	saip_status st = need_ready(b, "saip_batch_reinitialize_tasks");
+	if (st) return st;
+	bool saved = false;
+	std::vector<bool> otg;
+	for (auto& T : b->tasks) otg.push_back(T.otg_enabled), T.otg_enabled = false;  // reinit does not depend on the OTG flag
+	(void)saved;
+	CycleParams P;
+	st = make_params(b, P, false);
+	for (size_t i = 0; i < b->tasks.size(); i++) b->tasks[i].otg_enabled = otg[i];
+	if (st) return st;
+	hipError_t e = saip::launch_reinit(P, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "reinit launch failed: %s", hipGetErrorString(e));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+
+extern "C" saip_status saip_batch_update_task_models(saip_batch* b) {
+	saip_status st = need_ready(b, "saip_batch_update_task_models");
+	if (st) return st;
+	// The task models are a pure function of the state set by saip_batch_set_state_host; the fused cycle kernel
+	// evaluates them together with the control law when computeControlTorques is called (goals may still change).
+	b->models_valid = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_step_async(saip_batch* b) {
+	saip_status st = need_ready(b, "saip_batch_step_async");
+	if (st) return st;
+	return launch_cycle(b, false);
+}
+extern "C" saip_status saip_batch_synchronize(saip_batch* b) {
+	saip_status st = need_ready(b, "saip_batch_synchronize");
+	if (st) return st;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_get_torques_host(saip_batch* b, double* tau_host, uint8_t* status_host) {
+	saip_status st = need_ready(b, "saip_batch_get_torques_host");
+	if (st) return st;
+	if (tau_host && (st = copy_d2h(b, tau_host, b->tau_bound ? b->tau_bound : b->tau, b->model->n))) return st;
+	if (status_host) {
+		HIP_TRY(hipMemcpyAsync(status_host, b->status, b->B, hipMemcpyDeviceToHost, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+	}
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_compute_control_torques(saip_batch* b, double* tau_host, uint8_t* status_host) {
+	saip_status st = need_ready(b, "saip_batch_compute_control_torques");
+	if (st) return st;
+	if (!b->models_valid)
+		return fail(SAIP_ERR_ORDER, "computeControlTorques: the robot state changed since the last updateControllerTaskModels (stale task models are not supported)");
+	if ((st = launch_cycle(b, false))) return st;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return saip_batch_get_torques_host(b, tau_host, status_host);
+}
+extern "C" saip_status saip_batch_get_task_nullspace_host(saip_batch* b, int t, double* N) {
+	saip_status st = need_ready(b, "saip_batch_get_task_nullspace_host");
+	if (st) return st;
+	if (t < 0 || t >= (int)b->tasks.size() || !N) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task id or null output");
+	const int n = b->model->n;
+	TaskHost& T = b->tasks[t];
+	if (!T.diag_dev && (st = dev_alloc(b, &T.diag_dev, (size_t)n * n * b->ld))) return st;
+	// the diagnostic pass must not advance integrator state: it re-evaluates the models only
+	bool ia = b->integ_always;
+	std::vector<int> hk;
+	for (auto& X : b->tasks) hk.push_back(X.dev.has_ki), X.dev.has_ki = 0;
+	b->integ_always = false;
+	st = launch_cycle(b, true);
+	b->integ_always = ia;
+	for (size_t i = 0; i < b->tasks.size(); i++) b->tasks[i].dev.has_ki = hk[i];
+	b->config_dirty = true;
+	if (st) return st;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return copy_d2h(b, N, T.diag_dev, n * n);
+}
+extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
+	if (!b || which < 0 || which > 2) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1 or 2");
+	b->kernel_choice = which;
+	return SAIP_OK;
+}
+extern "C" const char* saip_batch_kernel_name(saip_batch* b) { return b ? b->kernel_name.c_str() : ""; }
+
+extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmup, double* elapsed_ms) {
+	saip_status st = need_ready(b, "saip_batch_time_steps");
+	if (st) return st;
+	if (steps <= 0 || warmup < 0 || !elapsed_ms) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad timing arguments");
+	for (int i = 0; i < warmup; i++)
+		if ((st = launch_cycle(b, false))) return st;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, b->stream));
+	for (int i = 0; i < steps; i++)
+		if ((st = launch_cycle(b, false))) return st;
+	HIP_TRY(hipEventRecord(e1, b->stream));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	*elapsed_ms = ms;
+	return SAIP_OK;
+}
+
+extern "C" const char* saip_last_error(void) { return g_err.c_str(); }
+extern "C" const char* saip_version(void) { return "saip 0.1 (gfx950)"; }

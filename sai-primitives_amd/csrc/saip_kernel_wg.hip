@@ -1,0 +1,790 @@
+// General control-cycle kernel: ONE WORKGROUP PER ROBOT INSTANCE, every matrix of the instance resident in LDS.
+//
+// Covers any serial chain with dof <= NMAX and any task stack (runtime sizes, batch-uniform control flow).
+//   NMAX = 8,  T = 64  : one wavefront per instance (Panda-class arms), ~12 KB LDS -> up to 13 instances per CU
+//   NMAX = 32, T = 256 : four wavefronts per instance (humanoid-scale chains), ~125 KB LDS -> 1 instance per CU
+//
+// What it computes (reference call stack):
+//   SaiModel::updateModel()                       -> fk_prefix(), composite_inertia(), mass_matrix(), spd_inverse()
+//   RobotController::updateControllerTaskModels() -> per task: projected Jacobian, range / singular values, Lambda, N
+//       /root/reference/src/RobotController.cpp:68-77, tasks/MotionForceTask.cpp:247-268,
+//       tasks/SingularityHandler.cpp:75-228 (non-singular branch), tasks/JointTask.cpp:218-283
+//   RobotController::computeControlTorques()      -> per task control law + torque mapping + disturbance compensation
+//       /root/reference/src/RobotController.cpp:79-118, tasks/MotionForceTask.cpp:270-509,
+//       tasks/SingularityHandler.cpp:297-309, tasks/JointTask.cpp:285-356
+//
+// Algorithms differ from the reference's (and from the CPU oracle's) on purpose:
+//   - forward kinematics as a log-step prefix product over the chain (all lanes busy) instead of a serial walk,
+//   - M(q) from world-frame composite spatial inertias (suffix sums) instead of RBDL's CRBA recursion,
+//   - every inverse is an SPD inverse via Cholesky (M, M_BIE, J M^-1 J^T) instead of general LU inverses,
+//   - the SVDs of SingularityHandler / matrixRangeBasis are replaced by a parallel-ordered Jacobi eigen-solve of the
+//     small Gram matrix Jp Jp^T: its eigenvalues are sigma^2 (branch predicates), its eigenvectors the left singular
+//     vectors (range basis).  For the fully non-singular branch the torques are invariant to the choice of
+//     orthonormal basis of range(Jp), so the basis of range(P) is used directly.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "saip_device.h"
+
+namespace saip {
+
+#define SYNC() __syncthreads()
+
+enum { GEMM_SET = 0, GEMM_I_MINUS = 1, GEMM_ADD = 2, GEMM_SUB = 3 };
+
+// C(m x p) (op)= A(m x k) * B(k x p); A(i,l) = A[i*ars + l*acs], B(l,j) = B[l*brs + j*bcs]  (strides express transposes)
+template <int T>
+__device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ars, int acs, const double* Bm, int brs, int bcs,
+									 int m, int k, int p, int tid, int mode = GEMM_SET) {
+	for (int e = tid; e < m * p; e += T) {
+		int i = e / p, j = e - i * p;
+		double s = 0.0;
+		for (int l = 0; l < k; l++) s = fma(A[i * ars + l * acs], Bm[l * brs + j * bcs], s);
+		double* c = C + i * ldc + j;
+		if (mode == GEMM_SET) *c = s;
+		else if (mode == GEMM_I_MINUS) *c = (i == j ? 1.0 : 0.0) - s;
+		else if (mode == GEMM_ADD) *c += s;
+		else *c -= s;
+	}
+}
+
+// Aout = Ain^-1 for a symmetric positive definite n x n matrix.  WL, WX: n x n work (ld), dv: n doubles.
+// Cholesky (right-looking, 2 barriers per column) -> L^-1 by column-parallel forward substitution -> L^-T L^-1.
+template <int T>
+__device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double* WX, double* dv, int n, int ld, int tid) {
+	for (int e = tid; e < n * n; e += T) {
+		int i = e / n, j = e - i * n;
+		WL[i * ld + j] = Ain[i * ld + j];
+	}
+	SYNC();
+	for (int k = 0; k < n; k++) {
+		double d = sqrt(WL[k * ld + k]);
+		double rd = 1.0 / d;
+		for (int i = k + 1 + tid; i < n; i += T) WL[i * ld + k] *= rd;
+		if (tid == 0) dv[k] = d;
+		SYNC();
+		int rem = n - k - 1;
+		for (int e = tid; e < rem * rem; e += T) {
+			int a = e / rem, b = e - a * rem;
+			if (b <= a) {
+				int i = k + 1 + a, j = k + 1 + b;
+				WL[i * ld + j] = fma(-WL[i * ld + k], WL[j * ld + k], WL[i * ld + j]);
+			}
+		}
+		SYNC();
+	}
+	// X = L^-1 (lower); thread c owns column c
+	for (int c = tid; c < n; c += T) {
+		WX[c * ld + c] = 1.0 / dv[c];
+		for (int i = c + 1; i < n; i++) {
+			double s = 0.0;
+			for (int k = c; k < i; k++) s = fma(WL[i * ld + k], WX[k * ld + c], s);
+			WX[i * ld + c] = -s / dv[i];
+		}
+	}
+	SYNC();
+	for (int e = tid; e < n * n; e += T) {
+		int i = e / n, j = e - i * n;
+		int k0 = i > j ? i : j;
+		double s = 0.0;
+		for (int k = k0; k < n; k++) s = fma(WX[k * ld + i], WX[k * ld + j], s);
+		Aout[i * ld + j] = s;
+	}
+	SYNC();
+}
+
+// Symmetric eigen-decomposition by parallel-ordered (round-robin) Jacobi: A -> diag (eigenvalues), V (optional) <- eigenvectors.
+// cs: 4*(NMAX/2+1) doubles scratch, flag: one int in LDS.  3 barriers per round, n-1 (n even) or n rounds per sweep.
+template <int T>
+__device__ void jacobi_eig(double* A, double* V, int n, int ld, double* cs, int* flag, int tid) {
+	if (V) {
+		for (int e = tid; e < n * n; e += T) {
+			int i = e / n, j = e - i * n;
+			V[i * ld + j] = (i == j) ? 1.0 : 0.0;
+		}
+	}
+	double tr = 0.0;
+	for (int i = 0; i < n; i++) tr += fabs(A[i * ld + i]);
+	const double thresh = 1e-15 * (tr / n);  // off-diagonals below this are zero for every downstream tolerance
+	if (n < 2) {
+		SYNC();
+		return;
+	}
+	const int npad = (n + 1) & ~1, half = npad >> 1, rounds = npad - 1;
+	for (int sweep = 0; sweep < 14; sweep++) {
+		if (tid == 0) *flag = 0;
+		SYNC();
+		for (int r = 0; r < rounds; r++) {
+			if (tid < half) {
+				int p, q;
+				if (tid == 0) {
+					p = npad - 1;
+					q = r;
+				} else {
+					p = (r + tid) % rounds;
+					q = (r - tid + rounds) % rounds;
+				}
+				if (p > q) {
+					int t_ = p;
+					p = q;
+					q = t_;
+				}
+				double c = 1.0, s = 0.0;
+				if (q < n) {
+					double app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
+					if (fabs(apq) > thresh) {
+						double theta = (aqq - app) / (2.0 * apq);
+						double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+						c = 1.0 / sqrt(t * t + 1.0);
+						s = t * c;
+						*flag = 1;
+					}
+				} else {
+					q = -1;
+				}
+				cs[4 * tid + 0] = c;
+				cs[4 * tid + 1] = s;
+				cs[4 * tid + 2] = (double)p;
+				cs[4 * tid + 3] = (double)q;
+			}
+			SYNC();
+			// column rotation A <- A J, V <- V J
+			for (int e = tid; e < n * half; e += T) {
+				int i = e / half, pi = e - i * half;
+				int q = (int)cs[4 * pi + 3];
+				if (q < 0) continue;
+				int p = (int)cs[4 * pi + 2];
+				double c = cs[4 * pi], s = cs[4 * pi + 1];
+				double ap = A[i * ld + p], aq = A[i * ld + q];
+				A[i * ld + p] = c * ap - s * aq;
+				A[i * ld + q] = s * ap + c * aq;
+				if (V) {
+					double vp = V[i * ld + p], vq = V[i * ld + q];
+					V[i * ld + p] = c * vp - s * vq;
+					V[i * ld + q] = s * vp + c * vq;
+				}
+			}
+			SYNC();
+			// row rotation A <- J^T A
+			for (int e = tid; e < n * half; e += T) {
+				int pi = e / n, j = e - pi * n;
+				int q = (int)cs[4 * pi + 3];
+				if (q < 0) continue;
+				int p = (int)cs[4 * pi + 2];
+				double c = cs[4 * pi], s = cs[4 * pi + 1];
+				double ap = A[p * ld + j], aq = A[q * ld + j];
+				A[p * ld + j] = c * ap - s * aq;
+				A[q * ld + j] = s * ap + c * aq;
+			}
+			SYNC();
+		}
+		if (*flag == 0) break;
+		SYNC();
+	}
+}
+
+__device__ __forceinline__ void mat3_mul_vec(const double* R, const double* v, double* o) {
+	o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+	o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+	o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+
+template <int NMAX>
+struct WgSmem {
+	static constexpr int LD = NMAX + 1;
+	static constexpr int MS = NMAX * LD;
+	static constexpr int NWORK = 9;
+	double Minv[MS], MBinv[MS], NpA[MS], NpB[MS];
+	double W[NWORK][MS];
+	double fkA[NMAX * 12], fkB[NMAX * 12];  // per body: R (9, row-major) + o (3), world frame
+	double zax[NMAX * 3];                   // world joint axes
+	double body[NMAX * 10], comp[NMAX * 10];  // spatial inertia about the world origin: m, h(3)=m*c, Io(6: xx yy zz xy xz yz)
+	double Jw[6 * LD];
+	double q[NMAX], dq[NMAX], tau[NMAX], v0[NMAX], v1[NMAX], v2[NMAX], v3[NMAX], v4[NMAX], dv[NMAX];
+	double goal[3 * NMAX > 24 ? 3 * NMAX : 24];
+	double vw[6], Fum[6], xp[3], Rc[9];
+	double cs[4 * (NMAX / 2 + 1)];
+	int colidx[NMAX];
+	int flag, rank;
+};
+
+template <int NMAX, int T>
+__global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
+	using SM = WgSmem<NMAX>;
+	constexpr int LD = SM::LD;
+	__shared__ SM sm;
+	const int tid = threadIdx.x;
+	const int b = blockIdx.x;
+	if (b >= P.B) return;
+	const int n = P.n;
+	const ModelDev& md = *P.model;
+
+	// ---------------------------------------------------------------- state
+	if (tid < n) {
+		sm.q[tid] = P.q[(size_t)tid * P.ld + b];
+		sm.dq[tid] = P.dq[(size_t)tid * P.ld + b];
+		sm.tau[tid] = 0.0;
+	}
+	SYNC();
+	// ---------------------------------------------------------------- updateModel(): kinematics
+	// local transforms X_j = (R0_j * Rot(axis_j, q_j), p0_j [+ R0_j axis_j q_j])
+	for (int j = tid; j < n; j += T) {
+		double* X = sm.fkA + 12 * j;
+		const double* R0 = md.R0[j];
+		const double ax = md.axis[j][0], ay = md.axis[j][1], az = md.axis[j][2];
+		if (md.jtype[j] == 1) {
+			double s, c;
+			sincos(sm.q[j], &s, &c);
+			double v = 1.0 - c;
+			double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+							ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+							az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+			for (int r = 0; r < 3; r++)
+				for (int cc = 0; cc < 3; cc++) X[3 * r + cc] = R0[3 * r] * Rq[cc] + R0[3 * r + 1] * Rq[3 + cc] + R0[3 * r + 2] * Rq[6 + cc];
+			X[9] = md.p0[j][0];
+			X[10] = md.p0[j][1];
+			X[11] = md.p0[j][2];
+		} else {
+			for (int e = 0; e < 9; e++) X[e] = R0[e];
+			double a[3] = {ax, ay, az}, d[3];
+			mat3_mul_vec(R0, a, d);
+			for (int e = 0; e < 3; e++) X[9 + e] = md.p0[j][e] + d[e] * sm.q[j];
+		}
+	}
+	SYNC();
+	// log-step prefix product: T_j <- T_{j-d} o T_j,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
+	double* fk = sm.fkA;
+	double* fk2 = sm.fkB;
+	for (int d = 1; d < n; d <<= 1) {
+		for (int e = tid; e < n * 12; e += T) {
+			int j = e / 12, c = e - 12 * j;
+			const double* Xb = fk + 12 * j;
+			double val;
+			if (j < d) {
+				val = Xb[c];
+			} else {
+				const double* Xa = fk + 12 * (j - d);
+				if (c < 9) {
+					int r = c / 3, cc = c - 3 * r;
+					val = Xa[3 * r] * Xb[cc] + Xa[3 * r + 1] * Xb[3 + cc] + Xa[3 * r + 2] * Xb[6 + cc];
+				} else {
+					int r = c - 9;
+					val = Xa[9 + r] + Xa[3 * r] * Xb[9] + Xa[3 * r + 1] * Xb[10] + Xa[3 * r + 2] * Xb[11];
+				}
+			}
+			fk2[e] = val;
+		}
+		SYNC();
+		double* t_ = fk;
+		fk = fk2;
+		fk2 = t_;
+	}
+	// world axes + per-body spatial inertia about the world origin
+	for (int j = tid; j < n; j += T) {
+		const double* R = fk + 12 * j;
+		const double* o = R + 9;
+		double a[3] = {md.axis[j][0], md.axis[j][1], md.axis[j][2]}, z[3], c[3], cl[3] = {md.com[j][0], md.com[j][1], md.com[j][2]};
+		mat3_mul_vec(R, a, z);
+		mat3_mul_vec(R, cl, c);
+		for (int e = 0; e < 3; e++) {
+			sm.zax[3 * j + e] = z[e];
+			c[e] += o[e];
+		}
+		const double* I6 = md.inertia[j];
+		double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]}, RI[9], Iw[9];
+		for (int r = 0; r < 3; r++)
+			for (int cc = 0; cc < 3; cc++) RI[3 * r + cc] = R[3 * r] * Il[cc] + R[3 * r + 1] * Il[3 + cc] + R[3 * r + 2] * Il[6 + cc];
+		for (int r = 0; r < 3; r++)
+			for (int cc = 0; cc < 3; cc++) Iw[3 * r + cc] = RI[3 * r] * R[3 * cc] + RI[3 * r + 1] * R[3 * cc + 1] + RI[3 * r + 2] * R[3 * cc + 2];
+		double m = md.mass[j], cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+		double* Bd = sm.body + 10 * j;
+		Bd[0] = m;
+		Bd[1] = m * c[0];
+		Bd[2] = m * c[1];
+		Bd[3] = m * c[2];
+		Bd[4] = Iw[0] + m * (cc2 - c[0] * c[0]);
+		Bd[5] = Iw[4] + m * (cc2 - c[1] * c[1]);
+		Bd[6] = Iw[8] + m * (cc2 - c[2] * c[2]);
+		Bd[7] = Iw[1] - m * c[0] * c[1];
+		Bd[8] = Iw[2] - m * c[0] * c[2];
+		Bd[9] = Iw[5] - m * c[1] * c[2];
+	}
+	SYNC();
+	// composite inertias: suffix sums (plain sums, everything is expressed about the world origin)
+	for (int e = tid; e < n * 10; e += T) {
+		int j = e / 10, c = e - 10 * j;
+		double s = 0.0;
+		for (int l = j; l < n; l++) s += sm.body[10 * l + c];
+		sm.comp[e] = s;
+	}
+	SYNC();
+	// ---------------------------------------------------------------- M(q): M_ij = S_i . (Ic_j S_j), i <= j
+	double* Mm = sm.W[0];
+	double* MB = sm.W[1];
+	for (int e = tid; e < n * n; e += T) {
+		int i = e / n, j = e - i * n;
+		if (i > j) continue;
+		const double* Ic = sm.comp + 10 * j;
+		const double* zj = sm.zax + 3 * j;
+		const double* oj = fk + 12 * j + 9;
+		double w[3], v[3];  // spatial motion of joint j about the world origin: angular w, linear v
+		if (md.jtype[j] == 1) {
+			w[0] = zj[0]; w[1] = zj[1]; w[2] = zj[2];
+			v[0] = oj[1] * zj[2] - oj[2] * zj[1];
+			v[1] = oj[2] * zj[0] - oj[0] * zj[2];
+			v[2] = oj[0] * zj[1] - oj[1] * zj[0];
+		} else {
+			w[0] = w[1] = w[2] = 0.0;
+			v[0] = zj[0]; v[1] = zj[1]; v[2] = zj[2];
+		}
+		const double m = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
+		double f[3] = {m * v[0] + (w[1] * hz - w[2] * hy), m * v[1] + (w[2] * hx - w[0] * hz), m * v[2] + (w[0] * hy - w[1] * hx)};
+		double nO[3] = {Ic[4] * w[0] + Ic[7] * w[1] + Ic[8] * w[2] + (hy * v[2] - hz * v[1]),
+						Ic[7] * w[0] + Ic[5] * w[1] + Ic[9] * w[2] + (hz * v[0] - hx * v[2]),
+						Ic[8] * w[0] + Ic[9] * w[1] + Ic[6] * w[2] + (hx * v[1] - hy * v[0])};
+		const double* zi = sm.zax + 3 * i;
+		const double* oi = fk + 12 * i + 9;
+		double val;
+		if (md.jtype[i] == 1) {
+			double vi[3] = {oi[1] * zi[2] - oi[2] * zi[1], oi[2] * zi[0] - oi[0] * zi[2], oi[0] * zi[1] - oi[1] * zi[0]};
+			val = zi[0] * nO[0] + zi[1] * nO[1] + zi[2] * nO[2] + vi[0] * f[0] + vi[1] * f[1] + vi[2] * f[2];
+		} else {
+			val = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
+		}
+		Mm[i * LD + j] = val;
+		Mm[j * LD + i] = val;
+	}
+	SYNC();
+	// does any task use bounded inertia estimates?  (M_BIE: diagonal clamped from below, SingularityHandler.cpp:176-182)
+	bool any_bie = false;
+	double bie_thr = 0.0;
+	for (int t = 0; t < P.nt; t++)
+		if (P.tasks[t].decoupling == DEC_BIE) {
+			any_bie = true;
+			bie_thr = P.tasks[t].bie_threshold;  // per-task thresholds that differ are handled below by recomputing
+		}
+	spd_inverse<T>(Mm, sm.Minv, sm.W[2], sm.W[3], sm.dv, n, LD, tid);
+	double cur_bie_thr = -1.0;
+	if (any_bie) {
+		for (int e = tid; e < n * n; e += T) {
+			int i = e / n, j = e - i * n;
+			double v = Mm[i * LD + j];
+			if (i == j && v < bie_thr) v = bie_thr;
+			MB[i * LD + j] = v;
+		}
+		SYNC();
+		spd_inverse<T>(MB, sm.MBinv, sm.W[2], sm.W[3], sm.dv, n, LD, tid);
+		cur_bie_thr = bie_thr;
+	}
+	// keep M for per-task BIE thresholds that differ from cur_bie_thr: W[8] is reserved for it
+	double* Mkeep = sm.W[8];
+	for (int e = tid; e < n * n; e += T) {
+		int i = e / n, j = e - i * n;
+		Mkeep[i * LD + j] = Mm[i * LD + j];
+	}
+	// N_prec = I
+	double* Np = sm.NpA;
+	double* Np2 = sm.NpB;
+	for (int e = tid; e < n * n; e += T) {
+		int i = e / n, j = e - i * n;
+		Np[i * LD + j] = (i == j) ? 1.0 : 0.0;
+	}
+	SYNC();
+
+	bool singular = false;
+	// ---------------------------------------------------------------- task hierarchy
+	for (int t = 0; t < P.nt; t++) {
+		const TaskDev& tk = P.tasks[t];
+		double* Jh = sm.W[4];
+		int r = 0;           // rank of the task in its range basis
+		bool empty = false;  // JointTask with no controllable dof left
+		bool u_identity = true;
+		const int gs = tk.goal_comps;
+		for (int e = tid; e < gs; e += T) sm.goal[e] = tk.goal[(size_t)e * P.ld + b];
+
+		if (tk.type == TASK_MOTION_FORCE) {
+			const int k = tk.k, bd = tk.body;
+			// control point, control frame, world Jacobian [Jv; Jw] (JWorldFrame)
+			const double* Rb = fk + 12 * bd;
+			const double* ob = Rb + 9;
+			double pw[3];
+			mat3_mul_vec(Rb, tk.pos, pw);
+			for (int e = 0; e < 3; e++) pw[e] += ob[e];
+			if (tid < 3) sm.xp[tid] = pw[tid];
+			if (tid < 9) {
+				int rr = tid / 3, cc = tid - 3 * rr;
+				sm.Rc[tid] = Rb[3 * rr] * tk.rot[cc] + Rb[3 * rr + 1] * tk.rot[3 + cc] + Rb[3 * rr + 2] * tk.rot[6 + cc];
+			}
+			for (int j = tid; j < n; j += T) {
+				double col[6] = {0, 0, 0, 0, 0, 0};
+				if (j <= bd) {
+					const double* z = sm.zax + 3 * j;
+					if (md.jtype[j] == 1) {
+						const double* o = fk + 12 * j + 9;
+						double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
+						col[0] = z[1] * rz - z[2] * ry;
+						col[1] = z[2] * rx - z[0] * rz;
+						col[2] = z[0] * ry - z[1] * rx;
+						col[3] = z[0]; col[4] = z[1]; col[5] = z[2];
+					} else {
+						col[0] = z[0]; col[1] = z[1]; col[2] = z[2];
+					}
+				}
+				for (int e = 0; e < 6; e++) sm.Jw[e * LD + j] = col[e];
+			}
+			SYNC();
+			// Jb = Bm^T Jw (k x n): rows of the task Jacobian in the basis of range(P)
+			gemm<T>(sm.W[0], LD, tk.Bm, 1, 6, sm.Jw, LD, 1, k, 6, n, tid);
+			// task-frame velocities use the UNprojected J = P Jw (MotionForceTask.cpp:293-298): vw = Jw dq
+			if (tid < 6) {
+				double s = 0.0;
+				for (int j = 0; j < n; j++) s = fma(sm.Jw[tid * LD + j], sm.dq[j], s);
+				sm.vw[tid] = s;
+			}
+			SYNC();
+			gemm<T>(Jh, LD, sm.W[0], LD, 1, Np, LD, 1, k, n, n, tid);  // Jh = Jb N_prec
+			SYNC();
+			// singular values of the projected Jacobian: eig(Jh Jh^T) = sigma^2   (SingularityHandler.cpp:78-121)
+			gemm<T>(sm.W[1], LD, Jh, LD, 1, Jh, 1, LD, k, n, k, tid);
+			SYNC();
+			jacobi_eig<T>(sm.W[1], nullptr, k, LD, sm.cs, &sm.flag, tid);
+			double lmax = 0.0;
+			for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
+			double s0 = sqrt(lmax);
+			bool sing = (s0 < tk.s_abs_tol);
+			for (int i = 0; i < k; i++) {
+				double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
+				if (si / s0 < tk.s_max) sing = true;
+			}
+			if (sing) singular = true;
+			r = k;
+			SYNC();
+		} else {
+			const int m = tk.m;
+			// Jp = S N_prec  (JointTask.cpp:231)
+			const double* Jp = Np;
+			if (!tk.s_identity) {
+				gemm<T>(sm.W[0], LD, tk.S, n, 1, Np, LD, 1, m, n, n, tid);
+				Jp = sm.W[0];
+				SYNC();
+			}
+			// matrixRangeBasis(Jp): eigen-decomposition of the Gram matrix Jp Jp^T (m x m)
+			gemm<T>(sm.W[1], LD, Jp, LD, 1, Jp, 1, LD, m, n, m, tid);
+			SYNC();
+			double tr = 0.0;
+			for (int i = 0; i < m; i++) tr += sm.W[1][i * LD + i];  // ||Jp||_F^2
+			SYNC();
+			jacobi_eig<T>(sm.W[1], sm.W[2], m, LD, sm.cs, &sm.flag, tid);
+			if (tid == 0) {
+				double lmax = 0.0;
+				for (int i = 0; i < m; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
+				int rr = 0;
+				if (sqrt(fmax(tr, 0.0)) >= 1e-3 && sqrt(lmax) >= 1e-3) {
+					for (int i = 0; i < m; i++)
+						if (sqrt(fmax(sm.W[1][i * LD + i], 0.0) / lmax) >= 1e-3) sm.colidx[rr++] = i;
+				}
+				sm.rank = rr;
+			}
+			SYNC();
+			r = sm.rank;
+			empty = (r == 0);
+			u_identity = (r == m);
+			if (!empty) {
+				if (u_identity) {
+					for (int e = tid; e < m * n; e += T) {
+						int i = e / n, j = e - i * n;
+						Jh[i * LD + j] = Jp[i * LD + j];
+					}
+				} else {
+					// U = selected eigenvectors (m x r) -> W[3];  Jh = U^T Jp
+					for (int e = tid; e < m * r; e += T) {
+						int i = e / r, c = e - i * r;
+						sm.W[3][i * LD + c] = sm.W[2][i * LD + sm.colidx[c]];
+					}
+					SYNC();
+					gemm<T>(Jh, LD, sm.W[3], 1, LD, Jp, LD, 1, r, m, n, tid);
+				}
+			}
+			SYNC();
+		}
+
+		double* Lam = sm.W[2];
+		double* Lmod = sm.W[7];
+		double* Nt = sm.W[6];
+		if (!empty && !singular) {
+			// operationalSpaceMatrices(Jh): Lambda = (Jh M^-1 Jh^T)^-1, N = I - M^-1 Jh^T Lambda Jh
+			gemm<T>(sm.W[0], LD, Jh, LD, 1, sm.Minv, LD, 1, r, n, n, tid);  // T1 = Jh Minv
+			SYNC();
+			gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, Jh, 1, LD, r, n, r, tid);  // A = T1 Jh^T
+			SYNC();
+			spd_inverse<T>(sm.W[1], Lam, sm.W[5], sm.W[6], sm.dv, r, LD, tid);
+			gemm<T>(sm.W[5], LD, Lam, LD, 1, sm.W[0], LD, 1, r, r, n, tid);  // T2 = Lambda T1 = Jbar^T
+			SYNC();
+			gemm<T>(Nt, LD, sm.W[5], 1, LD, Jh, LD, 1, n, r, n, tid, GEMM_I_MINUS);  // N = I - T2^T Jh
+			SYNC();
+			if (tk.decoupling == DEC_FULL) {
+				Lmod = Lam;
+			} else if (tk.decoupling == DEC_IMPEDANCE) {
+				for (int e = tid; e < r * r; e += T) {
+					int i = e / r, j = e - i * r;
+					Lmod[i * LD + j] = (i == j) ? 1.0 : 0.0;
+				}
+				SYNC();
+			} else {
+				if (tk.bie_threshold != cur_bie_thr) {  // another threshold than the cached one: rebuild M_BIE^-1
+					for (int e = tid; e < n * n; e += T) {
+						int i = e / n, j = e - i * n;
+						double v = Mkeep[i * LD + j];
+						if (i == j && v < tk.bie_threshold) v = tk.bie_threshold;
+						sm.W[1][i * LD + j] = v;
+					}
+					SYNC();
+					spd_inverse<T>(sm.W[1], sm.MBinv, sm.W[0], sm.W[5], sm.dv, n, LD, tid);
+					cur_bie_thr = tk.bie_threshold;
+				}
+				gemm<T>(sm.W[0], LD, Jh, LD, 1, sm.MBinv, LD, 1, r, n, n, tid);
+				SYNC();
+				gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, Jh, 1, LD, r, n, r, tid);
+				SYNC();
+				spd_inverse<T>(sm.W[1], Lmod, sm.W[5], sm.W[0], sm.dv, r, LD, tid);
+			}
+			if (P.diag && tk.diag_N) {
+				for (int e = tid; e < n * n; e += T) {
+					int i = e / n, j = e - i * n;
+					tk.diag_N[(size_t)e * P.ld + b] = Nt[i * LD + j];
+				}
+			}
+
+			// ------------------------------------------------------------ control law -> g (r) in v3, then tau_t = Jh^T g
+			const bool track = (tk.has_ki || P.integ_always);
+			if (tk.type == TASK_MOTION_FORCE) {
+				if (tid == 0) {
+					const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3
+					double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
+					mat3_mul_vec(tk.Ppos, sm.vw, v);
+					mat3_mul_vec(tk.Pori, sm.vw + 3, w);
+					if (track)
+						for (int i = 0; i < 3; i++) {
+							ip[i] = tk.integ[(size_t)i * P.ld + b];
+							io[i] = tk.integ[(size_t)(3 + i) * P.ld + b];
+						}
+					for (int i = 0; i < 3; i++) e3[i] = sm.xp[i] - G[i];
+					mat3_mul_vec(tk.sig_p, e3, tmp);
+					for (int i = 0; i < 3; i++) ip[i] += tmp[i] * tk.dt;  // MotionForceTask.cpp:411-413
+					for (int i = 0; i < 3; i++) tmp[i] = G[18 + i] - tk.kp_pos[i] * e3[i] - tk.kv_pos[i] * (v[i] - G[12 + i]) - tk.ki_pos[i] * ip[i];
+					mat3_mul_vec(tk.sig_p, tmp, sm.Fum);  // :431-437
+					// orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+					double oe[3] = {0, 0, 0};
+					const double* Rd = G + 3;
+					for (int c = 0; c < 3; c++) {
+						double a0 = sm.Rc[c], a1 = sm.Rc[3 + c], a2 = sm.Rc[6 + c], b0 = Rd[c], b1 = Rd[3 + c], b2 = Rd[6 + c];
+						oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+						oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+						oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+					}
+					double dphi[3];
+					mat3_mul_vec(tk.sig_o, oe, dphi);  // :441-443
+					for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk.dt;  // :446
+					for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk.kp_ori[i] * dphi[i] - tk.kv_ori[i] * (w[i] - G[15 + i]) - tk.ki_ori[i] * io[i];
+					mat3_mul_vec(tk.sig_o, tmp, sm.Fum + 3);  // :463-468
+					if (track)
+						for (int i = 0; i < 3; i++) {
+							tk.integ[(size_t)i * P.ld + b] = ip[i];
+							tk.integ[(size_t)(3 + i) * P.ld + b] = io[i];
+						}
+				}
+				SYNC();
+				if (tid < r) {  // fhat = Bm^T F_um   (force-related terms are zero: sigma_force = sigma_moment = 0)
+					double s = 0.0;
+					for (int i = 0; i < 6; i++) s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
+					sm.v0[tid] = s;
+				}
+				SYNC();
+				if (tid < r) {  // g = Lambda_mod fhat   (SingularityHandler.cpp:307-309)
+					double s = 0.0;
+					for (int i = 0; i < r; i++) s = fma(Lmod[tid * LD + i], sm.v0[i], s);
+					sm.v3[tid] = s;
+				}
+				SYNC();
+				// computeTorques(tau_prec): the reference's _Lambda is never written => no compensation
+			} else {
+				const int m = tk.m;
+				// e, f (m-vectors)
+				for (int i = tid; i < m; i += T) {
+					double cur = 0.0, vel = 0.0;
+					if (tk.s_identity) {
+						cur = sm.q[i];
+						vel = sm.dq[i];
+					} else {
+						for (int j = 0; j < n; j++) {
+							cur = fma(tk.S[i * n + j], sm.q[j], cur);
+							vel = fma(tk.S[i * n + j], sm.dq[j], vel);
+						}
+					}
+					double e = cur - sm.goal[i];
+					double ie = track ? tk.integ[(size_t)i * P.ld + b] : 0.0;
+					ie += e * tk.dt;  // JointTask.cpp:323-324
+					if (track) tk.integ[(size_t)i * P.ld + b] = ie;
+					sm.v0[i] = -tk.kp[i] * e - tk.kv[i] * (vel - sm.goal[m + i]) - tk.ki[i] * ie;  // :342-345
+				}
+				// w = Minv tau_prec
+				for (int i = tid; i < n; i += T) {
+					double s = 0.0;
+					for (int j = 0; j < n; j++) s = fma(sm.Minv[i * LD + j], sm.tau[j], s);
+					sm.v1[i] = s;
+				}
+				SYNC();
+				// sw = S w - (nothing): v2 (m)
+				for (int i = tid; i < m; i += T) {
+					double s = 0.0;
+					if (tk.s_identity) s = sm.v1[i];
+					else
+						for (int j = 0; j < n; j++) s = fma(tk.S[i * n + j], sm.v1[j], s);
+					sm.v2[i] = s;
+				}
+				SYNC();
+				// range coordinates: a1 = U^T ddq_d - U^T sw (acts through Lambda), b1 = U^T f (acts through Lambda_mod)
+				for (int c = tid; c < r; c += T) {
+					double a1 = 0.0, b1 = 0.0;
+					if (u_identity) {
+						a1 = sm.goal[2 * m + c] - sm.v2[c];
+						b1 = sm.v0[c];
+					} else {
+						for (int i = 0; i < m; i++) {
+							double u = sm.W[3][i * LD + c];
+							a1 = fma(u, sm.goal[2 * m + i] - sm.v2[i], a1);
+							b1 = fma(u, sm.v0[i], b1);
+						}
+					}
+					sm.v4[c] = a1;
+					sm.dv[c] = b1;
+				}
+				SYNC();
+				for (int c = tid; c < r; c += T) {  // g = Lambda a1 + Lambda_mod b1   (JointTask.cpp:348-351, 287-291)
+					double s = 0.0;
+					for (int i = 0; i < r; i++) s = fma(Lam[c * LD + i], sm.v4[i], fma(Lmod[c * LD + i], sm.dv[i], s));
+					sm.v3[c] = s;
+				}
+				SYNC();
+			}
+			for (int j = tid; j < n; j += T) {  // tau += Jh^T g
+				double s = 0.0;
+				for (int c = 0; c < r; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+				sm.tau[j] += s;
+			}
+			// N_prec <- N N_prec   (getTaskAndPreviousNullspace)
+			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);
+			SYNC();
+			double* t_ = Np;
+			Np = Np2;
+			Np2 = t_;
+		} else if (empty && P.diag && tk.diag_N) {
+			for (int e = tid; e < n * n; e += T) {
+				int i = e / n, j = e - i * n;
+				tk.diag_N[(size_t)e * P.ld + b] = (i == j) ? 1.0 : 0.0;
+			}
+		}
+		SYNC();
+		if (singular) break;
+	}
+
+	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
+	if (tid < n) {
+		double tv = sm.tau[tid];
+		if (P.torque_sat) {
+			double lim = md.effort[tid];
+			tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
+		}
+		if (P.gravity_comp) {
+			// jointGravityVector: tau_g[j] = -(d c_com / d q_j) . (m g) summed over the subtree = -S_j . (composite gravity wrench)
+			const double* Ic = sm.comp + 10 * tid;
+			const double* z = sm.zax + 3 * tid;
+			const double* o = fk + 12 * tid + 9;
+			const double* g = md.gravity;
+			double tg;
+			if (md.jtype[tid] == 1) {
+				double ax = Ic[1] - Ic[0] * o[0], ay = Ic[2] - Ic[0] * o[1], az = Ic[3] - Ic[0] * o[2];  // m (c - o)
+				double cx = z[1] * az - z[2] * ay, cy = z[2] * ax - z[0] * az, cz = z[0] * ay - z[1] * ax;
+				tg = -(cx * g[0] + cy * g[1] + cz * g[2]);
+			} else {
+				tg = -Ic[0] * (z[0] * g[0] + z[1] * g[1] + z[2] * g[2]);
+			}
+			tv += tg;
+		}
+		if (singular) tv = __builtin_nan("");
+		P.tau[(size_t)tid * P.ld + b] = tv;
+	}
+	if (tid == 0) P.status[b] = singular ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)
+__global__ void saip_reinit_kernel(const CycleParams P) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= P.B) return;
+	const ModelDev& md = *P.model;
+	const int n = P.n;
+	for (int t = 0; t < P.nt; t++) {
+		const TaskDev& tk = P.tasks[t];
+		if (tk.type == TASK_MOTION_FORCE) {
+			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+			for (int j = 0; j <= tk.body; j++) {
+				double t3[3], Rn[9], Rt[9];
+				mat3_mul_vec(R, md.p0[j], t3);
+				for (int e = 0; e < 3; e++) o[e] += t3[e];
+				for (int r = 0; r < 3; r++)
+					for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * md.R0[j][c] + R[3 * r + 1] * md.R0[j][3 + c] + R[3 * r + 2] * md.R0[j][6 + c];
+				double qj = P.q[(size_t)j * P.ld + b];
+				const double ax = md.axis[j][0], ay = md.axis[j][1], az = md.axis[j][2];
+				if (md.jtype[j] == 1) {
+					double s, c;
+					sincos(qj, &s, &c);
+					double v = 1.0 - c;
+					double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+									ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+									az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+					for (int r = 0; r < 3; r++)
+						for (int c2 = 0; c2 < 3; c2++) Rn[3 * r + c2] = Rt[3 * r] * Rq[c2] + Rt[3 * r + 1] * Rq[3 + c2] + Rt[3 * r + 2] * Rq[6 + c2];
+				} else {
+					double a[3] = {ax, ay, az}, d[3];
+					mat3_mul_vec(Rt, a, d);
+					for (int e = 0; e < 3; e++) o[e] += d[e] * qj;
+					for (int e = 0; e < 9; e++) Rn[e] = Rt[e];
+				}
+				for (int e = 0; e < 9; e++) R[e] = Rn[e];
+			}
+			double p[3];
+			mat3_mul_vec(R, tk.pos, p);
+			for (int e = 0; e < 3; e++) tk.goal[(size_t)e * P.ld + b] = o[e] + p[e];
+			for (int r = 0; r < 3; r++)
+				for (int c = 0; c < 3; c++)
+					tk.goal[(size_t)(3 + 3 * r + c) * P.ld + b] = R[3 * r] * tk.rot[c] + R[3 * r + 1] * tk.rot[3 + c] + R[3 * r + 2] * tk.rot[6 + c];
+			for (int e = 12; e < 24; e++) tk.goal[(size_t)e * P.ld + b] = 0.0;
+			for (int e = 0; e < 6; e++) tk.integ[(size_t)e * P.ld + b] = 0.0;
+		} else {
+			for (int i = 0; i < tk.m; i++) {
+				double cur = 0.0;
+				for (int j = 0; j < n; j++) cur = fma(tk.S[i * n + j], P.q[(size_t)j * P.ld + b], cur);
+				tk.goal[(size_t)i * P.ld + b] = cur;
+				tk.goal[(size_t)(tk.m + i) * P.ld + b] = 0.0;
+				tk.goal[(size_t)(2 * tk.m + i) * P.ld + b] = 0.0;
+				tk.integ[(size_t)i * P.ld + b] = 0.0;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------- host-callable launchers
+hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream) {
+	if (P.n <= 8) {
+		hipLaunchKernelGGL((saip_cycle_wg<8, 64>), dim3(P.B), dim3(64), 0, stream, P);
+	} else {
+		hipLaunchKernelGGL((saip_cycle_wg<32, 256>), dim3(P.B), dim3(256), 0, stream, P);
+	}
+	return hipGetLastError();
+}
+hipError_t launch_reinit(const CycleParams& P, hipStream_t stream) {
+	hipLaunchKernelGGL(saip_reinit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, stream, P);
+	return hipGetLastError();
+}
+
+}  // namespace saip

@@ -560,7 +560,7 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
     q = lo + (hi - lo) * rng.uniform_range(0.0, 1.0, n)
     has_mf = any(t["type"] == "motion_force" for t in tasks)
     if has_mf:
-        for _ in range(200):
+        for _ in range(5000):
             bad = _task_sv_ratio(model, tasks, q) < min_ratio
             if not bad.any():
                 break
