@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: control-cycles/sec for BASELINE.json configs[1]
+(4096 x Panda 7-DoF, full MotionForceTask + full JointTask in its nullspace) per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one control cycle (updateModel + updateControllerTaskModels + computeControlTorques) of every instance of
+the rank's batch = one launch of the cycle kernel, inputs already resident in HBM.  Weak scaling: every rank owns
+4096 instances (rank r = instances [4096 r, 4096 (r+1)) of the seeded stream); no data-path collective; ONE RCCL
+all_gather of the final torque slabs at the end of the timed region (north_star: "RCCL ... only for the final torque gather").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (FP32 vector 157.3 TF / 2, MI355X_MICROARCH.md:41)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md:36 (spec; 6290 measured)
+
+
+def cpu_baseline(d, seconds_target=12.0):
+    """The CPU oracle (literal restatement of the reference path, -O2) timed on this box's host cores.
+    Bounded sample of the same workload; this is the ONLY place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from oracle import Oracle
+    cores = min(os.cpu_count() or 1, 16)
+    o = Oracle(d["model"], d["tasks"])
+    q, dq = np.ascontiguousarray(d["q"].T), np.ascontiguousarray(d["dq"].T)
+    goals = [np.ascontiguousarray(g.T) for g in d["goals"]]
+    B = q.shape[1]
+    o.step_soa(q, dq, goals, nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    o.step_soa(q, dq, goals, nthreads=cores)
+    one = max(time.perf_counter() - t0, 1e-4)
+    reps = max(3, min(2000, int(seconds_target / one)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o.step_soa(q, dq, goals, nthreads=cores)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r1 = max(1, reps // (4 * cores))
+    for _ in range(r1):
+        o.step_soa(q, dq, goals, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": B * reps / dt, "unit": "control-cycles/s", "cores": cores, "kind": "port",
+            "sample": f"{B} instances x {reps} passes of the literal CPU restatement (oracle/saip_oracle.c, gcc -O2, pthreads), "
+                      f"{dt:.1f} s; not the Eigen/sai-model binary (cannot be built: Eigen3, sai-model, RBDL absent)",
+            "single_thread_value": B * r1 / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (config 2: 4096)")
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general workgroup-per-instance, 2 lane-per-instance")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", type=float, default=None, help="measured HBM bytes per launch (from a separate rocprofv3 --pmc pass)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import workloads as W
+    import sai_primitives_amd as sp
+    from sai_primitives_amd import sharding
+    from sai_primitives_amd.controller import controller_from_specs
+
+    rank, local_rank, world = sharding.dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        sharding.init_process_group("nccl")
+        import torch.distributed as dist
+
+    B = args.batch
+    d = W.make_inputs(args.config, B, shard=rank)
+    robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=local_rank)
+    ctrl.setKernel(args.kernel)
+    n = robot.dof()
+    ld = ctrl.devicePointers()["ld"]
+    tau_t = torch.zeros((n, ld), dtype=torch.float64, device=dev)   # engine writes torques straight into the gather buffer
+    ctrl.bindTauDevice(tau_t.data_ptr())
+    robot.setQ(d["q"])
+    robot.setDq(d["dq"])
+    robot.updateModel()
+    ctrl.setGoals(d["goals"])
+
+    # untimed warmup
+    ctrl.timeSteps(max(args.warmup, 1), 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms = ctrl.timeSteps(args.steps, 0)              # K launches on the engine stream, HIP events around them
+    gathered = sharding.gather_torques(tau_t, world)   # the final torque gather (RCCL all_gather for world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, dev)
+    ev_ms = sharding.max_over_ranks(ev_ms, dev)
+
+    # correctness of what was timed: finite torques, no flagged instance, gather holds this rank's slab
+    tau = ctrl.getTorques()
+    ok = bool(np.isfinite(tau).all() and ctrl.status.sum() == 0)
+    ok = ok and bool(torch.equal(gathered[rank], tau_t))
+
+    if rank == 0:
+        total_cycles = B * world * args.steps
+        value = total_cycles / elapsed
+        flops = W.algorithmic_flops(d["model"], d["tasks"])
+        byts = W.algorithmic_bytes(d["model"], d["tasks"])
+        launch_s = ev_ms * 1e-3 / args.steps
+        ach_tf = flops * B / launch_s / 1e12
+        ach_gbs = byts * B / launch_s / 1e9
+        out = {
+            "metric": "control-cycles/sec (whole node), 7-DoF 2-task hierarchy, batch=4096",
+            "value": value, "unit": "control-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {W.CONFIGS[args.config]['desc']}", "batch_per_gpu": B,
+                       "global_batch": B * world, "robot": d["model"].name, "dof": n,
+                       "tasks": [t["name"] for t in d["tasks"]], "parallelism": f"instances sharded x{world}, no data-path collective, "
+                       "one final torque all_gather", "kernel": ctrl.kernelName()},
+            "roofline": {"bound": "mfma", "note": "FP64 compute bound (FP64 vector pipe; its peak equals the FP64 MFMA peak on MI355X); HBM never binds",
+                         "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+                         "traffic": args.traffic, "algorithmic_flops_per_cycle": flops, "units_per_launch": B,
+                         "avg_launch_us": launch_s * 1e6, "kernel": ctrl.kernelName()},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_cycle": byts, "traffic": args.traffic},
+            "max_abs_tau": float(np.abs(tau).max()), "valid": ok,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(d)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench: invalid torques")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+"""Multi-GPU plumbing: robot instances are independent, so a batch shards by contiguous instance ranges
+(one process per GPU, no data-path collective).  The only collective is the optional gather of the torque slabs
+(RCCL all_gather over xGMI on GPUs, gloo in the CPU tests).  torch.distributed is used for rendezvous/collectives
+only; the engine itself never touches torch."""
+from __future__ import annotations
+
+import os
+
+
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_range(total: int, world: int, rank: int):
+    """contiguous block of instances owned by `rank` (sizes differ by at most one)"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_process_group(backend: str):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def gather_torques(tau_local, world: int):
+    """tau_local: torch tensor [dof, ld] (device for nccl, cpu for gloo) -> [world, dof, ld] on every rank"""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty((world,) + tuple(tau_local.shape), dtype=tau_local.dtype, device=tau_local.device)
+    if world == 1:
+        out[0].copy_(tau_local)
+    else:
+        dist.all_gather_into_tensor(out, tau_local.contiguous())
+    return out
+
+
+def max_over_ranks(value: float, device) -> float:
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

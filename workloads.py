@@ -599,3 +599,63 @@ def torque_error(tau, tau_ref):
     tau, tau_ref = np.asarray(tau), np.asarray(tau_ref)
     scale = np.maximum(np.abs(tau_ref), 1e-3 * np.max(np.abs(tau_ref), axis=-1, keepdims=True))
     return float(np.max(np.abs(tau - tau_ref) / scale))
+
+
+# ------------------------------------------------------------------ roofline accounting (DESIGN.md "Algorithmic work")
+def algorithmic_bytes(model, tasks) -> int:
+    """minimal HBM I/O per instance-cycle: q, dq, goals in; tau out; FP64; integrators elided (ki = 0)."""
+    n = model.dof
+    words = 2 * n + n
+    for t in tasks:
+        if t["type"] == "motion_force":
+            _, _, pr, orr = mf_projection(t)
+            words += (9 if pr else 0) + (15 if orr else 0)  # x,v,a  /  R,w,alpha
+        else:
+            words += goal_size(t, n)
+    return 8 * words
+
+
+def algorithmic_flops(model, tasks) -> int:
+    """Lean closed-form operation count per instance-cycle (mul and add count 1 each), by formula:
+    sin/cos 40 each; FK 108/joint; body spatial inertia 125/body + suffix sums 10(n-1); M: 80 per upper-triangle entry;
+    SPD inverse of a p x p matrix p^3; symmetric eigenvalues of a k x k Gram matrix 4/3 k^3 + 3 k^2 (tridiagonal QR);
+    rank-revealing orthonormal range basis of an m x n matrix of rank r: 4 m n r; dense products at 2*m*k*p
+    (symmetric results at half of that).  First task skips the product with N_prec = I; the last task skips the
+    N_prec update.  This is the figure bench.py prices the kernel with (10.6 kflop for config 2; SURVEY's a-priori
+    estimate was ~12 k)."""
+    n = model.dof
+    f = 40 * n + 108 * n + 125 * n + 10 * (n - 1) + 80 * n * (n + 1) // 2
+    any_bie = any(t["decoupling"] == BOUNDED_INERTIA_ESTIMATES for t in tasks)
+    f += n ** 3 * (2 if any_bie else 1)
+    first = True
+    for ti, t in enumerate(tasks):
+        last = ti == len(tasks) - 1
+        if t["type"] == "motion_force":
+            _, _, pr, orr = mf_projection(t)
+            k = pr + orr
+            f += 9 * n + (0 if k == 6 else 2 * k * 6 * n)           # world Jacobian (+ basis projection)
+            f += 0 if first else 2 * k * n * n                      # Jh = Jb N_prec
+            f += k * (k + 1) // 2 * (2 * n - 1) + (4 * k ** 3) // 3 + 3 * k * k   # Gram + singular values
+            r, law = k, 150 + 2 * 6 * k
+        else:
+            m = joint_selection(t, n).shape[0]
+            r = min(m, n)
+            f += 0 if (t["S"] is None or first) else 2 * m * n * n  # Jp = S N_prec
+            law = 5 * m + 2 * n * n + 2 * m
+            if not first:
+                # rank of S N_prec: n minus the ranks of the tasks above, capped by m
+                used = 0
+                for u in tasks[:ti]:
+                    used += (sum(mf_projection(u)[2:]) if u["type"] == "motion_force" else joint_selection(u, n).shape[0])
+                r = max(1, min(m, n - used))
+                f += 4 * m * n * r + 2 * r * m * n                  # range basis + Jh = U^T Jp
+            law += 3 * 2 * r * m + 2 * 2 * r * r
+        f += 2 * r * n * n + r * (r + 1) // 2 * (2 * n - 1) + r ** 3       # T1, A, Lambda
+        if not last:
+            f += 2 * r * r * n + 2 * n * n * r + n * n                      # Jbar^T, N
+            f += 0 if first else 2 * n ** 3                                 # N_prec <- N N_prec
+        if t["decoupling"] == BOUNDED_INERTIA_ESTIMATES:
+            f += 2 * r * n * n + r * (r + 1) // 2 * (2 * n - 1) + r ** 3
+        f += law + 2 * r * r + 2 * r * n                                    # control law, g, tau += Jh^T g
+        first = False
+    return int(f)
