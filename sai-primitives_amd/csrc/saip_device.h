@@ -35,7 +35,10 @@ struct TaskDev {
 	int s_identity;    // joint: S == I
 	int has_ki;        // any integral gain != 0
 	int goal_comps;
+	int bm_identity;   // motion force: Bm == I6 (full task)
+	int pad0_;
 	double dt, bie_threshold, s_min, s_max, s_abs_tol;
+	double cert_kroot; // k^(-1/16): lower/upper bound ratio of the trace-power bound on lambda_max (lane kernel certificate)
 	double pos[3];     // control point in the body frame
 	double rot[9];     // control frame rotation in the body frame
 	double Bm[36];     // 6 x 6 row-major, first k columns = orthonormal basis of range(P)
@@ -58,6 +61,13 @@ struct CycleParams {
 	uint8_t* status;   // [ld]
 	const ModelDev* model;
 	const TaskDev* tasks;
+	// lane-per-instance kernel only
+	int mf_task[2];               // task ids of the (at most two) motion-force tasks, -1 when absent
+	int rank_bound[SAIP_MAXT];    // batch-uniform upper bound on the rank of each task in the hierarchy
+	int lane_task_is_joint[SAIP_MAXT];
+	int any_bie;
+	int pad1_;
+	double bie_thr;
 };
 
 }  // namespace saip

@@ -422,6 +422,8 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	m3_mul(T.dev.Pori, PT, T.dev.sig_o);
 	T.dev.k = pr + orr;
 	T.dev.goal_comps = 24;
+	T.dev.bm_identity = (pr == 3 && orr == 3) ? 1 : 0;
+	T.dev.cert_kroot = pow((double)T.dev.k, -1.0 / 16.0);
 	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:44-49
 		T.dev.kp_pos[i] = 100.0; T.dev.kv_pos[i] = 20.0; T.dev.ki_pos[i] = 0.0;
 		T.dev.kp_ori[i] = 200.0; T.dev.kv_ori[i] = 28.3; T.dev.ki_ori[i] = 0.0;
@@ -798,22 +800,59 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.status = b->status;
 	P.model = b->model_dev;
 	P.tasks = b->tasks_dev;
+	// lane kernel: motion-force task slots, batch-uniform rank bounds, the shared BIE threshold
+	P.mf_task[0] = P.mf_task[1] = -1;
+	P.any_bie = 0;
+	P.bie_thr = 0.0;
+	int nmf = 0, used = 0;
+	for (int t = 0; t < SAIP_MAXT; t++) P.rank_bound[t] = P.lane_task_is_joint[t] = 0;
+	for (size_t t = 0; t < b->tasks.size(); t++) {
+		const TaskDev& d = b->tasks[t].dev;
+		int own = d.type == saip::TASK_MOTION_FORCE ? d.k : d.m;
+		int bound = own < P.n - used ? own : P.n - used;  // rank(J N_prec) <= n - sum of the ranks certified above
+		P.rank_bound[t] = bound < 0 ? 0 : bound;
+		P.lane_task_is_joint[t] = d.type == saip::TASK_JOINT;
+		if (d.type == saip::TASK_MOTION_FORCE) {
+			if (nmf < 2) P.mf_task[nmf] = (int)t;
+			nmf++;
+			used += d.k;  // exact whenever the instance stays in the non-singular branch (otherwise it is flagged anyway)
+		}
+		if (d.decoupling == SAIP_BOUNDED_INERTIA_ESTIMATES) {
+			P.any_bie = 1;
+			P.bie_thr = d.bie_threshold;
+		}
+	}
 	return SAIP_OK;
+}
+// the lane-per-instance register kernel covers 6..8 dof, at most two motion-force tasks and one shared BIE threshold
+static bool lane_eligible(const saip_batch* b) {
+	const int n = b->model->n;
+	if (n < 6 || n > 8) return false;
+	int nmf = 0;
+	double thr = -1.0;
+	for (auto& T : b->tasks) {
+		if (T.dev.type == saip::TASK_MOTION_FORCE) nmf++;
+		if (T.dev.decoupling == SAIP_BOUNDED_INERTIA_ESTIMATES) {
+			if (thr >= 0.0 && thr != T.dev.bie_threshold) return false;
+			thr = T.dev.bie_threshold;
+		}
+	}
+	return nmf <= 2;
 }
 static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;
 	saip_status st = make_params(b, P, diag);
 	if (st) return st;
 	bool lane_ok = false;
-	if (!diag && b->kernel_choice != 1) {
+	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
 		hipError_t e = saip::launch_cycle_lane(P, b->stream, &lane_ok);
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
 			b->kernel_name = "saip_cycle_lane";
 			return SAIP_OK;
 		}
-		if (b->kernel_choice == 2) return fail(SAIP_ERR_UNSUPPORTED, "the lane-per-instance kernel does not cover this robot/task stack");
 	}
+	if (!diag && b->kernel_choice == 2) return fail(SAIP_ERR_UNSUPPORTED, "the lane-per-instance kernel does not cover this robot/task stack");
 	hipError_t e = saip::launch_cycle_wg(P, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
 	b->kernel_name = P.n <= 8 ? "saip_cycle_wg<8,64>" : "saip_cycle_wg<32,256>";

@@ -25,169 +25,9 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_wg_linalg.h"
 
 namespace saip {
-
-#define SYNC() __syncthreads()
-
-enum { GEMM_SET = 0, GEMM_I_MINUS = 1, GEMM_ADD = 2, GEMM_SUB = 3 };
-
-// C(m x p) (op)= A(m x k) * B(k x p); A(i,l) = A[i*ars + l*acs], B(l,j) = B[l*brs + j*bcs]  (strides express transposes)
-template <int T>
-__device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ars, int acs, const double* Bm, int brs, int bcs,
-									 int m, int k, int p, int tid, int mode = GEMM_SET) {
-	for (int e = tid; e < m * p; e += T) {
-		int i = e / p, j = e - i * p;
-		double s = 0.0;
-		for (int l = 0; l < k; l++) s = fma(A[i * ars + l * acs], Bm[l * brs + j * bcs], s);
-		double* c = C + i * ldc + j;
-		if (mode == GEMM_SET) *c = s;
-		else if (mode == GEMM_I_MINUS) *c = (i == j ? 1.0 : 0.0) - s;
-		else if (mode == GEMM_ADD) *c += s;
-		else *c -= s;
-	}
-}
-
-// Aout = Ain^-1 for a symmetric positive definite n x n matrix.  WL, WX: n x n work (ld), dv: n doubles.
-// Cholesky (right-looking, 2 barriers per column) -> L^-1 by column-parallel forward substitution -> L^-T L^-1.
-template <int T>
-__device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double* WX, double* dv, int n, int ld, int tid) {
-	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
-		WL[i * ld + j] = Ain[i * ld + j];
-	}
-	SYNC();
-	for (int k = 0; k < n; k++) {
-		double d = sqrt(WL[k * ld + k]);
-		double rd = 1.0 / d;
-		for (int i = k + 1 + tid; i < n; i += T) WL[i * ld + k] *= rd;
-		if (tid == 0) dv[k] = d;
-		SYNC();
-		int rem = n - k - 1;
-		for (int e = tid; e < rem * rem; e += T) {
-			int a = e / rem, b = e - a * rem;
-			if (b <= a) {
-				int i = k + 1 + a, j = k + 1 + b;
-				WL[i * ld + j] = fma(-WL[i * ld + k], WL[j * ld + k], WL[i * ld + j]);
-			}
-		}
-		SYNC();
-	}
-	// X = L^-1 (lower); thread c owns column c
-	for (int c = tid; c < n; c += T) {
-		WX[c * ld + c] = 1.0 / dv[c];
-		for (int i = c + 1; i < n; i++) {
-			double s = 0.0;
-			for (int k = c; k < i; k++) s = fma(WL[i * ld + k], WX[k * ld + c], s);
-			WX[i * ld + c] = -s / dv[i];
-		}
-	}
-	SYNC();
-	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
-		int k0 = i > j ? i : j;
-		double s = 0.0;
-		for (int k = k0; k < n; k++) s = fma(WX[k * ld + i], WX[k * ld + j], s);
-		Aout[i * ld + j] = s;
-	}
-	SYNC();
-}
-
-// Symmetric eigen-decomposition by parallel-ordered (round-robin) Jacobi: A -> diag (eigenvalues), V (optional) <- eigenvectors.
-// cs: 4*(NMAX/2+1) doubles scratch, flag: one int in LDS.  3 barriers per round, n-1 (n even) or n rounds per sweep.
-template <int T>
-__device__ void jacobi_eig(double* A, double* V, int n, int ld, double* cs, int* flag, int tid) {
-	if (V) {
-		for (int e = tid; e < n * n; e += T) {
-			int i = e / n, j = e - i * n;
-			V[i * ld + j] = (i == j) ? 1.0 : 0.0;
-		}
-	}
-	double tr = 0.0;
-	for (int i = 0; i < n; i++) tr += fabs(A[i * ld + i]);
-	const double thresh = 1e-15 * (tr / n);  // off-diagonals below this are zero for every downstream tolerance
-	if (n < 2) {
-		SYNC();
-		return;
-	}
-	const int npad = (n + 1) & ~1, half = npad >> 1, rounds = npad - 1;
-	for (int sweep = 0; sweep < 14; sweep++) {
-		if (tid == 0) *flag = 0;
-		SYNC();
-		for (int r = 0; r < rounds; r++) {
-			if (tid < half) {
-				int p, q;
-				if (tid == 0) {
-					p = npad - 1;
-					q = r;
-				} else {
-					p = (r + tid) % rounds;
-					q = (r - tid + rounds) % rounds;
-				}
-				if (p > q) {
-					int t_ = p;
-					p = q;
-					q = t_;
-				}
-				double c = 1.0, s = 0.0;
-				if (q < n) {
-					double app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
-					if (fabs(apq) > thresh) {
-						double theta = (aqq - app) / (2.0 * apq);
-						double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-						c = 1.0 / sqrt(t * t + 1.0);
-						s = t * c;
-						*flag = 1;
-					}
-				} else {
-					q = -1;
-				}
-				cs[4 * tid + 0] = c;
-				cs[4 * tid + 1] = s;
-				cs[4 * tid + 2] = (double)p;
-				cs[4 * tid + 3] = (double)q;
-			}
-			SYNC();
-			// column rotation A <- A J, V <- V J
-			for (int e = tid; e < n * half; e += T) {
-				int i = e / half, pi = e - i * half;
-				int q = (int)cs[4 * pi + 3];
-				if (q < 0) continue;
-				int p = (int)cs[4 * pi + 2];
-				double c = cs[4 * pi], s = cs[4 * pi + 1];
-				double ap = A[i * ld + p], aq = A[i * ld + q];
-				A[i * ld + p] = c * ap - s * aq;
-				A[i * ld + q] = s * ap + c * aq;
-				if (V) {
-					double vp = V[i * ld + p], vq = V[i * ld + q];
-					V[i * ld + p] = c * vp - s * vq;
-					V[i * ld + q] = s * vp + c * vq;
-				}
-			}
-			SYNC();
-			// row rotation A <- J^T A
-			for (int e = tid; e < n * half; e += T) {
-				int pi = e / n, j = e - pi * n;
-				int q = (int)cs[4 * pi + 3];
-				if (q < 0) continue;
-				int p = (int)cs[4 * pi + 2];
-				double c = cs[4 * pi], s = cs[4 * pi + 1];
-				double ap = A[p * ld + j], aq = A[q * ld + j];
-				A[p * ld + j] = c * ap - s * aq;
-				A[q * ld + j] = s * ap + c * aq;
-			}
-			SYNC();
-		}
-		if (*flag == 0) break;
-		SYNC();
-	}
-}
-
-__device__ __forceinline__ void mat3_mul_vec(const double* R, const double* v, double* o) {
-	o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
-	o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
-	o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
-}
 
 template <int NMAX>
 struct WgSmem {
