@@ -27,6 +27,11 @@ namespace saip {
 
 #define UNR _Pragma("unroll")
 #define CONSTANT_AS __attribute__((address_space(4)))
+#ifdef SAIP_NO_FENCE
+#define PHASE_FENCE()
+#else
+#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 typedef const ModelDev CONSTANT_AS* ModelCPtr;
 typedef const TaskDev CONSTANT_AS* TaskCPtr;
@@ -34,7 +39,7 @@ typedef const TaskDev CONSTANT_AS* TaskCPtr;
 template <int N>
 struct LaneSmem {
 	static constexpr int LD = 9;
-	static constexpr int PARK = 2 * N + 6 * N + 24;  // sin/cos, joint axes + origins, two control frames
+	static constexpr int PARK = 6 * N + 24 + 10 * N;  // joint axes + origins, two control frames, per-body spatial inertias
 	double park[PARK][64];
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
@@ -98,20 +103,20 @@ __device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const d
 		UNR for (int a = 0; a < R; a++)
 			UNR for (int c = 0; c < R; c++) Lmod[a][c] = (a == c) ? 1.0 : 0.0;
 	} else {
-		double Tb[R][N];
-		UNR for (int a = 0; a < R; a++)
+		UNR for (int a = 0; a < R; a++) {
+			double tb[N];  // row a of Jh M_BIE^-1, consumed immediately
 			UNR for (int j = 0; j < N; j++) {
 				double s = 0.0;
 				UNR for (int l = 0; l < N; l++) s = fma(Jh[a][l], MBinv[l][j], s);
-				Tb[a][j] = s;
+				tb[j] = s;
 			}
-		UNR for (int a = 0; a < R; a++)
 			UNR for (int c = 0; c <= a; c++) {
 				double s = 0.0;
-				UNR for (int j = 0; j < N; j++) s = fma(Tb[a][j], Jh[c][j], s);
+				UNR for (int j = 0; j < N; j++) s = fma(tb[j], Jh[c][j], s);
 				if (a == c) s = (a >= r_lane) ? 1.0 : s;
 				A[a][c] = s;
 			}
+		}
 		spd_inv_reg<R>(A, Lmod);
 	}
 }
@@ -126,22 +131,23 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 		tau[j] += s;
 	}
 	if (last) return;
-	double T2[R][N];
-	UNR for (int a = 0; a < R; a++)
-		UNR for (int j = 0; j < N; j++) {
-			double s = 0.0;
-			UNR for (int c = 0; c < R; c++) s = fma(Lam[a][c], T1[c][j], s);
-			T2[a][j] = (a < r_lane) ? s : 0.0;
-		}
+	// Jbar^T = Lambda T1 (R x N) is consumed one column at a time (never materialised: register pressure)
 	if (first) {
-		UNR for (int i = 0; i < N; i++)
+		UNR for (int i = 0; i < N; i++) {
+			double t2[R];
+			UNR for (int a = 0; a < R; a++) {
+				double s = 0.0;
+				UNR for (int c = 0; c < R; c++) s = fma(Lam[a][c], T1[c][i], s);
+				t2[a] = (a < r_lane) ? s : 0.0;
+			}
 			UNR for (int j = 0; j < N; j++) {
 				double s = (i == j) ? 1.0 : 0.0;
-				UNR for (int a = 0; a < R; a++) s = fma(-T2[a][i], Jh[a][j], s);
+				UNR for (int a = 0; a < R; a++) s = fma(-t2[a], Jh[a][j], s);
 				Np[i][j] = s;
 			}
+		}
 	} else {
-		// N N_prec = N_prec - T2^T (Jh N_prec)
+		// N N_prec = N_prec - Jbar (Jh N_prec)
 		double JN[R][N];
 		UNR for (int a = 0; a < R; a++)
 			UNR for (int j = 0; j < N; j++) {
@@ -149,20 +155,432 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 				UNR for (int l = 0; l < N; l++) s = fma(Jh[a][l], Np[l][j], s);
 				JN[a][j] = s;
 			}
-		UNR for (int i = 0; i < N; i++)
+		UNR for (int i = 0; i < N; i++) {
+			double t2[R];
+			UNR for (int a = 0; a < R; a++) {
+				double s = 0.0;
+				UNR for (int c = 0; c < R; c++) s = fma(Lam[a][c], T1[c][i], s);
+				t2[a] = (a < r_lane) ? s : 0.0;
+			}
 			UNR for (int j = 0; j < N; j++) {
 				double s = Np[i][j];
-				UNR for (int a = 0; a < R; a++) s = fma(-T2[a][i], JN[a][j], s);
+				UNR for (int a = 0; a < R; a++) s = fma(-t2[a], JN[a][j], s);
 				Np[i][j] = s;
 			}
+		}
 	}
 }
 
+template <int N>
+__device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, LaneSmem<N>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
+		double (&Np)[N][N], double (&tau)[N], bool& singular) {
+	constexpr int LD = LaneSmem<N>::LD;
+	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
+	const size_t ld = P.ld;
+	const TaskCPtr tk = tasks + t;
+	const bool track = (tk->has_ki || P.integ_always);
+	(void)LD; (void)P_Z; (void)P_O; (void)P_CAP; (void)md;
+	// ======================================================== MotionForceTask (6 rows; rows >= k are zero)
+	const int k = tk->k, bd = tk->body;
+	const int cbase = P_CAP + ((t == P.mf_task[1]) ? 12 : 0);
+	double pw[3];
+	UNR for (int e = 0; e < 3; e++) pw[e] = sm.park[cbase + e][lane];
+	double Jh[6][N], vw[6];
+	UNR for (int e = 0; e < 6; e++) vw[e] = 0.0;
+	{
+		// world Jacobian [Jv; Jw] of the control point (JWorldFrame), task velocities, rows in the basis of range(P)
+		double Jw[6][N];
+		UNR for (int j = 0; j < N; j++) {
+			double z[3], o[3];
+			UNR for (int e = 0; e < 3; e++) {
+				z[e] = sm.park[P_Z + 3 * j + e][lane];
+				o[e] = sm.park[P_O + 3 * j + e][lane];
+			}
+			const bool on = (j <= bd);
+			if (md->jtype[j] == 1) {
+				const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
+				Jw[0][j] = on ? z[1] * rz - z[2] * ry : 0.0;
+				Jw[1][j] = on ? z[2] * rx - z[0] * rz : 0.0;
+				Jw[2][j] = on ? z[0] * ry - z[1] * rx : 0.0;
+				Jw[3][j] = on ? z[0] : 0.0;
+				Jw[4][j] = on ? z[1] : 0.0;
+				Jw[5][j] = on ? z[2] : 0.0;
+			} else {
+				Jw[0][j] = on ? z[0] : 0.0;
+				Jw[1][j] = on ? z[1] : 0.0;
+				Jw[2][j] = on ? z[2] : 0.0;
+				Jw[3][j] = Jw[4][j] = Jw[5][j] = 0.0;
+			}
+			const double dqj = P.dq[(size_t)j * ld + b];
+			UNR for (int e = 0; e < 6; e++) vw[e] = fma(Jw[e][j], dqj, vw[e]);
+		}
+		if (tk->bm_identity) {
+			if (first) {
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int j = 0; j < N; j++) Jh[a][j] = Jw[a][j];
+			} else {
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int j = 0; j < N; j++) {
+						double s = 0.0;
+						UNR for (int l = 0; l < N; l++) s = fma(Jw[a][l], Np[l][j], s);
+						Jh[a][j] = s;
+					}
+			}
+		} else {
+			double Jb[6][N];
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int j = 0; j < N; j++) {
+					double s = 0.0;
+					UNR for (int e = 0; e < 6; e++) s = fma(tk->Bm[e * 6 + a], Jw[e][j], s);  // columns >= k of Bm are zero
+					Jb[a][j] = s;
+				}
+			if (first) {
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int j = 0; j < N; j++) Jh[a][j] = Jb[a][j];
+			} else {
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int j = 0; j < N; j++) {
+						double s = 0.0;
+						UNR for (int l = 0; l < N; l++) s = fma(Jb[a][l], Np[l][j], s);
+						Jh[a][j] = s;
+					}
+			}
+		}
+	}
+	PHASE_FENCE();
+	// ---- SingularityHandler branch predicate on G = Jh Jh^T (k x k block; padded rows give zero rows/columns)
+	bool need_exact = false;
+	double G[6][6];
+	{
+		double tr = 0.0;
+		UNR for (int a = 0; a < 6; a++)
+			UNR for (int c = 0; c <= a; c++) {
+				double s = 0.0;
+				UNR for (int j = 0; j < N; j++) s = fma(Jh[a][j], Jh[c][j], s);
+				G[a][c] = s;
+				G[c][a] = s;
+				if (a == c) tr += s;
+			}
+		const double itr = 1.0 / tr;
+		double Gs[6][6], G2[6][6], Gt[6][6];
+		UNR for (int a = 0; a < 6; a++)
+			UNR for (int c = 0; c < 6; c++) {
+				Gs[a][c] = G[a][c] * itr;
+				G2[a][c] = Gs[a][c];
+			}
+		UNR for (int rep = 0; rep < 3; rep++) {  // G2 <- G2^2: Gs^2, Gs^4, Gs^8
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c <= a; c++) {
+					double s = 0.0;
+					UNR for (int l = 0; l < 6; l++) s = fma(G2[a][l], G2[l][c], s);
+					Gt[a][c] = s;
+				}
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c <= a; c++) {
+					G2[a][c] = Gt[a][c];
+					G2[c][a] = Gt[a][c];
+				}
+		}
+		double t16 = 0.0;  // trace(Gs^16) = ||Gs^8||_F^2
+		UNR for (int a = 0; a < 6; a++)
+			UNR for (int c = 0; c < 6; c++) t16 = fma(G2[a][c], G2[a][c], t16);
+		const double u = sqrt(sqrt(sqrt(sqrt(t16))));  // lambda_max(Gs) <= u <= k^(1/16) lambda_max(Gs)
+		const bool ok_s0 = (u * tk->cert_kroot * tr >= tk->s_abs_tol * tk->s_abs_tol);
+		const double shift = tk->s_max * tk->s_max * u;
+		// LDL^T pivots of Gs - shift I on the k x k block (padded diagonal entries are set to 1)
+		bool pos = true;
+		UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < k) ? Gs[a][a] - shift : 1.0;
+		UNR for (int kk = 0; kk < 6; kk++) {
+			const double d = Gs[kk][kk];
+			pos = pos && (d > 1e-13);
+			const double id = 1.0 / d;
+			UNR for (int i = kk + 1; i < 6; i++) {
+				const double lik = Gs[i][kk] * id;
+				UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
+			}
+		}
+		need_exact = !(ok_s0 && pos && tr > 0.0);
+	}
+	// exact path (rare): wave-cooperative Jacobi eigen-solve of this lane's Gram matrix
+	unsigned long long need = __ballot(need_exact);
+	while (need) {
+		const int src = __builtin_ctzll(need);
+		need &= need - 1;
+		if (lane == src) {
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c < 6; c++) sm.A[a * LD + c] = G[a][c];
+		}
+		__syncthreads();
+		jacobi_eig<64>(sm.A, nullptr, k, LD, sm.cs, &sm.flag, lane);
+		if (lane == src) {
+			double lmax = 0.0;
+			for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.A[i * LD + i]);
+			const double s0 = sqrt(lmax);
+			bool sing = !(s0 >= tk->s_abs_tol);
+			for (int i = 0; i < k; i++)
+				if (sqrt(fmax(sm.A[i * LD + i], 0.0)) / s0 < tk->s_max) sing = true;
+			if (sing) singular = true;
+		}
+		__syncthreads();
+	}
+	PHASE_FENCE();
+	double Lam[6][6], Lmod[6][6], T1[6][N];
+	opspace_lambda<N, 6>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
+
+	PHASE_FENCE();
+	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off)
+	double g[6];
+	{
+		double xp[3], Rc[9], G24[24];
+		UNR for (int e = 0; e < 3; e++) xp[e] = pw[e];
+		UNR for (int e = 0; e < 9; e++) Rc[e] = sm.park[cbase + 3 + e][lane];
+		UNR for (int e = 0; e < 24; e++) G24[e] = tk->goal[(size_t)e * ld + b];
+		double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
+		UNR for (int i = 0; i < 3; i++) {
+			v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];
+			w[i] = tk->Pori[3 * i] * vw[3] + tk->Pori[3 * i + 1] * vw[4] + tk->Pori[3 * i + 2] * vw[5];
+		}
+		if (track) {
+			UNR for (int i = 0; i < 3; i++) {
+				ip[i] = tk->integ[(size_t)i * ld + b];
+				io[i] = tk->integ[(size_t)(3 + i) * ld + b];
+			}
+		}
+		UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G24[i];
+		UNR for (int i = 0; i < 3; i++) ip[i] += (tk->sig_p[3 * i] * e3[0] + tk->sig_p[3 * i + 1] * e3[1] + tk->sig_p[3 * i + 2] * e3[2]) * tk->dt;
+		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - tk->kp_pos[i] * e3[i] - tk->kv_pos[i] * (v[i] - G24[12 + i]) - tk->ki_pos[i] * ip[i];
+		UNR for (int i = 0; i < 3; i++) Fum[i] = tk->sig_p[3 * i] * tmp[0] + tk->sig_p[3 * i + 1] * tmp[1] + tk->sig_p[3 * i + 2] * tmp[2];
+		double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+		UNR for (int c = 0; c < 3; c++) {
+			const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
+			oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+			oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+			oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+		}
+		double dphi[3];
+		UNR for (int i = 0; i < 3; i++) dphi[i] = tk->sig_o[3 * i] * oe[0] + tk->sig_o[3 * i + 1] * oe[1] + tk->sig_o[3 * i + 2] * oe[2];
+		UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk->dt;
+		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
+		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
+		if (track && live) {
+			UNR for (int i = 0; i < 3; i++) {
+				tk->integ[(size_t)i * ld + b] = ip[i];
+				tk->integ[(size_t)(3 + i) * ld + b] = io[i];
+			}
+		}
+		double fh[6];  // fhat = Bm^T F_um  (columns >= k of Bm are zero)
+		if (tk->bm_identity) {
+			UNR for (int a = 0; a < 6; a++) fh[a] = Fum[a];
+		} else {
+			UNR for (int a = 0; a < 6; a++) {
+				double s = 0.0;
+				UNR for (int e = 0; e < 6; e++) s = fma(tk->Bm[e * 6 + a], Fum[e], s);
+				fh[a] = s;
+			}
+		}
+		UNR for (int a = 0; a < 6; a++) {  // g = Lambda_mod fhat  (SingularityHandler.cpp:307-309)
+			double s = 0.0;
+			UNR for (int c = 0; c < 6; c++) s = fma(Lmod[a][c], fh[c], s);
+			g[a] = s;
+		}
+		// computeTorques(tau_prec): the reference's _Lambda is never written => no compensation
+	}
+	PHASE_FENCE();
+	apply_task<N, 6>(Jh, g, Lam, T1, k, first, last, tau, Np);
+	PHASE_FENCE();
+}
+
 template <int N, int RJ>
+__device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
+		double (&Np)[N][N], double (&tau)[N], bool& singular) {
+	constexpr int LD = LaneSmem<N>::LD;
+	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
+	const size_t ld = P.ld;
+	const TaskCPtr tk = tasks + t;
+	const bool track = (tk->has_ki || P.integ_always);
+	(void)LD; (void)P_Z; (void)P_O; (void)P_CAP; (void)md;
+	// ======================================================== JointTask (RJ rows in the range basis)
+	const int m = tk->m;
+	double U[N][RJ], Jh[RJ][N];
+	int r_lane = 0;
+	bool need_exact = false;
+	{
+		// Jp = S N_prec; column-pivoted Gram-Schmidt on its columns with a clean-gap acceptance rule.
+		// The deflation coefficients u_s^T W are exactly the rows of Jh = U^T Jp.
+		double Wc[N][N];
+		if (tk->s_identity) {
+			UNR for (int i = 0; i < N; i++)
+				UNR for (int j = 0; j < N; j++) Wc[i][j] = Np[i][j];
+		} else {
+			UNR for (int i = 0; i < N; i++)
+				UNR for (int j = 0; j < N; j++) {
+					double s = 0.0;
+					UNR for (int l = 0; l < N; l++) s = fma((i < m) ? tk->S[i * N + l] : 0.0, Np[l][j], s);
+					Wc[i][j] = s;
+				}
+		}
+		double c0 = 1.0;
+		bool going = true;
+		UNR for (int s = 0; s <= RJ; s++) {
+			double cn[N], best = -1.0, frob2 = 0.0;
+			UNR for (int j = 0; j < N; j++) {
+				double a = 0.0;
+				UNR for (int i = 0; i < N; i++) a = fma(Wc[i][j], Wc[i][j], a);
+				cn[j] = a;
+				frob2 += a;
+				best = fmax(best, a);
+			}
+			if (s == 0) {
+				c0 = best;
+				// ||Jp||_F < 1e-3 or sigma_0 < 1e-3 => empty range (matrixRangeBasis); sigma_0^2 lies in [best, frob2]
+				if (frob2 < 1e-6) going = false;
+				else if (best < 1e-5) { going = false; need_exact = true; }
+			} else if (going) {
+				const double ratio = best / c0;
+				if (ratio < 1e-20) going = false;                              // numerically exact rank
+				else if (ratio < 1e-4 || s == RJ) { going = false; need_exact = true; }  // ambiguous gap / bound exceeded: exact path decides
+			}
+			if (s < RJ) {
+				double pv[N], pbest = -1.0;
+				UNR for (int i = 0; i < N; i++) pv[i] = 0.0;
+				UNR for (int j = 0; j < N; j++) {
+					const bool take = cn[j] > pbest;
+					pbest = take ? cn[j] : pbest;
+					UNR for (int i = 0; i < N; i++) pv[i] = take ? Wc[i][j] : pv[i];
+				}
+				const double inv = going ? rsqrt(pbest) : 0.0;
+				UNR for (int i = 0; i < N; i++) {
+					pv[i] *= inv;
+					U[i][s < RJ ? s : 0] = pv[i];
+				}
+				UNR for (int j = 0; j < N; j++) {
+					double d = 0.0;
+					UNR for (int i = 0; i < N; i++) d = fma(pv[i], Wc[i][j], d);
+					Jh[s < RJ ? s : 0][j] = d;
+					UNR for (int i = 0; i < N; i++) Wc[i][j] = fma(-d, pv[i], Wc[i][j]);
+				}
+				if (going) r_lane = s + 1;
+			}
+		}
+	}
+	// exact path (rare): Gram eigen-decomposition by the whole wavefront, reference tolerance semantics
+	unsigned long long need = __ballot(need_exact);
+	while (need) {
+		const int src = __builtin_ctzll(need);
+		need &= need - 1;
+		if (lane == src) {
+			UNR for (int i = 0; i < N; i++)
+				UNR for (int j = 0; j < N; j++) {
+					double s = 0.0;
+					if (i < m) {
+						UNR for (int l = 0; l < N; l++) s = fma(tk->S[i * N + l], Np[l][j], s);
+					}
+					sm.Jp[i * LD + j] = s;
+				}
+		}
+		__syncthreads();
+		gemm<64>(sm.A, LD, sm.Jp, LD, 1, sm.Jp, 1, LD, m, N, m, lane);
+		__syncthreads();
+		double trc = 0.0;
+		for (int i = 0; i < m; i++) trc += sm.A[i * LD + i];
+		__syncthreads();
+		jacobi_eig<64>(sm.A, sm.V, m, LD, sm.cs, &sm.flag, lane);
+		if (lane == 0) {
+			double lmax = 0.0;
+			for (int i = 0; i < m; i++) lmax = fmax(lmax, sm.A[i * LD + i]);
+			int rr = 0;
+			if (sqrt(fmax(trc, 0.0)) >= 1e-3 && sqrt(lmax) >= 1e-3) {
+				for (int i = 0; i < m; i++)
+					if (sqrt(fmax(sm.A[i * LD + i], 0.0) / lmax) >= 1e-3) sm.colidx[rr++] = i;
+			}
+			sm.rank = rr;
+		}
+		__syncthreads();
+		if (lane == src) {
+			const int rr = sm.rank;
+			if (rr > RJ) singular = true;  // cannot happen while the host's rank bound holds; never silently truncate
+			r_lane = rr < RJ ? rr : RJ;
+			UNR for (int c = 0; c < RJ; c++) {
+				const int col = (c < rr) ? sm.colidx[c] : 0;
+				UNR for (int i = 0; i < N; i++) {
+					double uv = 0.0;
+					if (c < rr && i < m) uv = (rr == m) ? ((i == c) ? 1.0 : 0.0) : sm.V[i * LD + col];
+					U[i][c] = uv;
+				}
+			}
+			UNR for (int c = 0; c < RJ; c++)
+				UNR for (int j = 0; j < N; j++) {
+					double s = 0.0;
+					UNR for (int i = 0; i < N; i++) s = fma(U[i][c], sm.Jp[i * LD + j], s);
+					Jh[c][j] = s;
+				}
+		}
+		__syncthreads();
+	}
+	PHASE_FENCE();
+	double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
+	opspace_lambda<N, RJ>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
+
+	// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
+	double g[RJ];
+	{
+		double w[N], qv[N], dqv[N];
+		UNR for (int i = 0; i < N; i++) {  // w = M^-1 tau_prec (disturbance compensation, :287-291)
+			double s = 0.0;
+			UNR for (int j = 0; j < N; j++) s = fma(Minv[i][j], tau[j], s);
+			w[i] = s;
+		}
+		UNR for (int j = 0; j < N; j++) {
+			qv[j] = P.q[(size_t)j * ld + b];
+			dqv[j] = P.dq[(size_t)j * ld + b];
+		}
+		double a1[RJ], b1[RJ];
+		UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
+		UNR for (int i = 0; i < N; i++) {
+			if (i < m) {
+				double cur = 0.0, vel = 0.0, sw = 0.0;
+				if (tk->s_identity) {
+					cur = qv[i];
+					vel = dqv[i];
+					sw = w[i];
+				} else {
+					UNR for (int j = 0; j < N; j++) {
+						const double sij = tk->S[i * N + j];
+						cur = fma(sij, qv[j], cur);
+						vel = fma(sij, dqv[j], vel);
+						sw = fma(sij, w[j], sw);
+					}
+				}
+				const double e = cur - tk->goal[(size_t)i * ld + b];
+				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
+				ie += e * tk->dt;  // :323-324
+				if (track && live) tk->integ[(size_t)i * ld + b] = ie;
+				const double fi = -tk->kp[i] * e - tk->kv[i] * (vel - tk->goal[(size_t)(m + i) * ld + b]) - tk->ki[i] * ie;  // :342-345
+				const double ai = tk->goal[(size_t)(2 * m + i) * ld + b] - sw;
+				UNR for (int c = 0; c < RJ; c++) {
+					a1[c] = fma(U[i][c], ai, a1[c]);
+					b1[c] = fma(U[i][c], fi, b1[c]);
+				}
+			}
+		}
+		UNR for (int a = 0; a < RJ; a++) {  // g = Lambda a1 + Lambda_mod b1  (:348-351)
+			double s = 0.0;
+			UNR for (int c = 0; c < RJ; c++) s = fma(Lam[a][c], a1[c], fma(Lmod[a][c], b1[c], s));
+			g[a] = (a < r_lane) ? s : 0.0;
+		}
+	}
+	apply_task<N, RJ>(Jh, g, Lam, T1, r_lane, first, last, tau, Np);
+}
+
+enum { SIG_GENERIC = 0, SIG_MF_JT = 1 };
+
+template <int N, int RJ, int SIG>
 __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	using SM = LaneSmem<N>;
 	constexpr int LD = SM::LD;
-	constexpr int P_SC = 0, P_Z = 2 * N, P_O = 5 * N, P_CAP = 8 * N;
+	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N, P_BODY = 6 * N + 24;
 	__shared__ SM sm;
 	const int lane = threadIdx.x;
 	int b = blockIdx.x * 64 + lane;
@@ -172,44 +590,36 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	const TaskCPtr tasks = (TaskCPtr)P.tasks;
 	const size_t ld = P.ld;
 
-	// ---------------------------------------------------------------- sin/cos of the joint angles (one rolled loop = one code copy)
-	_Pragma("unroll 1") for (int j = 0; j < N; j++) {
-		double s, c;
-		sincos(P.q[(size_t)j * ld + b], &s, &c);
-		sm.park[P_SC + 2 * j][lane] = s;
-		sm.park[P_SC + 2 * j + 1][lane] = c;
-	}
-
-	// ---------------------------------------------------------------- forward kinematics, per-body spatial inertia, M(q), gravity
+	// ---------------------------------------------------------------- forward kinematics (ONE rolled loop over the joints: one code copy,
+	// short live ranges); joint axes/origins, per-body spatial inertias and the control frames are parked in LDS
 	double Minv[N][N], MBinv[N][N], taug[N];
 	{
-		double zj[N][3], oj[N][3], body[N][10];
 		{
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-			UNR for (int j = 0; j < N; j++) {
+			_Pragma("unroll 1") for (int j = 0; j < N; j++) {
 				const double CONSTANT_AS* R0 = md->R0[j];
 				const double CONSTANT_AS* p0 = md->p0[j];
 				const double ax = md->axis[j][0], ay = md->axis[j][1], az = md->axis[j][2];
+				const double qj = P.q[(size_t)j * ld + b];
 				double Rt[9];
 				UNR for (int r = 0; r < 3; r++) o[r] += R[3 * r] * p0[0] + R[3 * r + 1] * p0[1] + R[3 * r + 2] * p0[2];
 				UNR for (int r = 0; r < 3; r++)
 					UNR for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * R0[c] + R[3 * r + 1] * R0[3 + c] + R[3 * r + 2] * R0[6 + c];
 				if (md->jtype[j] == 1) {
-					const double s = sm.park[P_SC + 2 * j][lane], c = sm.park[P_SC + 2 * j + 1][lane], v = 1.0 - c;
+					double s, c;
+					sincos(qj, &s, &c);
+					const double v = 1.0 - c;
 					const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
 										  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
 										  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
 					UNR for (int r = 0; r < 3; r++)
 						UNR for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rt[3 * r] * Rq[cc] + Rt[3 * r + 1] * Rq[3 + cc] + Rt[3 * r + 2] * Rq[6 + cc];
 				} else {
-					const double qj = P.q[(size_t)j * ld + b];
 					UNR for (int r = 0; r < 3; r++) o[r] += (Rt[3 * r] * ax + Rt[3 * r + 1] * ay + Rt[3 * r + 2] * az) * qj;
 					UNR for (int e = 0; e < 9; e++) R[e] = Rt[e];
 				}
 				UNR for (int r = 0; r < 3; r++) {
-					zj[j][r] = R[3 * r] * ax + R[3 * r + 1] * ay + R[3 * r + 2] * az;
-					oj[j][r] = o[r];
-					sm.park[P_Z + 3 * j + r][lane] = zj[j][r];
+					sm.park[P_Z + 3 * j + r][lane] = R[3 * r] * ax + R[3 * r + 1] * ay + R[3 * r + 2] * az;
 					sm.park[P_O + 3 * j + r][lane] = o[r];
 				}
 				{  // spatial inertia of body j about the world origin: m, h = m c, Io (xx yy zz xy xz yz)
@@ -226,16 +636,17 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 					Iw[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];
 					UNR for (int r = 0; r < 3; r++) c3[r] = o[r] + R[3 * r] * md->com[j][0] + R[3 * r + 1] * md->com[j][1] + R[3 * r + 2] * md->com[j][2];
 					const double m = md->mass[j], cc2 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
-					body[j][0] = m;
-					body[j][1] = m * c3[0];
-					body[j][2] = m * c3[1];
-					body[j][3] = m * c3[2];
-					body[j][4] = Iw[0] + m * (cc2 - c3[0] * c3[0]);
-					body[j][5] = Iw[1] + m * (cc2 - c3[1] * c3[1]);
-					body[j][6] = Iw[2] + m * (cc2 - c3[2] * c3[2]);
-					body[j][7] = Iw[3] - m * c3[0] * c3[1];
-					body[j][8] = Iw[4] - m * c3[0] * c3[2];
-					body[j][9] = Iw[5] - m * c3[1] * c3[2];
+					const int pb = P_BODY + 10 * j;
+					sm.park[pb + 0][lane] = m;
+					sm.park[pb + 1][lane] = m * c3[0];
+					sm.park[pb + 2][lane] = m * c3[1];
+					sm.park[pb + 3][lane] = m * c3[2];
+					sm.park[pb + 4][lane] = Iw[0] + m * (cc2 - c3[0] * c3[0]);
+					sm.park[pb + 5][lane] = Iw[1] + m * (cc2 - c3[1] * c3[1]);
+					sm.park[pb + 6][lane] = Iw[2] + m * (cc2 - c3[2] * c3[2]);
+					sm.park[pb + 7][lane] = Iw[3] - m * c3[0] * c3[1];
+					sm.park[pb + 8][lane] = Iw[4] - m * c3[0] * c3[2];
+					sm.park[pb + 9][lane] = Iw[5] - m * c3[1] * c3[2];
 				}
 				UNR for (int s = 0; s < 2; s++) {  // control frames of the motion-force tasks attached to this body
 					const int t = P.mf_task[s];
@@ -250,20 +661,26 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 				}
 			}
 		}
+		PHASE_FENCE();
 		// M(q) from composite inertias (backward sweep): M_ij = S_i . (Ic_j S_j), i <= j
 		double Mm[N][N];
 		{
 			double Sw[N][3], Sv[N][3];
 			UNR for (int j = 0; j < N; j++) {
+				double z[3], o[3];
+				UNR for (int e = 0; e < 3; e++) {
+					z[e] = sm.park[P_Z + 3 * j + e][lane];
+					o[e] = sm.park[P_O + 3 * j + e][lane];
+				}
 				if (md->jtype[j] == 1) {
-					UNR for (int e = 0; e < 3; e++) Sw[j][e] = zj[j][e];
-					Sv[j][0] = oj[j][1] * zj[j][2] - oj[j][2] * zj[j][1];
-					Sv[j][1] = oj[j][2] * zj[j][0] - oj[j][0] * zj[j][2];
-					Sv[j][2] = oj[j][0] * zj[j][1] - oj[j][1] * zj[j][0];
+					UNR for (int e = 0; e < 3; e++) Sw[j][e] = z[e];
+					Sv[j][0] = o[1] * z[2] - o[2] * z[1];
+					Sv[j][1] = o[2] * z[0] - o[0] * z[2];
+					Sv[j][2] = o[0] * z[1] - o[1] * z[0];
 				} else {
 					UNR for (int e = 0; e < 3; e++) {
 						Sw[j][e] = 0.0;
-						Sv[j][e] = zj[j][e];
+						Sv[j][e] = z[e];
 					}
 				}
 			}
@@ -271,7 +688,8 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 			UNR for (int e = 0; e < 10; e++) Ic[e] = 0.0;
 			UNR for (int jj = 0; jj < N; jj++) {
 				const int j = N - 1 - jj;
-				UNR for (int e = 0; e < 10; e++) Ic[e] += body[j][e];
+				PHASE_FENCE();
+				UNR for (int e = 0; e < 10; e++) Ic[e] += sm.park[P_BODY + 10 * j + e][lane];
 				const double* w = Sw[j];
 				const double* v = Sv[j];
 				const double m = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
@@ -285,12 +703,18 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 					Mm[j][i] = val;
 				}
 				// jointGravityVector: -S_j . (gravity wrench of the subtree about the world origin) = -(w.(h x g) + v.(m g))
-				const double gx = md->gravity[0], gy = md->gravity[1], gz = md->gravity[2];
-				const double hxg[3] = {hy * gz - hz * gy, hz * gx - hx * gz, hx * gy - hy * gx};
-				taug[j] = -(w[0] * hxg[0] + w[1] * hxg[1] + w[2] * hxg[2] + m * (v[0] * gx + v[1] * gy + v[2] * gz));
+				if (P.gravity_comp) {  // wave-uniform; keeps the computation here instead of being sunk to the epilogue
+					const double gx = md->gravity[0], gy = md->gravity[1], gz = md->gravity[2];
+					const double hxg[3] = {hy * gz - hz * gy, hz * gx - hx * gz, hx * gy - hy * gx};
+					taug[j] = -(w[0] * hxg[0] + w[1] * hxg[1] + w[2] * hxg[2] + m * (v[0] * gx + v[1] * gy + v[2] * gz));
+				} else {
+					taug[j] = 0.0;
+				}
 			}
 		}
+		PHASE_FENCE();
 		spd_inv_reg<N>(Mm, Minv);
+		PHASE_FENCE();
 		if (P.any_bie) {  // M_BIE: diagonal clamped from below (SingularityHandler.cpp:176-182, JointTask.cpp:254-259)
 			UNR for (int i = 0; i < N; i++) Mm[i][i] = fmax(Mm[i][i], P.bie_thr);
 			spd_inv_reg<N>(Mm, MBinv);
@@ -300,6 +724,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 	}
 
+	PHASE_FENCE();
 	// ---------------------------------------------------------------- task hierarchy
 	double Np[N][N], tau[N];
 	UNR for (int i = 0; i < N; i++) {
@@ -309,388 +734,18 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	bool singular = false;
 	bool first = true;
 
-	_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
-		const TaskCPtr tk = tasks + t;
-		const bool last = (t == P.nt - 1);
-		const bool track = (tk->has_ki || P.integ_always);
-
-		if (tk->type == TASK_MOTION_FORCE) {
-			// ======================================================== MotionForceTask (6 rows; rows >= k are zero)
-			const int k = tk->k, bd = tk->body;
-			const int cbase = P_CAP + ((t == P.mf_task[1]) ? 12 : 0);
-			double pw[3];
-			UNR for (int e = 0; e < 3; e++) pw[e] = sm.park[cbase + e][lane];
-			double Jh[6][N], vw[6];
-			UNR for (int e = 0; e < 6; e++) vw[e] = 0.0;
-			{
-				// world Jacobian [Jv; Jw] of the control point (JWorldFrame), task velocities, rows in the basis of range(P)
-				double Jw[6][N];
-				UNR for (int j = 0; j < N; j++) {
-					double z[3], o[3];
-					UNR for (int e = 0; e < 3; e++) {
-						z[e] = sm.park[P_Z + 3 * j + e][lane];
-						o[e] = sm.park[P_O + 3 * j + e][lane];
-					}
-					const bool on = (j <= bd);
-					if (md->jtype[j] == 1) {
-						const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
-						Jw[0][j] = on ? z[1] * rz - z[2] * ry : 0.0;
-						Jw[1][j] = on ? z[2] * rx - z[0] * rz : 0.0;
-						Jw[2][j] = on ? z[0] * ry - z[1] * rx : 0.0;
-						Jw[3][j] = on ? z[0] : 0.0;
-						Jw[4][j] = on ? z[1] : 0.0;
-						Jw[5][j] = on ? z[2] : 0.0;
-					} else {
-						Jw[0][j] = on ? z[0] : 0.0;
-						Jw[1][j] = on ? z[1] : 0.0;
-						Jw[2][j] = on ? z[2] : 0.0;
-						Jw[3][j] = Jw[4][j] = Jw[5][j] = 0.0;
-					}
-					const double dqj = P.dq[(size_t)j * ld + b];
-					UNR for (int e = 0; e < 6; e++) vw[e] = fma(Jw[e][j], dqj, vw[e]);
-				}
-				if (tk->bm_identity) {
-					if (first) {
-						UNR for (int a = 0; a < 6; a++)
-							UNR for (int j = 0; j < N; j++) Jh[a][j] = Jw[a][j];
-					} else {
-						UNR for (int a = 0; a < 6; a++)
-							UNR for (int j = 0; j < N; j++) {
-								double s = 0.0;
-								UNR for (int l = 0; l < N; l++) s = fma(Jw[a][l], Np[l][j], s);
-								Jh[a][j] = s;
-							}
-					}
-				} else {
-					double Jb[6][N];
-					UNR for (int a = 0; a < 6; a++)
-						UNR for (int j = 0; j < N; j++) {
-							double s = 0.0;
-							UNR for (int e = 0; e < 6; e++) s = fma(tk->Bm[e * 6 + a], Jw[e][j], s);  // columns >= k of Bm are zero
-							Jb[a][j] = s;
-						}
-					if (first) {
-						UNR for (int a = 0; a < 6; a++)
-							UNR for (int j = 0; j < N; j++) Jh[a][j] = Jb[a][j];
-					} else {
-						UNR for (int a = 0; a < 6; a++)
-							UNR for (int j = 0; j < N; j++) {
-								double s = 0.0;
-								UNR for (int l = 0; l < N; l++) s = fma(Jb[a][l], Np[l][j], s);
-								Jh[a][j] = s;
-							}
-					}
-				}
-			}
-			// ---- SingularityHandler branch predicate on G = Jh Jh^T (k x k block; padded rows give zero rows/columns)
-			bool need_exact = false;
-			double G[6][6];
-			{
-				double tr = 0.0;
-				UNR for (int a = 0; a < 6; a++)
-					UNR for (int c = 0; c <= a; c++) {
-						double s = 0.0;
-						UNR for (int j = 0; j < N; j++) s = fma(Jh[a][j], Jh[c][j], s);
-						G[a][c] = s;
-						G[c][a] = s;
-						if (a == c) tr += s;
-					}
-				const double itr = 1.0 / tr;
-				double Gs[6][6], G2[6][6], Gt[6][6];
-				UNR for (int a = 0; a < 6; a++)
-					UNR for (int c = 0; c < 6; c++) {
-						Gs[a][c] = G[a][c] * itr;
-						G2[a][c] = Gs[a][c];
-					}
-				UNR for (int rep = 0; rep < 3; rep++) {  // G2 <- G2^2: Gs^2, Gs^4, Gs^8
-					UNR for (int a = 0; a < 6; a++)
-						UNR for (int c = 0; c <= a; c++) {
-							double s = 0.0;
-							UNR for (int l = 0; l < 6; l++) s = fma(G2[a][l], G2[l][c], s);
-							Gt[a][c] = s;
-						}
-					UNR for (int a = 0; a < 6; a++)
-						UNR for (int c = 0; c <= a; c++) {
-							G2[a][c] = Gt[a][c];
-							G2[c][a] = Gt[a][c];
-						}
-				}
-				double t16 = 0.0;  // trace(Gs^16) = ||Gs^8||_F^2
-				UNR for (int a = 0; a < 6; a++)
-					UNR for (int c = 0; c < 6; c++) t16 = fma(G2[a][c], G2[a][c], t16);
-				const double u = sqrt(sqrt(sqrt(sqrt(t16))));  // lambda_max(Gs) <= u <= k^(1/16) lambda_max(Gs)
-				const bool ok_s0 = (u * tk->cert_kroot * tr >= tk->s_abs_tol * tk->s_abs_tol);
-				const double shift = tk->s_max * tk->s_max * u;
-				// LDL^T pivots of Gs - shift I on the k x k block (padded diagonal entries are set to 1)
-				bool pos = true;
-				UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < k) ? Gs[a][a] - shift : 1.0;
-				UNR for (int kk = 0; kk < 6; kk++) {
-					const double d = Gs[kk][kk];
-					pos = pos && (d > 1e-13);
-					const double id = 1.0 / d;
-					UNR for (int i = kk + 1; i < 6; i++) {
-						const double lik = Gs[i][kk] * id;
-						UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
-					}
-				}
-				need_exact = !(ok_s0 && pos && tr > 0.0);
-			}
-			// exact path (rare): wave-cooperative Jacobi eigen-solve of this lane's Gram matrix
-			unsigned long long need = __ballot(need_exact);
-			while (need) {
-				const int src = __builtin_ctzll(need);
-				need &= need - 1;
-				if (lane == src) {
-					UNR for (int a = 0; a < 6; a++)
-						UNR for (int c = 0; c < 6; c++) sm.A[a * LD + c] = G[a][c];
-				}
-				__syncthreads();
-				jacobi_eig<64>(sm.A, nullptr, k, LD, sm.cs, &sm.flag, lane);
-				if (lane == src) {
-					double lmax = 0.0;
-					for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.A[i * LD + i]);
-					const double s0 = sqrt(lmax);
-					bool sing = !(s0 >= tk->s_abs_tol);
-					for (int i = 0; i < k; i++)
-						if (sqrt(fmax(sm.A[i * LD + i], 0.0)) / s0 < tk->s_max) sing = true;
-					if (sing) singular = true;
-				}
-				__syncthreads();
-			}
-			double Lam[6][6], Lmod[6][6], T1[6][N];
-			opspace_lambda<N, 6>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
-
-			// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off)
-			double g[6];
-			{
-				double xp[3], Rc[9], G24[24];
-				UNR for (int e = 0; e < 3; e++) xp[e] = pw[e];
-				UNR for (int e = 0; e < 9; e++) Rc[e] = sm.park[cbase + 3 + e][lane];
-				UNR for (int e = 0; e < 24; e++) G24[e] = tk->goal[(size_t)e * ld + b];
-				double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
-				UNR for (int i = 0; i < 3; i++) {
-					v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];
-					w[i] = tk->Pori[3 * i] * vw[3] + tk->Pori[3 * i + 1] * vw[4] + tk->Pori[3 * i + 2] * vw[5];
-				}
-				if (track) {
-					UNR for (int i = 0; i < 3; i++) {
-						ip[i] = tk->integ[(size_t)i * ld + b];
-						io[i] = tk->integ[(size_t)(3 + i) * ld + b];
-					}
-				}
-				UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G24[i];
-				UNR for (int i = 0; i < 3; i++) ip[i] += (tk->sig_p[3 * i] * e3[0] + tk->sig_p[3 * i + 1] * e3[1] + tk->sig_p[3 * i + 2] * e3[2]) * tk->dt;
-				UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - tk->kp_pos[i] * e3[i] - tk->kv_pos[i] * (v[i] - G24[12 + i]) - tk->ki_pos[i] * ip[i];
-				UNR for (int i = 0; i < 3; i++) Fum[i] = tk->sig_p[3 * i] * tmp[0] + tk->sig_p[3 * i + 1] * tmp[1] + tk->sig_p[3 * i + 2] * tmp[2];
-				double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
-				UNR for (int c = 0; c < 3; c++) {
-					const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
-					oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
-					oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
-					oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
-				}
-				double dphi[3];
-				UNR for (int i = 0; i < 3; i++) dphi[i] = tk->sig_o[3 * i] * oe[0] + tk->sig_o[3 * i + 1] * oe[1] + tk->sig_o[3 * i + 2] * oe[2];
-				UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk->dt;
-				UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
-				UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
-				if (track && live) {
-					UNR for (int i = 0; i < 3; i++) {
-						tk->integ[(size_t)i * ld + b] = ip[i];
-						tk->integ[(size_t)(3 + i) * ld + b] = io[i];
-					}
-				}
-				double fh[6];  // fhat = Bm^T F_um  (columns >= k of Bm are zero)
-				if (tk->bm_identity) {
-					UNR for (int a = 0; a < 6; a++) fh[a] = Fum[a];
-				} else {
-					UNR for (int a = 0; a < 6; a++) {
-						double s = 0.0;
-						UNR for (int e = 0; e < 6; e++) s = fma(tk->Bm[e * 6 + a], Fum[e], s);
-						fh[a] = s;
-					}
-				}
-				UNR for (int a = 0; a < 6; a++) {  // g = Lambda_mod fhat  (SingularityHandler.cpp:307-309)
-					double s = 0.0;
-					UNR for (int c = 0; c < 6; c++) s = fma(Lmod[a][c], fh[c], s);
-					g[a] = s;
-				}
-				// computeTorques(tau_prec): the reference's _Lambda is never written => no compensation
-			}
-			apply_task<N, 6>(Jh, g, Lam, T1, k, first, last, tau, Np);
-		} else {
-			// ======================================================== JointTask (RJ rows in the range basis)
-			const int m = tk->m;
-			double U[N][RJ], Jh[RJ][N];
-			int r_lane = 0;
-			bool need_exact = false;
-			{
-				// Jp = S N_prec; column-pivoted Gram-Schmidt on its columns with a clean-gap acceptance rule.
-				// The deflation coefficients u_s^T W are exactly the rows of Jh = U^T Jp.
-				double Wc[N][N];
-				if (tk->s_identity) {
-					UNR for (int i = 0; i < N; i++)
-						UNR for (int j = 0; j < N; j++) Wc[i][j] = Np[i][j];
-				} else {
-					UNR for (int i = 0; i < N; i++)
-						UNR for (int j = 0; j < N; j++) {
-							double s = 0.0;
-							UNR for (int l = 0; l < N; l++) s = fma((i < m) ? tk->S[i * N + l] : 0.0, Np[l][j], s);
-							Wc[i][j] = s;
-						}
-				}
-				double c0 = 1.0;
-				bool going = true;
-				UNR for (int s = 0; s <= RJ; s++) {
-					double cn[N], best = -1.0, frob2 = 0.0;
-					UNR for (int j = 0; j < N; j++) {
-						double a = 0.0;
-						UNR for (int i = 0; i < N; i++) a = fma(Wc[i][j], Wc[i][j], a);
-						cn[j] = a;
-						frob2 += a;
-						best = fmax(best, a);
-					}
-					if (s == 0) {
-						c0 = best;
-						// ||Jp||_F < 1e-3 or sigma_0 < 1e-3 => empty range (matrixRangeBasis); sigma_0^2 lies in [best, frob2]
-						if (frob2 < 1e-6) going = false;
-						else if (best < 1e-5) { going = false; need_exact = true; }
-					} else if (going) {
-						const double ratio = best / c0;
-						if (ratio < 1e-20) going = false;                              // numerically exact rank
-						else if (ratio < 1e-4 || s == RJ) { going = false; need_exact = true; }  // ambiguous gap / bound exceeded: exact path decides
-					}
-					if (s < RJ) {
-						double pv[N], pbest = -1.0;
-						UNR for (int i = 0; i < N; i++) pv[i] = 0.0;
-						UNR for (int j = 0; j < N; j++) {
-							const bool take = cn[j] > pbest;
-							pbest = take ? cn[j] : pbest;
-							UNR for (int i = 0; i < N; i++) pv[i] = take ? Wc[i][j] : pv[i];
-						}
-						const double inv = going ? rsqrt(pbest) : 0.0;
-						UNR for (int i = 0; i < N; i++) {
-							pv[i] *= inv;
-							U[i][s < RJ ? s : 0] = pv[i];
-						}
-						UNR for (int j = 0; j < N; j++) {
-							double d = 0.0;
-							UNR for (int i = 0; i < N; i++) d = fma(pv[i], Wc[i][j], d);
-							Jh[s < RJ ? s : 0][j] = d;
-							UNR for (int i = 0; i < N; i++) Wc[i][j] = fma(-d, pv[i], Wc[i][j]);
-						}
-						if (going) r_lane = s + 1;
-					}
-				}
-			}
-			// exact path (rare): Gram eigen-decomposition by the whole wavefront, reference tolerance semantics
-			unsigned long long need = __ballot(need_exact);
-			while (need) {
-				const int src = __builtin_ctzll(need);
-				need &= need - 1;
-				if (lane == src) {
-					UNR for (int i = 0; i < N; i++)
-						UNR for (int j = 0; j < N; j++) {
-							double s = 0.0;
-							if (i < m) {
-								UNR for (int l = 0; l < N; l++) s = fma(tk->S[i * N + l], Np[l][j], s);
-							}
-							sm.Jp[i * LD + j] = s;
-						}
-				}
-				__syncthreads();
-				gemm<64>(sm.A, LD, sm.Jp, LD, 1, sm.Jp, 1, LD, m, N, m, lane);
-				__syncthreads();
-				double trc = 0.0;
-				for (int i = 0; i < m; i++) trc += sm.A[i * LD + i];
-				__syncthreads();
-				jacobi_eig<64>(sm.A, sm.V, m, LD, sm.cs, &sm.flag, lane);
-				if (lane == 0) {
-					double lmax = 0.0;
-					for (int i = 0; i < m; i++) lmax = fmax(lmax, sm.A[i * LD + i]);
-					int rr = 0;
-					if (sqrt(fmax(trc, 0.0)) >= 1e-3 && sqrt(lmax) >= 1e-3) {
-						for (int i = 0; i < m; i++)
-							if (sqrt(fmax(sm.A[i * LD + i], 0.0) / lmax) >= 1e-3) sm.colidx[rr++] = i;
-					}
-					sm.rank = rr;
-				}
-				__syncthreads();
-				if (lane == src) {
-					const int rr = sm.rank;
-					if (rr > RJ) singular = true;  // cannot happen while the host's rank bound holds; never silently truncate
-					r_lane = rr < RJ ? rr : RJ;
-					UNR for (int c = 0; c < RJ; c++) {
-						const int col = (c < rr) ? sm.colidx[c] : 0;
-						UNR for (int i = 0; i < N; i++) {
-							double uv = 0.0;
-							if (c < rr && i < m) uv = (rr == m) ? ((i == c) ? 1.0 : 0.0) : sm.V[i * LD + col];
-							U[i][c] = uv;
-						}
-					}
-					UNR for (int c = 0; c < RJ; c++)
-						UNR for (int j = 0; j < N; j++) {
-							double s = 0.0;
-							UNR for (int i = 0; i < N; i++) s = fma(U[i][c], sm.Jp[i * LD + j], s);
-							Jh[c][j] = s;
-						}
-				}
-				__syncthreads();
-			}
-			double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
-			opspace_lambda<N, RJ>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
-
-			// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
-			double g[RJ];
-			{
-				double w[N], qv[N], dqv[N];
-				UNR for (int i = 0; i < N; i++) {  // w = M^-1 tau_prec (disturbance compensation, :287-291)
-					double s = 0.0;
-					UNR for (int j = 0; j < N; j++) s = fma(Minv[i][j], tau[j], s);
-					w[i] = s;
-				}
-				UNR for (int j = 0; j < N; j++) {
-					qv[j] = P.q[(size_t)j * ld + b];
-					dqv[j] = P.dq[(size_t)j * ld + b];
-				}
-				double a1[RJ], b1[RJ];
-				UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
-				UNR for (int i = 0; i < N; i++) {
-					if (i < m) {
-						double cur = 0.0, vel = 0.0, sw = 0.0;
-						if (tk->s_identity) {
-							cur = qv[i];
-							vel = dqv[i];
-							sw = w[i];
-						} else {
-							UNR for (int j = 0; j < N; j++) {
-								const double sij = tk->S[i * N + j];
-								cur = fma(sij, qv[j], cur);
-								vel = fma(sij, dqv[j], vel);
-								sw = fma(sij, w[j], sw);
-							}
-						}
-						const double e = cur - tk->goal[(size_t)i * ld + b];
-						double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
-						ie += e * tk->dt;  // :323-324
-						if (track && live) tk->integ[(size_t)i * ld + b] = ie;
-						const double fi = -tk->kp[i] * e - tk->kv[i] * (vel - tk->goal[(size_t)(m + i) * ld + b]) - tk->ki[i] * ie;  // :342-345
-						const double ai = tk->goal[(size_t)(2 * m + i) * ld + b] - sw;
-						UNR for (int c = 0; c < RJ; c++) {
-							a1[c] = fma(U[i][c], ai, a1[c]);
-							b1[c] = fma(U[i][c], fi, b1[c]);
-						}
-					}
-				}
-				UNR for (int a = 0; a < RJ; a++) {  // g = Lambda a1 + Lambda_mod b1  (:348-351)
-					double s = 0.0;
-					UNR for (int c = 0; c < RJ; c++) s = fma(Lam[a][c], a1[c], fma(Lmod[a][c], b1[c], s));
-					g[a] = (a < r_lane) ? s : 0.0;
-				}
-			}
-			apply_task<N, RJ>(Jh, g, Lam, T1, r_lane, first, last, tau, Np);
+	if (SIG == SIG_MF_JT) {
+		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
+		lane_motion_force_task<N>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
+		PHASE_FENCE();
+		lane_joint_task<N, RJ>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
+	} else {
+		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
+			const bool last = (t == P.nt - 1);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			else lane_joint_task<N, RJ>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			first = false;
 		}
-		first = false;
 	}
 
 	// ---------------------------------------------------------------- RobotController post-processing + store
@@ -724,14 +779,21 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	const int inst = pick_rj(P.n, rj);
 	*supported = inst != 0;
 	if (!inst) return hipSuccess;
+	const bool mf_jt = (P.nt == 2 && !P.lane_task_is_joint[0] && P.lane_task_is_joint[1]);
 	const dim3 grid((P.B + 63) / 64), block(64);
-#define LAUNCH(NN, RR) hipLaunchKernelGGL((saip_cycle_lane<NN, RR>), grid, block, 0, stream, P)
-	if (P.n == 7 && inst == 1) LAUNCH(7, 1);
-	else if (P.n == 7 && inst == 4) LAUNCH(7, 4);
-	else if (P.n == 7) LAUNCH(7, 7);
-	else if (P.n == 8 && inst == 2) LAUNCH(8, 2);
-	else if (P.n == 8) LAUNCH(8, 8);
-	else LAUNCH(6, 6);
+#define LAUNCH(NN, RR, SS) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS>), grid, block, 0, stream, P)
+	if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT);
+#ifndef SAIP_LANE_ONLY_71
+	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC);
+	else if (P.n == 7 && inst == 4 && mf_jt) LAUNCH(7, 4, SIG_MF_JT);
+	else if (P.n == 7 && inst == 4) LAUNCH(7, 4, SIG_GENERIC);
+	else if (P.n == 7) LAUNCH(7, 7, SIG_GENERIC);
+	else if (P.n == 8 && inst == 2) LAUNCH(8, 2, SIG_GENERIC);
+	else if (P.n == 8) LAUNCH(8, 8, SIG_GENERIC);
+	else LAUNCH(6, 6, SIG_GENERIC);
+#else
+	else { *supported = false; return hipSuccess; }
+#endif
 #undef LAUNCH
 	return hipGetLastError();
 }
