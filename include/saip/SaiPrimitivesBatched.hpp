@@ -1,0 +1,286 @@
+// SaiPrimitivesBatched.hpp -- header-only C++17 facade over the C-ABI (include/saip.h) that keeps the reference's
+// class and method names for the control-cycle path, in a batched flavour: one object = B robot instances.
+//
+//   reference (one robot, Eigen)                                   this facade (B robots, SoA std::vector<double>)
+//   SaiModel::SaiModel robot(urdf)                                  SaiPrimitivesBatched::SaiModel robot(links, B, device)
+//   robot->setQ(q); robot->setDq(dq); robot->updateModel();         robot->setQ(q); robot->setDq(dq); robot->updateModel();   q: [dof][B]
+//   MotionForceTask(robot, link, compliant_frame)                   MotionForceTask(robot, link, pos_in_link)
+//   JointTask(robot) / JointTask(robot, S)                          JointTask(robot) / JointTask(robot, S, rows)
+//   RobotController(robot, tasks)                                   RobotController(robot, tasks)
+//   controller->updateControllerTaskModels();                       controller->updateControllerTaskModels();
+//   task->setGoalPosition(x) ...                                    task->setGoalPosition(x) ...                               x: [3][B]
+//   tau = controller->computeControlTorques();                      tau = controller->computeControlTorques();                  tau: [dof][B]
+//
+// Reference interface: /root/reference/src/RobotController.h:47-90, src/tasks/TemplateTask.h:26-124,
+// src/tasks/MotionForceTask.h:96-110,211-300,423,670-736, src/tasks/JointTask.h:56-75,140-175,237-257,323,363.
+// Errors: std::invalid_argument where the reference throws it; std::runtime_error for device / unsupported / order errors.
+// Every array is struct-of-arrays, component-major: value of component c for instance b at [c * B + b].
+#pragma once
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../saip.h"
+
+namespace SaiPrimitivesBatched {
+
+enum TaskType { UNDEFINED = 0, JOINT_LIMIT_AVOIDANCE_TASK = 1, JOINT_TASK = 2, MOTION_FORCE_TASK = 3 };  // TemplateTask.h:19-24
+enum DynamicDecouplingType { FULL_DYNAMIC_DECOUPLING = 0, BOUNDED_INERTIA_ESTIMATES = 1, IMPEDANCE = 2 };  // SaiPrimitivesCommonDefinitions.h:14-20
+struct PIDGains {  // SaiPrimitivesCommonDefinitions.h:26-32
+	double kp, kv, ki;
+	PIDGains(double kp_, double kv_, double ki_) : kp(kp_), kv(kv_), ki(ki_) {}
+};
+
+inline void check(saip_status st) {
+	if (st == SAIP_OK) return;
+	const std::string msg = saip_last_error();
+	if (st == SAIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+	throw std::runtime_error("[saip status " + std::to_string((int)st) + "] " + msg);
+}
+
+class RobotController;
+
+// B instances of one robot: constants + host-side q/dq staging (the kinematics/dynamics run inside the GPU cycle)
+class SaiModel {
+public:
+	SaiModel(const std::vector<saip_link_desc>& links, int batch_size, int device = 0) : _batch(batch_size), _device(device) {
+		check(saip_model_create_serial_chain(links.data(), (int)links.size(), &_model));
+		_q.assign((size_t)dof() * _batch, 0.0);
+		_dq.assign((size_t)dof() * _batch, 0.0);
+	}
+	~SaiModel() { saip_model_destroy(_model); }
+	SaiModel(const SaiModel&) = delete;
+	SaiModel& operator=(const SaiModel&) = delete;
+
+	int dof() const { return saip_model_dof(_model); }
+	int batchSize() const { return _batch; }
+	int device() const { return _device; }
+	const std::vector<double>& q() const { return _q; }
+	const std::vector<double>& dq() const { return _dq; }
+	void setQ(const std::vector<double>& q) {
+		if (q.size() != _q.size()) throw std::invalid_argument("setQ: expected dof*batch values");
+		_q = q;
+		_version++;
+	}
+	void setDq(const std::vector<double>& dq) {
+		if (dq.size() != _dq.size()) throw std::invalid_argument("setDq: expected dof*batch values");
+		_dq = dq;
+		_version++;
+	}
+	void updateModel();  // pushes the state to the device (defined after RobotController)
+	const saip_model* handle() const { return _model; }
+
+private:
+	friend class RobotController;
+	saip_model* _model = nullptr;
+	int _batch, _device;
+	std::vector<double> _q, _dq;
+	long _version = 0;
+	RobotController* _controller = nullptr;
+};
+
+// TemplateTask.h:26-124
+class TemplateTask {
+public:
+	TemplateTask(std::shared_ptr<SaiModel>& robot, const std::string& task_name, TaskType type, double loop_timestep)
+		: _robot(robot), _task_name(task_name), _task_type(type), _loop_timestep(loop_timestep) {}
+	virtual ~TemplateTask() = default;
+	const std::shared_ptr<SaiModel>& getConstRobotModel() const { return _robot; }
+	const double& getLoopTimestep() const { return _loop_timestep; }
+	const TaskType& getTaskType() const { return _task_type; }
+	const std::string& getTaskName() const { return _task_name; }
+
+	void setDynamicDecouplingType(DynamicDecouplingType t) { cfg([=](saip_batch* b, int id) { return saip_batch_set_dynamic_decoupling_type(b, id, (int)t); }); }
+	void setBoundedInertiaEstimateThreshold(double thr) { cfg([=](saip_batch* b, int id) { return saip_batch_set_bie_threshold(b, id, thr); }); }
+	void disableInternalOtg() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 0); }); }
+	void enableInternalOtgAccelerationLimited() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 1); }); }
+	void disableVelocitySaturation() { cfg([](saip_batch* b, int id) { return saip_batch_set_velocity_saturation(b, id, 0); }); }
+	void enableVelocitySaturation() { cfg([](saip_batch* b, int id) { return saip_batch_set_velocity_saturation(b, id, 1); }); }
+	// (B x dof x dof as [dof*dof][B]) nullspace projector of this task for the current state, TemplateTask.h:71-77
+	std::vector<double> getTaskNullspace() {
+		need();
+		const int n = _robot->dof();
+		std::vector<double> N((size_t)n * n * _robot->batchSize());
+		check(saip_batch_get_task_nullspace_host(_batch, _id, N.data()));
+		return N;
+	}
+
+protected:
+	friend class RobotController;
+	template <typename F>
+	void cfg(F f) {
+		if (_batch) check(f(_batch, _id));
+		else _pending.emplace_back(f);
+	}
+	void need() const {
+		if (!_batch) throw std::runtime_error("task [" + _task_name + "] is not part of a RobotController yet");
+	}
+	void setField(int first, int comps, const std::vector<double>& v, const char* what) {
+		need();
+		if (v.size() != (size_t)comps * _robot->batchSize()) throw std::invalid_argument(what);
+		check(saip_batch_set_goal_field_host(_batch, _id, first, comps, v.data()));
+	}
+	virtual saip_status add(saip_batch* b, int* id) = 0;
+
+	std::shared_ptr<SaiModel> _robot;
+	std::string _task_name;
+	TaskType _task_type;
+	double _loop_timestep;
+	saip_batch* _batch = nullptr;
+	int _id = -1;
+	std::vector<std::function<saip_status(saip_batch*, int)>> _pending;
+};
+
+class MotionForceTask : public TemplateTask {
+public:
+	// full 6-dof task, MotionForceTask.h:96-101
+	MotionForceTask(std::shared_ptr<SaiModel>& robot, const std::string& link_name, const double (&pos_in_link)[3],
+					const std::string& task_name = "motion_force_task", double loop_timestep = 0.001)
+		: TemplateTask(robot, task_name, MOTION_FORCE_TASK, loop_timestep), _link(link_name), _partial(false) {
+		for (int i = 0; i < 3; i++) _pos[i] = pos_in_link[i];
+	}
+	// partial task, MotionForceTask.h:103-110: controlled directions as flat xyz triples
+	MotionForceTask(std::shared_ptr<SaiModel>& robot, const std::string& link_name, const std::vector<double>& controlled_directions_translation,
+					const std::vector<double>& controlled_directions_rotation, const double (&pos_in_link)[3],
+					const std::string& task_name = "partial_motion_force_task", double loop_timestep = 0.001)
+		: TemplateTask(robot, task_name, MOTION_FORCE_TASK, loop_timestep), _link(link_name), _partial(true),
+		  _dt(controlled_directions_translation), _dr(controlled_directions_rotation) {
+		for (int i = 0; i < 3; i++) _pos[i] = pos_in_link[i];
+		if (_dt.empty() && _dr.empty())
+			throw std::invalid_argument("controlled_directions_translation and controlled_directions_rotation cannot both be empty in MotionForceTask::MotionForceTask\n");
+	}
+	void setGoalPosition(const std::vector<double>& x) { setField(0, 3, x, "setGoalPosition: expected [3][B]"); }
+	void setGoalOrientation(const std::vector<double>& R) { setField(3, 9, R, "setGoalOrientation: expected [9][B] (row-major R)"); }
+	void setGoalLinearVelocity(const std::vector<double>& v) { setField(12, 3, v, "setGoalLinearVelocity: expected [3][B]"); }
+	void setGoalAngularVelocity(const std::vector<double>& w) { setField(15, 3, w, "setGoalAngularVelocity: expected [3][B]"); }
+	void setGoalLinearAcceleration(const std::vector<double>& a) { setField(18, 3, a, "setGoalLinearAcceleration: expected [3][B]"); }
+	void setGoalAngularAcceleration(const std::vector<double>& a) { setField(21, 3, a, "setGoalAngularAcceleration: expected [3][B]"); }
+	void setPosControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_pos_control_gains(b, id, &kp, &kv, &ki, 1); }); }
+	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
+	void setSingularityHandlingBounds(double s_min, double s_max) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_bounds(b, id, s_min, s_max); }); }
+
+protected:
+	saip_status add(saip_batch* b, int* id) override {
+		return saip_batch_add_motion_force_task(b, _task_name.c_str(), _link.c_str(), _pos, nullptr, _dt.empty() ? nullptr : _dt.data(),
+												_partial ? (int)_dt.size() / 3 : -1, _dr.empty() ? nullptr : _dr.data(),
+												_partial ? (int)_dr.size() / 3 : -1, _loop_timestep, id);
+	}
+	std::string _link;
+	bool _partial;
+	double _pos[3];
+	std::vector<double> _dt, _dr;
+};
+
+class JointTask : public TemplateTask {
+public:
+	JointTask(std::shared_ptr<SaiModel>& robot, const std::string& task_name = "joint_task", double loop_timestep = 0.001)
+		: TemplateTask(robot, task_name, JOINT_TASK, loop_timestep), _rows(0) {}
+	// joint_selection_matrix: rows x dof, row-major (JointTask.h:66-75)
+	JointTask(std::shared_ptr<SaiModel>& robot, const std::vector<double>& joint_selection_matrix, int rows,
+			  const std::string& task_name = "partial_joint_task", double loop_timestep = 0.001)
+		: TemplateTask(robot, task_name, JOINT_TASK, loop_timestep), _S(joint_selection_matrix), _rows(rows) {
+		if (rows <= 0 || _S.size() != (size_t)rows * robot->dof())
+			throw std::invalid_argument("joint selection matrix size not consistent with robot dof in JointTask constructor\n");
+	}
+	int getTaskDof() const { return _rows > 0 ? _rows : _robot->dof(); }
+	bool isFullJointTask() const { return getTaskDof() == _robot->dof(); }
+	void setGoalPosition(const std::vector<double>& q) { setField(0, getTaskDof(), q, "goal position vector size not consistent with task dof in JointTask::setGoalPosition\n"); }
+	void setGoalVelocity(const std::vector<double>& dq) { setField(getTaskDof(), getTaskDof(), dq, "goal velocity vector size not consistent with task dof in JointTask::setGoalVelocity\n"); }
+	void setGoalAcceleration(const std::vector<double>& ddq) { setField(2 * getTaskDof(), getTaskDof(), ddq, "goal acceleration vector size not consistent with task dof in JointTask::setGoalAcceleration\n"); }
+	void setGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_joint_gains(b, id, &kp, &kv, &ki, 1); }); }
+
+protected:
+	saip_status add(saip_batch* b, int* id) override {
+		return saip_batch_add_joint_task(b, _task_name.c_str(), _rows > 0 ? _S.data() : nullptr, _rows, _loop_timestep, id);
+	}
+	std::vector<double> _S;
+	int _rows;
+};
+
+// RobotController.h:47-90
+class RobotController {
+public:
+	RobotController(std::shared_ptr<SaiModel>& robot, std::vector<std::shared_ptr<TemplateTask>>& tasks) : _robot(robot), _tasks(tasks) {
+		if (tasks.empty()) throw std::invalid_argument("RobotController must have at least one task");
+		for (auto& t : tasks)
+			if (t->getConstRobotModel() != robot) throw std::invalid_argument("All tasks must have the same robot model in RobotController");
+		check(saip_batch_create(robot->handle(), robot->batchSize(), robot->device(), &_batch));
+		try {
+			for (auto& t : tasks) check(t->add(_batch, &t->_id));
+			check(saip_batch_finalize(_batch));
+		} catch (...) {
+			saip_batch_destroy(_batch);
+			_batch = nullptr;
+			throw;
+		}
+		for (auto& t : tasks) {
+			t->_batch = _batch;
+			for (auto& f : t->_pending) check(f(_batch, t->_id));
+			t->_pending.clear();
+			_task_names.push_back(t->getTaskName());
+		}
+		robot->_controller = this;
+	}
+	~RobotController() {
+		if (_robot->_controller == this) _robot->_controller = nullptr;
+		saip_batch_destroy(_batch);
+	}
+	RobotController(const RobotController&) = delete;
+	RobotController& operator=(const RobotController&) = delete;
+
+	void updateControllerTaskModels() {
+		pushState();
+		check(saip_batch_update_task_models(_batch));
+	}
+	// [dof][B] joint torques; instances that left the non-singular branch carry NaN and status()[b] == 1
+	std::vector<double> computeControlTorques() {
+		std::vector<double> tau((size_t)_robot->dof() * _robot->batchSize());
+		_status.assign(_robot->batchSize(), 0);
+		check(saip_batch_compute_control_torques(_batch, tau.data(), _status.data()));
+		return tau;
+	}
+	const std::vector<uint8_t>& status() const { return _status; }
+	void enableGravityCompensation(bool e) { check(saip_batch_enable_gravity_compensation(_batch, e)); }
+	void enableJointLimitAvoidance(bool e) { check(saip_batch_enable_joint_limit_avoidance(_batch, e)); }
+	void enableTorqueSaturation(bool e) { check(saip_batch_enable_torque_saturation(_batch, e)); }
+	void reinitializeTasks() {
+		pushState();
+		check(saip_batch_reinitialize_tasks(_batch));
+	}
+	const std::vector<std::string>& getTaskNames() const { return _task_names; }
+	std::shared_ptr<JointTask> getJointTaskByName(const std::string& name) { return byName<JointTask>(name, JOINT_TASK, "JointTask"); }
+	std::shared_ptr<MotionForceTask> getMotionForceTaskByName(const std::string& name) { return byName<MotionForceTask>(name, MOTION_FORCE_TASK, "MotionForceTask"); }
+	saip_batch* handle() { return _batch; }
+	void pushState() {
+		if (_pushed != _robot->_version) {
+			check(saip_batch_set_state_host(_batch, _robot->_q.data(), _robot->_dq.data()));
+			_pushed = _robot->_version;
+		}
+	}
+
+private:
+	template <typename T>
+	std::shared_ptr<T> byName(const std::string& name, TaskType type, const char* what) {
+		for (auto& t : _tasks)
+			if (t->getTaskName() == name) {
+				if (t->getTaskType() != type)
+					throw std::invalid_argument("Task " + name + " is not a " + what + ", and cannot be casted as such in RobotController::GetTaskByName");
+				return std::dynamic_pointer_cast<T>(t);
+			}
+		throw std::invalid_argument("Task " + name + " not found in RobotController::GetTaskByName");
+	}
+	std::shared_ptr<SaiModel> _robot;
+	std::vector<std::shared_ptr<TemplateTask>> _tasks;
+	std::vector<std::string> _task_names;
+	std::vector<uint8_t> _status;
+	saip_batch* _batch = nullptr;
+	long _pushed = -1;
+};
+
+inline void SaiModel::updateModel() {
+	if (_controller) _controller->pushState();
+}
+
+}  // namespace SaiPrimitivesBatched

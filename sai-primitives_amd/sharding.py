@@ -35,7 +35,7 @@ def gather_torques(tau_local, world: int):
     if world == 1:
         out[0].copy_(tau_local)
     else:
-        dist.all_gather_into_tensor(out, tau_local.contiguous())
+        dist.all_gather_into_tensor(out.view((-1,) + tuple(tau_local.shape[1:])), tau_local.contiguous())  # concat along dim 0
     return out
 
 

@@ -1,0 +1,78 @@
+"""world_size-2 test of the N>1 path on CPU (gloo): contiguous instance shards, no data-path collective,
+one all_gather of the torque slabs, max-over-ranks timing.  The GPU engine cannot run here, so each rank's
+shard is computed by the CPU oracle (allowed in tests/): what is under test is the sharding/gather plumbing
+bench.py uses (sai-primitives_amd/sharding.py) and that shard r of the seeded workload is exactly the r-th block
+of the global stream."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_rank, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import workloads as W
+    from oracle import Oracle
+    from sai_primitives_amd import sharding
+
+    r, lr, w = sharding.dist_env()
+    assert (r, w) == (rank, world)
+    dist = sharding.init_process_group("gloo")
+    d = W.make_inputs(2, per_rank, shard=rank)          # what bench.py does per rank
+    tau, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"])
+    assert st.sum() == 0
+    ld = (per_rank + 31) // 32 * 32                      # engine layout: [dof][ld]
+    slab = torch.zeros((7, ld), dtype=torch.float64)
+    slab[:, :per_rank] = torch.from_numpy(tau.T.copy())
+    gathered = sharding.gather_torques(slab, world)      # [world, dof, ld] on every rank
+    t = sharding.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    assert t == float(world)
+    np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_and_gather(tmp_path):
+    import torch.multiprocessing as mp
+    import workloads as W
+    from oracle import Oracle
+    from sai_primitives_amd import sharding
+
+    world, per_rank = 2, 24
+    mp.spawn(_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
+    g0 = np.load(tmp_path / "gathered_0.npy")
+    g1 = np.load(tmp_path / "gathered_1.npy")
+    assert np.array_equal(g0, g1)                        # every rank holds the whole result
+    # single-process reference over the global batch: ranks own contiguous blocks of the same stream
+    d = W.make_inputs(2, world * per_rank)
+    ref, _ = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"])
+    for r in range(world):
+        lo, hi = sharding.shard_range(world * per_rank, world, r)
+        assert (lo, hi) == (r * per_rank, (r + 1) * per_rank)
+        assert np.array_equal(g0[r][:, :per_rank].T, ref[lo:hi])
+
+
+def test_shard_range_covers_everything_once():
+    from sai_primitives_amd import sharding
+    for total, world in [(65536, 8), (4097, 8), (10, 3), (5, 8)]:
+        seen = []
+        for r in range(world):
+            lo, hi = sharding.shard_range(total, world, r)
+            seen += list(range(lo, hi))
+        assert seen == list(range(total))
