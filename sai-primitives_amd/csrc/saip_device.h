@@ -65,6 +65,8 @@ struct CycleParams {
 	int mf_task[2];               // task ids of the (at most two) motion-force tasks, -1 when absent
 	int rank_bound[SAIP_MAXT];    // batch-uniform upper bound on the rank of each task in the hierarchy
 	int lane_task_is_joint[SAIP_MAXT];
+	int lane_prefetch_ok;         // stack is {motion-force, full joint task}: the prefetch layout of the latency variant applies
+	int lane_active;              // instances per wavefront in the lane kernel (64 = every lane)
 	int any_bie;
 	int pad1_;
 	double bie_thr;

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -821,6 +822,13 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 			P.any_bie = 1;
 			P.bie_thr = d.bie_threshold;
 		}
+	}
+	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
+						  b->tasks[1].dev.m == P.n) ? 1 : 0;
+	{
+		const char* la = getenv("SAIP_LANE_ACTIVE");
+		int a = la ? atoi(la) : 64;
+		P.lane_active = (a >= 1 && a <= 64) ? a : 64;
 	}
 	return SAIP_OK;
 }

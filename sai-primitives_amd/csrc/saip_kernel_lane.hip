@@ -19,6 +19,7 @@
 // (wave-uniform branch on a ballot: no cost when no lane needs it, no CPU fallback ever).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "saip_device.h"
 #include "saip_wg_linalg.h"
@@ -33,12 +34,35 @@ namespace saip {
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// sin/cos for joint angles: Cody-Waite reduction by pi/2 (two FMA terms, exact for |x| < 1e5) + fdlibm kernel polynomials on
+// [-pi/4, pi/4] (errors < 1 ulp); the rare |x| >= 1e5 takes the library path.  ~35 instructions instead of ~110.
+__device__ __forceinline__ void sincos_joint(const double x, double* sn, double* cs) {
+	if (!(fabs(x) < 1.0e5)) {
+		sincos(x, sn, cs);
+		return;
+	}
+	const double k = rint(x * 6.36619772367581382433e-01);
+	double r = fma(-k, 1.57079632673412561417e+00, x);
+	r = fma(-k, 6.07710050650619224932e-11, r);
+	const double z = r * r;
+	const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+	const double s0 = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+	const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+	const double c0 = 1.0 - fma(0.5, z, -z * pc);
+	const int q = (int)k & 3;
+	const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+	*sn = (q & 2) ? -sa : sa;
+	*cs = ((q + 1) & 2) ? -ca : ca;
+}
+
 typedef const ModelDev CONSTANT_AS* ModelCPtr;
 typedef const TaskDev CONSTANT_AS* TaskCPtr;
 
-template <int N>
+template <int N, bool PF>
 struct LaneSmem {
 	static constexpr int LD = 9;
+	static constexpr int PFN = PF ? (2 * N + 24 + 3 * N) : 1;  // q, dq, motion-force goal block, joint goal block (SIG_MF_JT)
+	double pf[PFN][64];
 	static constexpr int PARK = 6 * N + 24 + 10 * N;  // joint axes + origins, two control frames, per-body spatial inertias
 	double park[PARK][64];
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
@@ -171,11 +195,11 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 	}
 }
 
-template <int N>
-__device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, LaneSmem<N>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+template <int N, bool PF>
+__device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, LaneSmem<N, PF>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
-	constexpr int LD = LaneSmem<N>::LD;
+	constexpr int LD = LaneSmem<N, PF>::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
 	const TaskCPtr tk = tasks + t;
@@ -212,7 +236,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, Lan
 				Jw[2][j] = on ? z[2] : 0.0;
 				Jw[3][j] = Jw[4][j] = Jw[5][j] = 0.0;
 			}
-			const double dqj = P.dq[(size_t)j * ld + b];
+			const double dqj = PF ? sm.pf[N + j][lane] : P.dq[(size_t)j * ld + b];
 			UNR for (int e = 0; e < 6; e++) vw[e] = fma(Jw[e][j], dqj, vw[e]);
 		}
 		if (tk->bm_identity) {
@@ -335,7 +359,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, Lan
 		double xp[3], Rc[9], G24[24];
 		UNR for (int e = 0; e < 3; e++) xp[e] = pw[e];
 		UNR for (int e = 0; e < 9; e++) Rc[e] = sm.park[cbase + 3 + e][lane];
-		UNR for (int e = 0; e < 24; e++) G24[e] = tk->goal[(size_t)e * ld + b];
+		UNR for (int e = 0; e < 24; e++) G24[e] = PF ? sm.pf[2 * N + e][lane] : tk->goal[(size_t)e * ld + b];
 		double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
 		UNR for (int i = 0; i < 3; i++) {
 			v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];
@@ -391,11 +415,11 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, Lan
 	PHASE_FENCE();
 }
 
-template <int N, int RJ>
-__device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+template <int N, int RJ, bool PF>
+__device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N, PF>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
-	constexpr int LD = LaneSmem<N>::LD;
+	constexpr int LD = LaneSmem<N, PF>::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
 	const TaskCPtr tk = tasks + t;
@@ -533,8 +557,8 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N
 			w[i] = s;
 		}
 		UNR for (int j = 0; j < N; j++) {
-			qv[j] = P.q[(size_t)j * ld + b];
-			dqv[j] = P.dq[(size_t)j * ld + b];
+			qv[j] = PF ? sm.pf[j][lane] : P.q[(size_t)j * ld + b];
+			dqv[j] = PF ? sm.pf[N + j][lane] : P.dq[(size_t)j * ld + b];
 		}
 		double a1[RJ], b1[RJ];
 		UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
@@ -553,12 +577,12 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N
 						sw = fma(sij, w[j], sw);
 					}
 				}
-				const double e = cur - tk->goal[(size_t)i * ld + b];
+				const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : tk->goal[(size_t)i * ld + b]);
 				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
 				ie += e * tk->dt;  // :323-324
 				if (track && live) tk->integ[(size_t)i * ld + b] = ie;
-				const double fi = -tk->kp[i] * e - tk->kv[i] * (vel - tk->goal[(size_t)(m + i) * ld + b]) - tk->ki[i] * ie;  // :342-345
-				const double ai = tk->goal[(size_t)(2 * m + i) * ld + b] - sw;
+				const double fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : tk->goal[(size_t)(m + i) * ld + b])) - tk->ki[i] * ie;  // :342-345
+				const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : tk->goal[(size_t)(2 * m + i) * ld + b]) - sw;
 				UNR for (int c = 0; c < RJ; c++) {
 					a1[c] = fma(U[i][c], ai, a1[c]);
 					b1[c] = fma(U[i][c], fi, b1[c]);
@@ -576,20 +600,37 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N
 
 enum { SIG_GENERIC = 0, SIG_MF_JT = 1 };
 
-template <int N, int RJ, int SIG>
+template <int N, int RJ, int SIG, bool PF>
 __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
-	using SM = LaneSmem<N>;
+	static_assert(!PF || SIG == SIG_MF_JT, "the prefetch layout is defined for the MotionForce+Joint stack");
+	using SM = LaneSmem<N, PF>;
 	constexpr int LD = SM::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N, P_BODY = 6 * N + 24;
 	__shared__ SM sm;
 	const int lane = threadIdx.x;
-	int b = blockIdx.x * 64 + lane;
+	const int act = P.lane_active;  // instances per wavefront (64 = full)
+	if (lane >= act) return;
+	int b = blockIdx.x * act + lane;
 	const bool live = b < P.B;
 	if (!live) b = P.B - 1;  // dead lanes shadow the last instance and never store
 	const ModelCPtr md = (ModelCPtr)P.model;
 	const TaskCPtr tasks = (TaskCPtr)P.tasks;
 	const size_t ld = P.ld;
 
+	// ---------------------------------------------------------------- latency variant: every per-instance input is fetched up front
+	// (59 independent coalesced loads in flight at once, one wait) and parked in LDS; nothing below touches HBM again
+	// until the torque store.  Used when the batch leaves at most one wavefront per CU (LDS is free then).
+	if (PF) {
+		double v[2 * N + 24 + 3 * N];
+		UNR for (int j = 0; j < N; j++) {
+			v[j] = P.q[(size_t)j * ld + b];
+			v[N + j] = P.dq[(size_t)j * ld + b];
+		}
+		UNR for (int e = 0; e < 24; e++) v[2 * N + e] = tasks[0].goal[(size_t)e * ld + b];
+		UNR for (int e = 0; e < 3 * N; e++) v[2 * N + 24 + e] = tasks[1].goal[(size_t)e * ld + b];  // full joint task: m == N
+		UNR for (int e = 0; e < 2 * N + 24 + 3 * N; e++) sm.pf[e][lane] = v[e];
+	}
+	PHASE_FENCE();
 	// ---------------------------------------------------------------- forward kinematics (ONE rolled loop over the joints: one code copy,
 	// short live ranges); joint axes/origins, per-body spatial inertias and the control frames are parked in LDS
 	double Minv[N][N], MBinv[N][N], taug[N];
@@ -600,14 +641,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 				const double CONSTANT_AS* R0 = md->R0[j];
 				const double CONSTANT_AS* p0 = md->p0[j];
 				const double ax = md->axis[j][0], ay = md->axis[j][1], az = md->axis[j][2];
-				const double qj = P.q[(size_t)j * ld + b];
+				const double qj = PF ? sm.pf[j][lane] : P.q[(size_t)j * ld + b];
 				double Rt[9];
 				UNR for (int r = 0; r < 3; r++) o[r] += R[3 * r] * p0[0] + R[3 * r + 1] * p0[1] + R[3 * r + 2] * p0[2];
 				UNR for (int r = 0; r < 3; r++)
 					UNR for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * R0[c] + R[3 * r + 1] * R0[3 + c] + R[3 * r + 2] * R0[6 + c];
 				if (md->jtype[j] == 1) {
 					double s, c;
-					sincos(qj, &s, &c);
+					sincos_joint(qj, &s, &c);
 					const double v = 1.0 - c;
 					const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
 										  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
@@ -736,14 +777,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 
 	if (SIG == SIG_MF_JT) {
 		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
-		lane_motion_force_task<N>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
+		lane_motion_force_task<N, PF>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
 		PHASE_FENCE();
-		lane_joint_task<N, RJ>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
+		lane_joint_task<N, RJ, PF>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
 	} else {
 		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 			const bool last = (t == P.nt - 1);
-			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
-			else lane_joint_task<N, RJ>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			else lane_joint_task<N, RJ, PF>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
 			first = false;
 		}
 	}
@@ -780,17 +821,22 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	*supported = inst != 0;
 	if (!inst) return hipSuccess;
 	const bool mf_jt = (P.nt == 2 && !P.lane_task_is_joint[0] && P.lane_task_is_joint[1]);
-	const dim3 grid((P.B + 63) / 64), block(64);
-#define LAUNCH(NN, RR, SS) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS>), grid, block, 0, stream, P)
-	if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT);
+	// latency variant: inputs prefetched into LDS (100 KB per wavefront).  Only worth it while a CU hosts one wavefront,
+	// and its layout assumes a full joint task (3 dof goal rows) below one motion-force task.
+	static const bool want_pf = getenv("SAIP_LANE_PF") != nullptr;  // measured SLOWER (33.0 vs 28.9 us at cfg2): off unless asked for
+	const bool pf = mf_jt && P.lane_prefetch_ok && P.B <= 64 * 256 && want_pf;
+	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
+#define LAUNCH(NN, RR, SS, PP) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP>), grid, block, 0, stream, P)
+	if (P.n == 7 && inst == 1 && mf_jt && pf) LAUNCH(7, 1, SIG_MF_JT, true);
+	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false);
 #ifndef SAIP_LANE_ONLY_71
-	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC);
-	else if (P.n == 7 && inst == 4 && mf_jt) LAUNCH(7, 4, SIG_MF_JT);
-	else if (P.n == 7 && inst == 4) LAUNCH(7, 4, SIG_GENERIC);
-	else if (P.n == 7) LAUNCH(7, 7, SIG_GENERIC);
-	else if (P.n == 8 && inst == 2) LAUNCH(8, 2, SIG_GENERIC);
-	else if (P.n == 8) LAUNCH(8, 8, SIG_GENERIC);
-	else LAUNCH(6, 6, SIG_GENERIC);
+	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC, false);
+	else if (P.n == 7 && inst == 4 && mf_jt) LAUNCH(7, 4, SIG_MF_JT, false);
+	else if (P.n == 7 && inst == 4) LAUNCH(7, 4, SIG_GENERIC, false);
+	else if (P.n == 7) LAUNCH(7, 7, SIG_GENERIC, false);
+	else if (P.n == 8 && inst == 2) LAUNCH(8, 2, SIG_GENERIC, false);
+	else if (P.n == 8) LAUNCH(8, 8, SIG_GENERIC, false);
+	else LAUNCH(6, 6, SIG_GENERIC, false);
 #else
 	else { *supported = false; return hipSuccess; }
 #endif
