@@ -58,12 +58,20 @@ __device__ __forceinline__ void sincos_joint(const double x, double* sn, double*
 typedef const ModelDev CONSTANT_AS* ModelCPtr;
 typedef const TaskDev CONSTANT_AS* TaskCPtr;
 
-template <int N, bool PF>
+// Makes a wave-uniform pointer opaque to the optimiser at this point: constant loads through the result cannot be hoisted
+// above it (they would otherwise all be issued at kernel entry and exhaust the SGPR file -> v_writelane/v_readlane spills).
+template <typename Ptr>
+__device__ __forceinline__ Ptr launder(Ptr p) {
+	asm volatile("" : "+s"(p));
+	return p;
+}
+
+template <int N, bool PF, bool LEAN = false>
 struct LaneSmem {
 	static constexpr int LD = 9;
 	static constexpr int PFN = PF ? (2 * N + 24 + 3 * N) : 1;  // q, dq, motion-force goal block, joint goal block (SIG_MF_JT)
 	double pf[PFN][64];
-	static constexpr int PARK = 6 * N + 24 + 10 * N;  // joint axes + origins, two control frames, per-body spatial inertias
+	static constexpr int PARK = 6 * N + 24 + (LEAN ? 0 : 10 * N);  // joint axes + origins, two control frames, (per-body spatial inertias)
 	double park[PARK][64];
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
@@ -195,14 +203,14 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 	}
 }
 
-template <int N, bool PF>
-__device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, LaneSmem<N, PF>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+template <int N, bool PF, typename SMT>
+__device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
-	constexpr int LD = LaneSmem<N, PF>::LD;
+	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
-	const TaskCPtr tk = tasks + t;
+	TaskCPtr tk = launder(tasks + t);
 	const bool track = (tk->has_ki || P.integ_always);
 	(void)LD; (void)P_Z; (void)P_O; (void)P_CAP; (void)md;
 	// ======================================================== MotionForceTask (6 rows; rows >= k are zero)
@@ -353,6 +361,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, Lan
 	opspace_lambda<N, 6>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
 
 	PHASE_FENCE();
+	tk = launder(tk);
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off)
 	double g[6];
 	{
@@ -415,14 +424,14 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, Lan
 	PHASE_FENCE();
 }
 
-template <int N, int RJ, bool PF>
-__device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N, PF>& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
+template <int N, int RJ, bool PF, typename SMT>
+__device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
-	constexpr int LD = LaneSmem<N, PF>::LD;
+	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
-	const TaskCPtr tk = tasks + t;
+	TaskCPtr tk = launder(tasks + t);
 	const bool track = (tk->has_ki || P.integ_always);
 	(void)LD; (void)P_Z; (void)P_O; (void)P_CAP; (void)md;
 	// ======================================================== JointTask (RJ rows in the range basis)
@@ -547,6 +556,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N
 	double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
 	opspace_lambda<N, RJ>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
 
+	tk = launder(tk);
 	// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
 	double g[RJ];
 	{
@@ -600,10 +610,10 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, LaneSmem<N
 
 enum { SIG_GENERIC = 0, SIG_MF_JT = 1 };
 
-template <int N, int RJ, int SIG, bool PF>
+template <int N, int RJ, int SIG, bool PF, bool LEAN>
 __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	static_assert(!PF || SIG == SIG_MF_JT, "the prefetch layout is defined for the MotionForce+Joint stack");
-	using SM = LaneSmem<N, PF>;
+	using SM = LaneSmem<N, PF, LEAN>;
 	constexpr int LD = SM::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N, P_BODY = 6 * N + 24;
 	__shared__ SM sm;
@@ -635,6 +645,13 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	// short live ranges); joint axes/origins, per-body spatial inertias and the control frames are parked in LDS
 	double Minv[N][N], MBinv[N][N], taug[N];
 	{
+		double Mm[N][N];
+		if (LEAN) {
+			UNR for (int i = 0; i < N; i++) {
+				taug[i] = 0.0;
+				UNR for (int c = 0; c < N; c++) Mm[i][c] = 0.0;
+			}
+		}
 		{
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
 			_Pragma("unroll 1") for (int j = 0; j < N; j++) {
@@ -677,17 +694,54 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 					Iw[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];
 					UNR for (int r = 0; r < 3; r++) c3[r] = o[r] + R[3 * r] * md->com[j][0] + R[3 * r + 1] * md->com[j][1] + R[3 * r + 2] * md->com[j][2];
 					const double m = md->mass[j], cc2 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
-					const int pb = P_BODY + 10 * j;
-					sm.park[pb + 0][lane] = m;
-					sm.park[pb + 1][lane] = m * c3[0];
-					sm.park[pb + 2][lane] = m * c3[1];
-					sm.park[pb + 3][lane] = m * c3[2];
-					sm.park[pb + 4][lane] = Iw[0] + m * (cc2 - c3[0] * c3[0]);
-					sm.park[pb + 5][lane] = Iw[1] + m * (cc2 - c3[1] * c3[1]);
-					sm.park[pb + 6][lane] = Iw[2] + m * (cc2 - c3[2] * c3[2]);
-					sm.park[pb + 7][lane] = Iw[3] - m * c3[0] * c3[1];
-					sm.park[pb + 8][lane] = Iw[4] - m * c3[0] * c3[2];
-					sm.park[pb + 9][lane] = Iw[5] - m * c3[1] * c3[2];
+					const double bd[10] = {m, m * c3[0], m * c3[1], m * c3[2], Iw[0] + m * (cc2 - c3[0] * c3[0]), Iw[1] + m * (cc2 - c3[1] * c3[1]),
+										   Iw[2] + m * (cc2 - c3[2] * c3[2]), Iw[3] - m * c3[0] * c3[1], Iw[4] - m * c3[0] * c3[2], Iw[5] - m * c3[1] * c3[2]};
+					if (!LEAN) {
+						UNR for (int e = 0; e < 10; e++) sm.park[P_BODY + 10 * j + e][lane] = bd[e];
+					} else {
+						// throughput variant (no LDS for the bodies => 4 wavefronts per CU): body j's inertia is added to every
+						// M_ac with a <= c <= j right away (O(n^3) instead of the composite sweep's O(n^2))
+						double Sw[N][3], Sv[N][3];
+						UNR for (int c = 0; c < N; c++) {
+							if (c <= j) {
+								double z[3], oo[3];
+								UNR for (int e = 0; e < 3; e++) {
+									z[e] = sm.park[P_Z + 3 * c + e][lane];
+									oo[e] = sm.park[P_O + 3 * c + e][lane];
+								}
+								if (md->jtype[c] == 1) {
+									UNR for (int e = 0; e < 3; e++) Sw[c][e] = z[e];
+									Sv[c][0] = oo[1] * z[2] - oo[2] * z[1];
+									Sv[c][1] = oo[2] * z[0] - oo[0] * z[2];
+									Sv[c][2] = oo[0] * z[1] - oo[1] * z[0];
+								} else {
+									UNR for (int e = 0; e < 3; e++) {
+										Sw[c][e] = 0.0;
+										Sv[c][e] = z[e];
+									}
+								}
+							}
+						}
+						const double hx = bd[1], hy = bd[2], hz = bd[3];
+						UNR for (int c = 0; c < N; c++) {
+							if (c <= j) {
+								const double* w = Sw[c];
+								const double* v = Sv[c];
+								const double f[3] = {m * v[0] + (w[1] * hz - w[2] * hy), m * v[1] + (w[2] * hx - w[0] * hz), m * v[2] + (w[0] * hy - w[1] * hx)};
+								const double nO[3] = {bd[4] * w[0] + bd[7] * w[1] + bd[8] * w[2] + (hy * v[2] - hz * v[1]),
+													  bd[7] * w[0] + bd[5] * w[1] + bd[9] * w[2] + (hz * v[0] - hx * v[2]),
+													  bd[8] * w[0] + bd[9] * w[1] + bd[6] * w[2] + (hx * v[1] - hy * v[0])};
+								UNR for (int a = 0; a <= c; a++)
+									Mm[a][c] += Sw[a][0] * nO[0] + Sw[a][1] * nO[1] + Sw[a][2] * nO[2] + Sv[a][0] * f[0] + Sv[a][1] * f[1] + Sv[a][2] * f[2];
+							}
+						}
+						if (P.gravity_comp) {
+							const double gx = md->gravity[0], gy = md->gravity[1], gz = md->gravity[2];
+							const double hxg[3] = {hy * gz - hz * gy, hz * gx - hx * gz, hx * gy - hy * gx};
+							UNR for (int a = 0; a < N; a++)
+								if (a <= j) taug[a] -= Sw[a][0] * hxg[0] + Sw[a][1] * hxg[1] + Sw[a][2] * hxg[2] + m * (Sv[a][0] * gx + Sv[a][1] * gy + Sv[a][2] * gz);
+						}
+					}
 				}
 				UNR for (int s = 0; s < 2; s++) {  // control frames of the motion-force tasks attached to this body
 					const int t = P.mf_task[s];
@@ -704,8 +758,10 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 		PHASE_FENCE();
 		// M(q) from composite inertias (backward sweep): M_ij = S_i . (Ic_j S_j), i <= j
-		double Mm[N][N];
-		{
+		if (LEAN) {
+			UNR for (int c = 0; c < N; c++)
+				UNR for (int a = 0; a < c; a++) Mm[c][a] = Mm[a][c];
+		} else {
 			double Sw[N][3], Sv[N][3];
 			UNR for (int j = 0; j < N; j++) {
 				double z[3], o[3];
@@ -777,14 +833,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 
 	if (SIG == SIG_MF_JT) {
 		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
-		lane_motion_force_task<N, PF>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
+		lane_motion_force_task<N, PF, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
 		PHASE_FENCE();
-		lane_joint_task<N, RJ, PF>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
+		lane_joint_task<N, RJ, PF, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
 	} else {
 		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 			const bool last = (t == P.nt - 1);
-			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
-			else lane_joint_task<N, RJ, PF>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			else lane_joint_task<N, RJ, PF, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
 			first = false;
 		}
 	}
@@ -825,9 +881,13 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	// and its layout assumes a full joint task (3 dof goal rows) below one motion-force task.
 	static const bool want_pf = getenv("SAIP_LANE_PF") != nullptr;  // measured SLOWER (33.0 vs 28.9 us at cfg2): off unless asked for
 	const bool pf = mf_jt && P.lane_prefetch_ok && P.B <= 64 * 256 && want_pf;
+	// throughput variant once the batch needs more than two wavefronts per CU: 36 KB LDS per wavefront instead of 72 KB
+	static const char* lean_env = getenv("SAIP_LANE_LEAN");  // "0"/"1" forces the choice (profiling)
+	const bool lean = lean_env ? (lean_env[0] == '1') : (P.B > 64 * 256 * 2);
 	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
-#define LAUNCH(NN, RR, SS, PP) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP>), grid, block, 0, stream, P)
-	if (P.n == 7 && inst == 1 && mf_jt && pf) LAUNCH(7, 1, SIG_MF_JT, true);
+#define LAUNCH(NN, RR, SS, PP) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false>), grid, block, 0, stream, P)
+	if (P.n == 7 && inst == 1 && mf_jt && lean) hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true>), grid, block, 0, stream, P);
+	else if (P.n == 7 && inst == 1 && mf_jt && pf) LAUNCH(7, 1, SIG_MF_JT, true);
 	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false);
 #ifndef SAIP_LANE_ONLY_71
 	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC, false);
