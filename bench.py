@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general workgroup-per-instance, 2 lane-per-instance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic", type=float, default=None, help="measured HBM bytes per launch (from a separate rocprofv3 --pmc pass)")
+    ap.add_argument("--traffic", type=float, default=None, help="measured HBM bytes per launch (from a separate rocprofv3 --pmc pass); "
+                    "default: the committed PMC summary profiles/pmc_traffic.json when it matches kernel/config/batch")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,6 +122,20 @@ def main():
     ok = ok and bool(torch.equal(gathered[rank], tau_t))
 
     if rank == 0:
+        traffic = args.traffic
+        traffic_src = "--traffic" if traffic is not None else None
+        if traffic is None:
+            # FETCH_SIZE / WRITE_SIZE come from separate `rocprofv3 --pmc` passes of this same command (gpurun refuses PMC + tracing
+            # in one run); their per-launch means are committed under profiles/ and keyed by config/batch/kernel variant.
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pt = json.load(f)
+                key = f"cfg{args.config}_B{B}"
+                if key in pt and pt[key]["kernel"] == ctrl.kernelName():
+                    traffic = pt[key]["hbm_bytes_per_launch"]
+                    traffic_src = pt[key]["source"]
+            except (OSError, KeyError, ValueError):
+                pass
         total_cycles = B * world * args.steps
         value = total_cycles / elapsed
         flops = W.algorithmic_flops(d["model"], d["tasks"])
@@ -139,10 +154,10 @@ def main():
                        "one final torque all_gather", "kernel": ctrl.kernelName()},
             "roofline": {"bound": "mfma", "note": "FP64 compute bound (FP64 vector pipe; its peak equals the FP64 MFMA peak on MI355X); HBM never binds",
                          "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
-                         "traffic": args.traffic, "algorithmic_flops_per_cycle": flops, "units_per_launch": B,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_cycle": flops, "units_per_launch": B,
                          "avg_launch_us": launch_s * 1e6, "kernel": ctrl.kernelName()},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_cycle": byts, "traffic": args.traffic},
+                             "algorithmic_bytes_per_cycle": byts, "traffic": traffic},
             "max_abs_tau": float(np.abs(tau).max()), "valid": ok,
         }
         if not args.no_cpu_baseline and world == 1:
