@@ -107,7 +107,7 @@ int saip_batch_task_type(const saip_batch* batch, int task_id);   /* TemplateTas
 const char* saip_batch_task_name(const saip_batch* batch, int task_id); /* TemplateTask::getTaskName / getTaskNames */
 int saip_batch_task_by_name(const saip_batch* batch, const char* name); /* get{Joint,MotionForce}TaskByName; -1 when absent */
 int saip_batch_task_dof(const saip_batch* batch, int task_id);    /* JointTask::getTaskDof (rows of S); 6-dof projector rank for motion-force */
-int saip_batch_goal_components(const saip_batch* batch, int task_id); /* 24 (x3,R9 row-major,v3,w3,a3,alpha3) or 3*m (q,dq,ddq) */
+int saip_batch_goal_components(const saip_batch* batch, int task_id); /* 30 (x3,R9 row-major,v3,w3,a3,alpha3,goal force 3,goal moment 3) or 3*m (q,dq,ddq) */
 /* MotionForceTask partial task projection P (6x6 row-major, MotionForceTask.cpp:55-87) and the orthonormal basis of
  * range(P) the engine works in (6x6 row-major, first *rank columns valid; = _current_task_range, :162-168) */
 saip_status saip_batch_get_task_projection(const saip_batch* batch, int task_id, double* P36, double* basis36, int* rank);
@@ -126,8 +126,26 @@ saip_status saip_batch_set_singularity_bounds(saip_batch*, int task, double s_mi
 /* disableInternalOtg / enableInternalOtg* (.h:423, JointTask.h:323).  The reference default is ENABLED; the engine
  * has no on-device OTG yet, so a cycle with OTG enabled on any task fails with SAIP_ERR_UNSUPPORTED. */
 saip_status saip_batch_set_internal_otg(saip_batch*, int task, int enabled);
-/* velocity saturation (MotionForceTask.h enable/disableVelocitySaturation, JointTask.h): enabled -> SAIP_ERR_UNSUPPORTED */
+/* velocity saturation: MotionForceTask::enableVelocitySaturation(linear, angular) / disableVelocitySaturation
+ * (MotionForceTask.cpp:771-792, law :416-430, :449-462); JointTask::enableVelocitySaturation(value | vector) (JointTask.cpp:410-436,
+ * law :327-341).  n_values: motion-force task 2 = {linear, angular}; joint task 1 or task dof; 0 keeps the stored/default limits
+ * (MotionForceTask.h:63-64: 0.3, pi/3; JointTask.h:44: pi/3). */
 saip_status saip_batch_set_velocity_saturation(saip_batch*, int task, int enabled);
+saip_status saip_batch_set_saturation_velocities(saip_batch*, int task, const double* values, int n_values);
+/* MotionForceTask::parametrizeForceMotionSpaces / parametrizeMomentRotMotionSpaces (MotionForceTask.cpp:828-890): dimension 0..3,
+ * axis used for dimensions 1 and 2.  *changed (optional) = the reference's return value; when the parametrisation changed and the
+ * device holds a state, the linear (angular) goal is reset to the current pose and the integrators to zero like the reference does. */
+saip_status saip_batch_parametrize_force_motion_spaces(saip_batch*, int task, int force_space_dimension, const double axis[3], int* changed);
+saip_status saip_batch_parametrize_moment_rot_motion_spaces(saip_batch*, int task, int moment_space_dimension, const double axis[3], int* changed);
+/* constructor argument is_force_motion_parametrization_in_compliant_frame (MotionForceTask.h:96-110): axes and goal force/moment
+ * are expressed in the compliant frame instead of the world frame */
+saip_status saip_batch_set_parametrization_in_compliant_frame(saip_batch*, int task, int enabled);
+/* MotionForceTask::setForceControlGains / setMomentControlGains: open-loop force control uses kv only (MotionForceTask.cpp:350-354, :379-383) */
+saip_status saip_batch_set_force_control_gains(saip_batch*, int task, double kp, double kv, double ki);
+saip_status saip_batch_set_moment_control_gains(saip_batch*, int task, double kp, double kv, double ki);
+/* setClosedLoopForceControl / setClosedLoopMomentControl: enabled -> SAIP_ERR_UNSUPPORTED (needs sensed forces + POPC, out of scope) */
+saip_status saip_batch_set_closed_loop_force_control(saip_batch*, int task, int enabled);
+saip_status saip_batch_set_closed_loop_moment_control(saip_batch*, int task, int enabled);
 /* RobotController::enable{GravityCompensation,JointLimitAvoidance,TorqueSaturation}, RobotController.h:64-75 */
 saip_status saip_batch_enable_gravity_compensation(saip_batch*, int enabled);
 saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* enabled -> SAIP_ERR_UNSUPPORTED (next row) */

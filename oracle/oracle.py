@@ -40,6 +40,8 @@ def lib():
         L.orc_set_timestep.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_goal_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_mf_force_spaces.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double]
+        L.orc_set_velocity_saturation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, dp]
         L.orc_reset_state.argtypes = [C.c_void_p]
         L.orc_step_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(dp), dp, C.POINTER(C.c_ubyte), C.c_int]
         L.orc_step_details.argtypes = [C.c_void_p, dp, dp, C.POINTER(dp), dp, dp, dp, dp, dp, dp]
@@ -95,6 +97,11 @@ class Oracle:
                 g = [_d(_vec3(t[k])) for k in ("kp_pos", "kv_pos", "ki_pos", "kp_ori", "kv_ori", "ki_ori")]
                 L.orc_set_mf_gains(self._h, tid, *[x[1] for x in g])
                 L.orc_set_singularity_bounds(self._h, tid, t["s_min"], t["s_max"])
+                fa, ma = _d(_vec3(t.get("force_axis", [0, 0, 1]))), _d(_vec3(t.get("moment_axis", [0, 0, 1])))
+                L.orc_set_mf_force_spaces(self._h, tid, int(t.get("force_dim", 0)), fa[1], int(t.get("moment_dim", 0)), ma[1],
+                                          int(bool(t.get("param_in_compliant_frame", False))), float(t.get("kv_force", 10.0)), float(t.get("kv_moment", 10.0)))
+                L.orc_set_velocity_saturation(self._h, tid, int(bool(t.get("vel_sat", False))), float(t.get("lin_sat", 0.3)),
+                                              float(t.get("ang_sat", np.pi / 3)), None)
             else:
                 import workloads as W
                 S = W.joint_selection(t, self.n)
@@ -108,6 +115,8 @@ class Oracle:
                 m = S.shape[0]
                 g = [_d(np.broadcast_to(np.asarray(t[k], float), (m,)).copy()) for k in ("kp", "kv", "ki")]
                 L.orc_set_joint_gains(self._h, tid, *[x[1] for x in g])
+                sat = _d(np.broadcast_to(np.asarray(t.get("sat", np.pi / 3), float), (m,)).copy())
+                L.orc_set_velocity_saturation(self._h, tid, int(bool(t.get("vel_sat", False))), 0.0, 0.0, sat[1])
             L.orc_set_decoupling(self._h, tid, int(t["decoupling"]), float(t["bie_threshold"]))
             L.orc_set_timestep(self._h, tid, float(t["dt"]))
             self.goal_sizes.append(L.orc_goal_size(self._h, tid))

@@ -56,10 +56,14 @@ typedef struct {
 	int pos_range, ori_range;
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double s_min, s_max, s_abs_tol;
+	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
+	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
+	double force_axis[3], moment_axis[3];
 	/* joint */
 	int m;
 	double S[MAXN * MAXN]; /* m x n row-major */
 	double kp[MAXN], kv[MAXN], ki[MAXN];
+	double sat[MAXN]; /* joint velocity saturation (uses vel_sat) */
 } orc_task;
 
 typedef struct {
@@ -455,6 +459,24 @@ static void mf_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	mm(tm->jacobian, tm->N_prec, tm->projected_jacobian, 6, n, n); /* :264 */
 	sh_update_task_model(c, t, rs, tm);                        /* :266 */
 }
+/* sigmaForce / sigmaMoment, MotionForceTask.cpp:892-925, 932-966 */
+static void sigma_space(const double Pb[9], int dim, const double axis[3], const double rot[9], double out[9]) {
+	if (dim == 0) {
+		memset(out, 0, 9 * sizeof(double));
+		return;
+	}
+	if (dim == 3) {
+		memcpy(out, Pb, 9 * sizeof(double));
+		return;
+	}
+	double a[3], nrm = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]), an[3] = {axis[0] / nrm, axis[1] / nrm, axis[2] / nrm};
+	mat3v(rot, an, a);
+	double in[9], T[9];
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) in[i * 3 + j] = dim == 1 ? a[i] * a[j] : (i == j) - a[i] * a[j];
+	mm(Pb, in, T, 3, 3, 3);
+	mmT(T, Pb, out, 3, 3, 3);
+}
 /* MotionForceTask::computeTorques(), :278-509, with sigma_force = sigma_moment = 0 (defaults, :897-899, :937-939),
  * OTG disabled (desired = goal, :385-391), velocity saturation off, open-loop force control. */
 static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm, const double* goal,
@@ -473,29 +495,78 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 			v[i] += tm->jacobian[i * n + j] * rs->dq[j];       /* :293-298 */
 			w[i] += tm->jacobian[(3 + i) * n + j] * rs->dq[j];
 		}
-	double sig_p[9], sig_o[9], Pp[9], Po[9], T[9];
+	double sig_p[9], sig_o[9], sig_f[9], sig_m[9], Pp[9], Po[9], rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	for (int i = 0; i < 3; i++)
 		for (int j = 0; j < 3; j++) {
 			Pp[i * 3 + j] = t->P[i * 6 + j];
 			Po[i * 3 + j] = t->P[(3 + i) * 6 + 3 + j];
 		}
-	mmT(Pp, Pp, sig_p, 3, 3, 3); /* sigmaPosition = Ppos (I - 0) Ppos^T, :927-930 */
-	mmT(Po, Po, sig_o, 3, 3, 3); /* :968-971 */
-	(void)T;
-	double e[3], tmp[3], F_um[6];
+	if (t->param_in_compliant_frame) memcpy(rot, Rc, sizeof(rot)); /* :894-897, 934-937 */
+	sigma_space(Pp, t->force_dim, t->force_axis, rot, sig_f);   /* sigmaForce :892-925 */
+	sigma_space(Po, t->moment_dim, t->moment_axis, rot, sig_m); /* sigmaMoment :932-966 */
+	{
+		double ImS[9], T[9];
+		for (int i = 0; i < 9; i++) ImS[i] = ((i % 4) == 0) - sig_f[i];
+		mm(Pp, ImS, T, 3, 3, 3);
+		mmT(T, Pp, sig_p, 3, 3, 3); /* sigmaPosition :927-930 */
+		for (int i = 0; i < 9; i++) ImS[i] = ((i % 4) == 0) - sig_m[i];
+		mm(Po, ImS, T, 3, 3, 3);
+		mmT(T, Po, sig_o, 3, 3, 3); /* sigmaOrientation :968-971 */
+	}
+	double goal_force[3] = {0, 0, 0}, goal_moment[3] = {0, 0, 0}, tmp[3], e[3], F_um[6];
+	if (t->force_dim || t->moment_dim) { /* getGoalForce / getGoalMoment :755-769 */
+		mat3v(rot, goal + 24, goal_force);
+		mat3v(rot, goal + 27, goal_moment);
+	}
+	/* open-loop force / moment terms :350-354, :379-383 */
+	double F_f[6];
+	for (int i = 0; i < 3; i++) tmp[i] = -t->kv_force * v[i];
+	mat3v(sig_f, tmp, F_f);
+	for (int i = 0; i < 3; i++) tmp[i] = -t->kv_moment * w[i];
+	mat3v(sig_m, tmp, F_f + 3);
 	for (int i = 0; i < 3; i++) e[i] = p[i] - xd[i];
 	mat3v(sig_p, e, tmp);
 	for (int i = 0; i < 3; i++) integ[i] += tmp[i] * t->dt;   /* :411-413 */
-	for (int i = 0; i < 3; i++) tmp[i] = ad[i] - t->kp_pos[i] * e[i] - t->kv_pos[i] * (v[i] - vd[i]) - t->ki_pos[i] * integ[i];
+	if (t->vel_sat) { /* :416-430 */
+		double se[3], vdes[3], nrm = 0;
+		mat3v(sig_p, e, se);
+		for (int i = 0; i < 3; i++) {
+			double kvi = fabs(t->kv_pos[i]) > 1e-6 ? 1.0 / t->kv_pos[i] : 0.0; /* computePseudoInverse of the diagonal gain */
+			vdes[i] = -t->kp_pos[i] * kvi * se[i] - t->ki_pos[i] * kvi * integ[i];
+			nrm += vdes[i] * vdes[i];
+		}
+		nrm = sqrt(nrm);
+		if (nrm > t->lin_sat)
+			for (int i = 0; i < 3; i++) vdes[i] *= t->lin_sat / nrm;
+		for (int i = 0; i < 3; i++) tmp[i] = ad[i] - t->kv_pos[i] * (v[i] - vdes[i]);
+	} else {
+		for (int i = 0; i < 3; i++) tmp[i] = ad[i] - t->kp_pos[i] * e[i] - t->kv_pos[i] * (v[i] - vd[i]) - t->ki_pos[i] * integ[i];
+	}
 	mat3v(sig_p, tmp, F_um);                                   /* :431-437 */
 	double oe[3], dphi[3];
 	orientation_error(Rd, Rc, oe);
 	mat3v(sig_o, oe, dphi);                                    /* :441-443 */
 	for (int i = 0; i < 3; i++) integ[3 + i] += dphi[i] * t->dt; /* :446 */
-	for (int i = 0; i < 3; i++) tmp[i] = ald[i] - t->kp_ori[i] * dphi[i] - t->kv_ori[i] * (w[i] - wd[i]) - t->ki_ori[i] * integ[3 + i];
+	if (t->vel_sat) { /* :449-462 */
+		double wdes[3], nrm = 0;
+		for (int i = 0; i < 3; i++) {
+			double kvi = fabs(t->kv_ori[i]) > 1e-6 ? 1.0 / t->kv_ori[i] : 0.0;
+			wdes[i] = -t->kp_ori[i] * kvi * dphi[i] - t->ki_ori[i] * kvi * integ[3 + i];
+			nrm += wdes[i] * wdes[i];
+		}
+		nrm = sqrt(nrm);
+		if (nrm > t->ang_sat)
+			for (int i = 0; i < 3; i++) wdes[i] *= t->ang_sat / nrm;
+		for (int i = 0; i < 3; i++) tmp[i] = ald[i] - t->kv_ori[i] * (w[i] - wdes[i]);
+	} else {
+		for (int i = 0; i < 3; i++) tmp[i] = ald[i] - t->kp_ori[i] * dphi[i] - t->kv_ori[i] * (w[i] - wd[i]) - t->ki_ori[i] * integ[3 + i];
+	}
 	mat3v(sig_o, tmp, F_um + 3);                               /* :463-468 */
-	/* force_moment_contribution + feedforward = 0 with sigma_force = sigma_moment = 0 (:350-354,:379-383,:480-482) */
-	double F_f[6] = {0, 0, 0, 0, 0, 0};
+	/* force_moment_contribution + feedforward (open loop: no kff scaling) :471-487 */
+	mat3v(sig_f, goal_force, tmp);
+	for (int i = 0; i < 3; i++) F_f[i] += tmp[i];
+	mat3v(sig_m, goal_moment, tmp);
+	for (int i = 0; i < 3; i++) F_f[3 + i] += tmp[i];
 	/* SingularityHandler::computeTorques, :307-309 */
 	double a[6], b[6], f[6];
 	mTm(tm->task_range_ns, F_um, a, 6, k, 1);
@@ -546,7 +617,15 @@ static void jt_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	const double *qd = goal, *dqd = goal + m, *ddqd = goal + 2 * m;
 	for (int i = 0; i < m; i++) {
 		integ[i] += (cur[i] - qd[i]) * t->dt;                   /* :323-324 */
-		f[i] = -t->kp[i] * (cur[i] - qd[i]) - t->kv[i] * (vel[i] - dqd[i]) - t->ki[i] * integ[i]; /* :342-345 */
+		if (t->vel_sat) { /* :327-341 */
+			double kvi = fabs(t->kv[i]) > 1e-6 ? 1.0 / t->kv[i] : 0.0;
+			double vdes = -t->kp[i] * kvi * (cur[i] - qd[i]) - t->ki[i] * kvi * integ[i];
+			if (vdes > t->sat[i]) vdes = t->sat[i];
+			else if (vdes < -t->sat[i]) vdes = -t->sat[i];
+			f[i] = -t->kv[i] * (vel[i] - vdes);
+		} else {
+			f[i] = -t->kp[i] * (cur[i] - qd[i]) - t->kv[i] * (vel[i] - dqd[i]) - t->ki[i] * integ[i]; /* :342-345 */
+		}
 	}
 	double a[MAXN], b[MAXN], fr[MAXN], g[MAXN], Ua[MAXN];
 	mTm(tm->current_task_range, ddqd, a, m, r, 1);
@@ -767,6 +846,9 @@ int orc_add_motion_force_task(orc_ctx* c, int link, const double* pos_in_link, c
 	}
 	t->s_min = 6e-3; t->s_max = 6e-2; /* MotionForceTask.cpp:197 */
 	t->s_abs_tol = 1e-3;              /* SingularityHandler.cpp:11 */
+	t->kv_force = 10.0; t->kv_moment = 10.0; /* MotionForceTask.h:51,54 */
+	t->lin_sat = 0.3; t->ang_sat = M_PI / 3;  /* :63-64 */
+	t->force_axis[2] = 1.0; t->moment_axis[2] = 1.0;
 	return c->nt++;
 }
 /* JointTask ctor: rows<=0 => full (S = I, JointTask.cpp:18-19) */
@@ -784,7 +866,7 @@ int orc_add_joint_task(orc_ctx* c, const double* S, int rows) {
 		t->m = rows;
 		memcpy(t->S, S, sizeof(double) * rows * c->n);
 	}
-	for (int i = 0; i < t->m; i++) { t->kp[i] = 50.0; t->kv[i] = 14.0; t->ki[i] = 0.0; } /* JointTask.h:32-34 */
+	for (int i = 0; i < t->m; i++) { t->kp[i] = 50.0; t->kv[i] = 14.0; t->ki[i] = 0.0; t->sat[i] = M_PI / 3.0; } /* JointTask.h:32-34, 44 */
 	return c->nt++;
 }
 void orc_set_mf_gains(orc_ctx* c, int task, const double* kp_pos, const double* kv_pos, const double* ki_pos, const double* kp_ori,
@@ -814,7 +896,23 @@ int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
 	c->torque_sat = torque_sat;
 	return 0;
 }
-int orc_goal_size(const orc_ctx* c, int task) { return c->task[task].type == TASK_MOTION_FORCE ? 24 : 3 * c->task[task].m; }
+int orc_goal_size(const orc_ctx* c, int task) {
+	const orc_task* t = &c->task[task];
+	if (t->type == TASK_MOTION_FORCE) return (t->force_dim || t->moment_dim) ? 30 : 24;
+	return 3 * t->m;
+}
+void orc_set_mf_force_spaces(orc_ctx* c, int task, int force_dim, const double* force_axis, int moment_dim, const double* moment_axis,
+							 int param_in_compliant_frame, double kv_force, double kv_moment) {
+	orc_task* t = &c->task[task];
+	t->force_dim = force_dim; t->moment_dim = moment_dim; t->param_in_compliant_frame = param_in_compliant_frame;
+	t->kv_force = kv_force; t->kv_moment = kv_moment;
+	for (int i = 0; i < 3; i++) { t->force_axis[i] = force_axis[i]; t->moment_axis[i] = moment_axis[i]; }
+}
+void orc_set_velocity_saturation(orc_ctx* c, int task, int enabled, double lin_sat, double ang_sat, const double* joint_sat) {
+	orc_task* t = &c->task[task];
+	t->vel_sat = enabled; t->lin_sat = lin_sat; t->ang_sat = ang_sat;
+	if (joint_sat) for (int i = 0; i < t->m; i++) t->sat[i] = joint_sat[i];
+}
 void orc_reset_state(orc_ctx* c) {
 	free(c->integ);
 	c->integ = NULL;

@@ -8,7 +8,7 @@ import subprocess
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libsaip.so")
 SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip"]
-HEADERS = ["csrc/saip_device.h", "../include/saip.h"]
+HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "../include/saip.h"]
 
 SAIP_OK, SAIP_ERR_INVALID_ARGUMENT, SAIP_ERR_UNSUPPORTED, SAIP_ERR_NO_DEVICE, SAIP_ERR_DEVICE, SAIP_ERR_ORDER = range(6)
 NAME_LEN = 48
@@ -87,6 +87,14 @@ def lib():
         "saip_batch_set_singularity_bounds": (C.c_int, [vp, C.c_int, C.c_double, C.c_double]),
         "saip_batch_set_internal_otg": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_velocity_saturation": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_saturation_velocities": (C.c_int, [vp, C.c_int, dp, C.c_int]),
+        "saip_batch_parametrize_force_motion_spaces": (C.c_int, [vp, C.c_int, C.c_int, dp, ip]),
+        "saip_batch_parametrize_moment_rot_motion_spaces": (C.c_int, [vp, C.c_int, C.c_int, dp, ip]),
+        "saip_batch_set_parametrization_in_compliant_frame": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_force_control_gains": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_double]),
+        "saip_batch_set_moment_control_gains": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_double]),
+        "saip_batch_set_closed_loop_force_control": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_closed_loop_moment_control": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_enable_gravity_compensation": (C.c_int, [vp, C.c_int]),
         "saip_batch_enable_joint_limit_avoidance": (C.c_int, [vp, C.c_int]),
         "saip_batch_enable_torque_saturation": (C.c_int, [vp, C.c_int]),

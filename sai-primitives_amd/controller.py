@@ -195,7 +195,12 @@ class _Task:
     def enableInternalOtgJerkLimited(self, *a):
         self._cfg("saip_batch_set_internal_otg", 1)
 
-    def enableVelocitySaturation(self, *a):
+    def enableVelocitySaturation(self, *values):
+        """MotionForceTask: (linear_vel_sat, angular_vel_sat); JointTask: (value) or (vector of task dof); () keeps the defaults"""
+        if values:
+            v = np.ascontiguousarray(np.concatenate([np.atleast_1d(np.asarray(x, float)) for x in values]))
+            self._keepalive.append(v)
+            self._cfg("saip_batch_set_saturation_velocities", _dptr(v), int(v.shape[0]))
         self._cfg("saip_batch_set_velocity_saturation", 1)
 
     def disableVelocitySaturation(self):
@@ -233,8 +238,10 @@ class MotionForceTask(_Task):
 
     def __init__(self, robot, link_name, compliant_frame_pos=(0.0, 0.0, 0.0), compliant_frame_rot=None,
                  controlled_directions_translation=None, controlled_directions_rotation=None,
-                 task_name="motion_force_task", loop_timestep=0.001):
+                 task_name="motion_force_task", is_force_motion_parametrization_in_compliant_frame=False, loop_timestep=0.001):
         super().__init__(robot, task_name, loop_timestep)
+        if is_force_motion_parametrization_in_compliant_frame:
+            self._cfg("saip_batch_set_parametrization_in_compliant_frame", 1)
         self.link_name = link_name
         self.pos = np.asarray(compliant_frame_pos, float).reshape(3).copy()
         self.rot = None if compliant_frame_rot is None else np.ascontiguousarray(np.asarray(compliant_frame_rot, float).reshape(9))
@@ -275,6 +282,40 @@ class MotionForceTask(_Task):
 
     def setGoalAngularAcceleration(self, a):
         self._set_field(21, 3, a, "setGoalAngularAcceleration")
+
+    def setGoalForce(self, f):  # MotionForceTask.h setGoalForce / setGoalMoment
+        self._set_field(24, 3, f, "setGoalForce")
+
+    def setGoalMoment(self, m):
+        self._set_field(27, 3, m, "setGoalMoment")
+
+    def _space(self, fn, dim, axis):
+        a = np.ascontiguousarray(np.asarray(axis if axis is not None else (0.0, 0.0, 0.0), float).reshape(3))
+        self._keepalive.append(a)
+        if self._ctrl is None:
+            self._pending.append((fn, (int(dim), _dptr(a), None)))
+            return None
+        ch = C.c_int(0)
+        self._ctrl._call(fn, self._id, int(dim), _dptr(a), C.byref(ch))
+        return bool(ch.value)
+
+    def parametrizeForceMotionSpaces(self, force_space_dimension, force_or_motion_single_axis=None):  # MotionForceTask.h:560-580
+        return self._space("saip_batch_parametrize_force_motion_spaces", force_space_dimension, force_or_motion_single_axis)
+
+    def parametrizeMomentRotMotionSpaces(self, moment_space_dimension, moment_or_rot_motion_single_axis=None):
+        return self._space("saip_batch_parametrize_moment_rot_motion_spaces", moment_space_dimension, moment_or_rot_motion_single_axis)
+
+    def setForceControlGains(self, kp, kv, ki=0.0):
+        self._cfg("saip_batch_set_force_control_gains", float(kp), float(kv), float(ki))
+
+    def setMomentControlGains(self, kp, kv, ki=0.0):
+        self._cfg("saip_batch_set_moment_control_gains", float(kp), float(kv), float(ki))
+
+    def setClosedLoopForceControl(self, enabled: bool):
+        self._cfg("saip_batch_set_closed_loop_force_control", int(enabled))
+
+    def setClosedLoopMomentControl(self, enabled: bool):
+        self._cfg("saip_batch_set_closed_loop_moment_control", int(enabled))
 
     def getGoalPosition(self):
         return self._get_goal()[:, 0:3]
@@ -451,6 +492,9 @@ class RobotController:
         """goals[t]: (B, goal_components) whole goal block per task, controller order"""
         for t, g in zip(self._tasks, goals):
             gs = capi.lib().saip_batch_goal_components(self._h, t._id)
+            g = np.asarray(g, float)
+            if gs == 30 and g.ndim == 2 and g.shape[1] == 24:  # no goal force / moment given: zeros
+                g = np.concatenate([g, np.zeros((g.shape[0], 6))], axis=1)
             a = _soa(g, self.batch_size, gs, f"goal of task {t.getTaskName()}")
             capi.check(capi.lib().saip_batch_set_goal_host(self._h, t._id, _dptr(a)))
 
@@ -489,10 +533,19 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
     for t in tasks:
         if t["type"] == "motion_force":
             o = MotionForceTask(robot, t["link"], t["pos_in_link"], t.get("rot_in_link"), t.get("dirs_trans"), t.get("dirs_rot"),
-                                task_name=t["name"], loop_timestep=t.get("dt", 0.001))
+                                task_name=t["name"], loop_timestep=t.get("dt", 0.001),
+                                is_force_motion_parametrization_in_compliant_frame=t.get("param_in_compliant_frame", False))
             o.setPosControlGains(t["kp_pos"], t["kv_pos"], t["ki_pos"])
             o.setOriControlGains(t["kp_ori"], t["kv_ori"], t["ki_ori"])
             o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
+            o.setForceControlGains(0.7, t.get("kv_force", 10.0), 1.3)
+            o.setMomentControlGains(0.7, t.get("kv_moment", 10.0), 1.3)
+            if t.get("force_dim", 0):
+                o.parametrizeForceMotionSpaces(t["force_dim"], t.get("force_axis"))
+            if t.get("moment_dim", 0):
+                o.parametrizeMomentRotMotionSpaces(t["moment_dim"], t.get("moment_axis"))
+            if t.get("vel_sat", False):
+                o.enableVelocitySaturation(t["lin_sat"], t["ang_sat"])
         else:
             S = t["S"]
             if S is not None:
@@ -503,6 +556,8 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
                     S[np.arange(len(rows)), rows] = 1.0
             o = JointTask(robot, S, task_name=t["name"], loop_timestep=t.get("dt", 0.001))
             o.setGains(t["kp"], t["kv"], t["ki"])
+            if t.get("vel_sat", False):
+                o.enableVelocitySaturation(t["sat"])
         o.setDynamicDecouplingType(t["decoupling"])
         o.setBoundedInertiaEstimateThreshold(t["bie_threshold"])
         if disable_otg:

@@ -46,6 +46,13 @@ struct TaskDev {
 	double sig_p[9], sig_o[9]; // sigmaPosition / sigmaOrientation (force & moment space dimension 0)
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double kp[SAIP_MAXN], kv[SAIP_MAXN], ki[SAIP_MAXN];
+	// velocity saturation, force / moment spaces (open-loop force control): MotionForceTask.cpp:306-383, 416-430, 449-462, 892-971; JointTask.cpp:327-341
+	int general_law;   // 0: defaults (no velocity saturation, force and moment space dimension 0) -> short control-law path
+	int vel_sat, force_dim, moment_dim, param_in_compliant_frame, pad1_[3];
+	double lin_sat, ang_sat, kv_force, kv_moment;
+	double force_axis[3], moment_axis[3];      // unit axes
+	double kvinv_pos[3], kvinv_ori[3];         // pseudo-inverse of the diagonal kv gains (computePseudoInverse)
+	double kvinv[SAIP_MAXN], sat[SAIP_MAXN];   // joint task
 	double S[SAIP_MAXN * SAIP_MAXN]; // m x n row-major
 	double* goal;      // [goal_comps][ld]
 	double* integ;     // [6 or m][ld]
@@ -67,6 +74,7 @@ struct CycleParams {
 	int lane_task_is_joint[SAIP_MAXT];
 	int lane_prefetch_ok;         // stack is {motion-force, full joint task}: the prefetch layout of the latency variant applies
 	int lane_active;              // instances per wavefront in the lane kernel (64 = every lane)
+	int reinit_task, reinit_mask; // reinit kernel: task (-1 = all) and parts (1 linear/joint, 2 angular, 4 goal force+moment)
 	int any_bie;
 	int pad1_;
 	double bie_thr;

@@ -298,7 +298,7 @@ struct TaskHost {
 struct saip_batch {
 	const saip_model* model = nullptr;
 	int B = 0, ld = 0, device = -1;
-	bool finalized = false, models_valid = false, config_dirty = true;
+	bool finalized = false, models_valid = false, config_dirty = true, state_pushed = false;
 	bool gravity_comp = false, torque_sat = false, integ_always = false;
 	int kernel_choice = 0;
 	std::string kernel_name = "none";
@@ -352,6 +352,7 @@ static saip_status check_batch(const saip_batch* b, int task, const char* fn) {
 	if (task >= (int)b->tasks.size() || task < -1) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: task id %d out of range", fn, task);
 	return SAIP_OK;
 }
+static void refresh_has_ki(TaskDev& d);
 static void task_defaults(TaskDev& d, double dt) {
 	memset(&d, 0, sizeof(TaskDev));
 	d.dt = dt;
@@ -422,7 +423,12 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	m3_T(T.dev.Pori, PT);
 	m3_mul(T.dev.Pori, PT, T.dev.sig_o);
 	T.dev.k = pr + orr;
-	T.dev.goal_comps = 24;
+	T.dev.goal_comps = 30;  // x3 R9 v3 w3 a3 alpha3 + goal force 3 + goal moment 3
+	T.dev.kv_force = 10.0;   // MotionForceTask.h:51,54
+	T.dev.kv_moment = 10.0;
+	T.dev.lin_sat = 0.3;     // :63-64
+	T.dev.ang_sat = M_PI / 3;
+	T.dev.force_axis[2] = T.dev.moment_axis[2] = 1.0;
 	T.dev.bm_identity = (pr == 3 && orr == 3) ? 1 : 0;
 	T.dev.cert_kroot = pow((double)T.dev.k, -1.0 / 16.0);
 	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:44-49
@@ -433,6 +439,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_max = 6e-2;
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
 	T.integ_rows = 6;
+	refresh_has_ki(T.dev);
 	b->tasks.push_back(T);
 	b->config_dirty = true;
 	if (task_id) *task_id = (int)b->tasks.size() - 1;
@@ -496,9 +503,11 @@ extern "C" saip_status saip_batch_add_joint_task(saip_batch* b, const char* task
 		T.dev.kp[i] = 50.0;
 		T.dev.kv[i] = 14.0;
 		T.dev.ki[i] = 0.0;
+		T.dev.sat[i] = M_PI / 3.0;  // JointTask.h:44
 	}
 	T.dev.goal_comps = 3 * T.dev.m;
 	T.integ_rows = T.dev.m;
+	refresh_has_ki(T.dev);
 	b->tasks.push_back(T);
 	b->config_dirty = true;
 	if (task_id) *task_id = (int)b->tasks.size() - 1;
@@ -596,6 +605,13 @@ static saip_status set_gain3(double* kp, double* kv, double* ki, const double* p
 	return SAIP_OK;
 }
 static void refresh_has_ki(TaskDev& d) {
+	// derived fields: pseudo-inverse of the diagonal kv gains (SaiModel::computePseudoInverse), control-law variant
+	for (int c = 0; c < 3; c++) {
+		d.kvinv_pos[c] = fabs(d.kv_pos[c]) > 1e-6 ? 1.0 / d.kv_pos[c] : 0.0;
+		d.kvinv_ori[c] = fabs(d.kv_ori[c]) > 1e-6 ? 1.0 / d.kv_ori[c] : 0.0;
+	}
+	for (int c = 0; c < d.m; c++) d.kvinv[c] = fabs(d.kv[c]) > 1e-6 ? 1.0 / d.kv[c] : 0.0;
+	d.general_law = (d.vel_sat || d.force_dim || d.moment_dim) ? 1 : 0;
 	d.has_ki = 0;
 	if (d.type == saip::TASK_MOTION_FORCE) {
 		for (int c = 0; c < 3; c++)
@@ -684,8 +700,97 @@ extern "C" saip_status saip_batch_set_velocity_saturation(saip_batch* b, int t, 
 	saip_status st = check_batch(b, t, "saip_batch_set_velocity_saturation");
 	if (st) return st;
 	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
-	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "velocity saturation is not implemented on the device yet");
-	b->tasks[t].vel_sat = false;
+	b->tasks[t].dev.vel_sat = enabled ? 1 : 0;
+	refresh_has_ki(b->tasks[t].dev);
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_saturation_velocities(saip_batch* b, int t, const double* v, int nv) {
+	saip_status st = check_batch(b, t, "saip_batch_set_saturation_velocities");
+	if (st) return st;
+	if (t < 0 || (nv > 0 && !v)) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task or null values");
+	TaskDev& d = b->tasks[t].dev;
+	if (d.type == saip::TASK_MOTION_FORCE) {
+		if (nv != 2) return fail(SAIP_ERR_INVALID_ARGUMENT, "MotionForceTask::enableVelocitySaturation takes a linear and an angular saturation velocity");
+		if (v[0] <= 0 || v[1] <= 0)  // MotionForceTask.cpp:773-777
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "Velocity saturation values should be strictly positive or zero in MotionForceTask::enableVelocitySaturation");
+		d.lin_sat = v[0];
+		d.ang_sat = v[1];
+	} else {
+		if (nv != 1 && nv != d.m)  // JointTask.cpp:423-427
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "saturation velocity vector size not consistent with task dof in JointTask::enableVelocitySaturation");
+		for (int i = 0; i < nv; i++)
+			if (v[i] <= 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saturation velocity must be positive in JointTask::enableVelocitySaturation");
+		for (int i = 0; i < d.m; i++) d.sat[i] = v[nv == 1 ? 0 : i];
+	}
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+static saip_status launch_reinit_masked(saip_batch* b, int task, int mask);
+static saip_status parametrize_space(saip_batch* b, int t, int dim, const double* axis, int* changed, bool moment, const char* who) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, who);
+	if (st) return st;
+	if (dim < 0 || dim > 3)  // MotionForceTask.cpp:831-835, 864-868
+		return fail(SAIP_ERR_INVALID_ARGUMENT, "%s space dimension should be between 0 and 3 in %s", moment ? "Moment" : "Force", who);
+	TaskDev& d = b->tasks[t].dev;
+	int& cur_dim = moment ? d.moment_dim : d.force_dim;
+	double* cur_axis = moment ? d.moment_axis : d.force_axis;
+	bool reset = dim != cur_dim;
+	if (dim == 1 || dim == 2) {
+		if (!axis) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: null axis", who);
+		double nrm = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+		if (nrm < 1e-2)  // :838-842, 871-875
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "%s axis should be a non singular vector in %s", moment ? "Moment or rot motion" : "Force or motion", who);
+		double a[3] = {axis[0] / nrm, axis[1] / nrm, axis[2] / nrm};
+		double diff = fabs(a[0] - cur_axis[0]) + fabs(a[1] - cur_axis[1]) + fabs(a[2] - cur_axis[2]);
+		reset = reset || diff > 1e-12;
+		memcpy(cur_axis, a, sizeof(a));
+	}
+	cur_dim = dim;
+	refresh_has_ki(d);
+	b->config_dirty = true;
+	if (changed) *changed = reset ? 1 : 0;
+	if (reset && b->finalized && b->device >= 0 && b->state_pushed)  // goal := current, integrators := 0 (:846-852, 880-886)
+		return launch_reinit_masked(b, t, moment ? 2 : 1);
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_parametrize_force_motion_spaces(saip_batch* b, int t, int dim, const double* axis, int* changed) {
+	return parametrize_space(b, t, dim, axis, changed, false, "MotionForceTask::parametrizeForceMotionSpaces");
+}
+extern "C" saip_status saip_batch_parametrize_moment_rot_motion_spaces(saip_batch* b, int t, int dim, const double* axis, int* changed) {
+	return parametrize_space(b, t, dim, axis, changed, true, "MotionForceTask::parametrizeMomentRotMotionSpaces");
+}
+extern "C" saip_status saip_batch_set_parametrization_in_compliant_frame(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_parametrization_in_compliant_frame");
+	if (st) return st;
+	b->tasks[t].dev.param_in_compliant_frame = enabled ? 1 : 0;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+static saip_status set_fm_gains(saip_batch* b, int t, double kp, double kv, double ki, bool moment, const char* who) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, who);
+	if (st) return st;
+	if (kp < 0 || kv < 0 || ki < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "all gains should be positive or zero in %s", who);
+	(moment ? b->tasks[t].dev.kv_moment : b->tasks[t].dev.kv_force) = kv;  // kp, ki only act in closed-loop force control
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_force_control_gains(saip_batch* b, int t, double kp, double kv, double ki) {
+	return set_fm_gains(b, t, kp, kv, ki, false, "MotionForceTask::setForceControlGains");
+}
+extern "C" saip_status saip_batch_set_moment_control_gains(saip_batch* b, int t, double kp, double kv, double ki) {
+	return set_fm_gains(b, t, kp, kv, ki, true, "MotionForceTask::setMomentControlGains");
+}
+extern "C" saip_status saip_batch_set_closed_loop_force_control(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_closed_loop_force_control");
+	if (st) return st;
+	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "closed-loop force control (sensed forces + POPC, MotionForceTask.cpp:327-349) is out of scope");
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_closed_loop_moment_control(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_closed_loop_moment_control");
+	if (st) return st;
+	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "closed-loop moment control (MotionForceTask.cpp:356-378) is out of scope");
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_enable_gravity_compensation(saip_batch* b, int e) {
@@ -736,6 +841,7 @@ extern "C" saip_status saip_batch_set_state_host(saip_batch* b, const double* q,
 	if (!q || !dq) return fail(SAIP_ERR_INVALID_ARGUMENT, "null state pointer");
 	b->models_valid = false;
 	if ((st = copy_h2d(b, b->q, q, b->model->n))) return st;
+	b->state_pushed = true;
 	return copy_h2d(b, b->dq, dq, b->model->n);
 }
 extern "C" saip_status saip_batch_set_goal_host(saip_batch* b, int t, const double* goal) {
@@ -823,8 +929,10 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 			P.bie_thr = d.bie_threshold;
 		}
 	}
+	P.reinit_task = -1;
+	P.reinit_mask = 7;
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
-						  b->tasks[1].dev.m == P.n) ? 1 : 0;
+						  b->tasks[1].dev.m == P.n && !b->tasks[0].dev.general_law) ? 1 : 0;
 	{
 		const char* la = getenv("SAIP_LANE_ACTIVE");
 		int a = la ? atoi(la) : 64;
@@ -867,21 +975,24 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	return SAIP_OK;
 }
 
-extern "C" saip_status saip_batch_reinitialize_tasks(saip_batch* b) {
-	saip_status st = need_ready(b, "saip_batch_reinitialize_tasks");
-	if (st) return st;
-	bool saved = false;
+static saip_status launch_reinit_masked(saip_batch* b, int task, int mask) {
 	std::vector<bool> otg;
 	for (auto& T : b->tasks) otg.push_back(T.otg_enabled), T.otg_enabled = false;  // reinit does not depend on the OTG flag
-	(void)saved;
 	CycleParams P;
-	st = make_params(b, P, false);
+	saip_status st = make_params(b, P, false);
 	for (size_t i = 0; i < b->tasks.size(); i++) b->tasks[i].otg_enabled = otg[i];
 	if (st) return st;
+	P.reinit_task = task;
+	P.reinit_mask = mask;
 	hipError_t e = saip::launch_reinit(P, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "reinit launch failed: %s", hipGetErrorString(e));
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_reinitialize_tasks(saip_batch* b) {
+	saip_status st = need_ready(b, "saip_batch_reinitialize_tasks");
+	if (st) return st;
+	return launch_reinit_masked(b, -1, 7);
 }
 
 extern "C" saip_status saip_batch_update_task_models(saip_batch* b) {

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "saip_device.h"
+#include "saip_law.h"
 #include "saip_wg_linalg.h"
 
 namespace saip {
@@ -365,55 +366,69 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off)
 	double g[6];
 	{
-		double xp[3], Rc[9], G24[24];
+		double xp[3], Rc[9], G24[30];
 		UNR for (int e = 0; e < 3; e++) xp[e] = pw[e];
 		UNR for (int e = 0; e < 9; e++) Rc[e] = sm.park[cbase + 3 + e][lane];
 		UNR for (int e = 0; e < 24; e++) G24[e] = PF ? sm.pf[2 * N + e][lane] : tk->goal[(size_t)e * ld + b];
-		double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
-		UNR for (int i = 0; i < 3; i++) {
-			v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];
-			w[i] = tk->Pori[3 * i] * vw[3] + tk->Pori[3 * i + 1] * vw[4] + tk->Pori[3 * i + 2] * vw[5];
-		}
+		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6], Ff[6] = {0, 0, 0, 0, 0, 0};
 		if (track) {
 			UNR for (int i = 0; i < 3; i++) {
 				ip[i] = tk->integ[(size_t)i * ld + b];
 				io[i] = tk->integ[(size_t)(3 + i) * ld + b];
 			}
 		}
-		UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G24[i];
-		UNR for (int i = 0; i < 3; i++) ip[i] += (tk->sig_p[3 * i] * e3[0] + tk->sig_p[3 * i + 1] * e3[1] + tk->sig_p[3 * i + 2] * e3[2]) * tk->dt;
-		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - tk->kp_pos[i] * e3[i] - tk->kv_pos[i] * (v[i] - G24[12 + i]) - tk->ki_pos[i] * ip[i];
-		UNR for (int i = 0; i < 3; i++) Fum[i] = tk->sig_p[3 * i] * tmp[0] + tk->sig_p[3 * i + 1] * tmp[1] + tk->sig_p[3 * i + 2] * tmp[2];
-		double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
-		UNR for (int c = 0; c < 3; c++) {
-			const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
-			oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
-			oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
-			oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+		if (tk->general_law) {
+			// velocity saturation and/or force & moment spaces (open-loop force control)
+			UNR for (int e = 24; e < 30; e++) G24[e] = tk->goal[(size_t)e * ld + b];
+			law_motion_force_general(tk, vw, xp, Rc, G24, ip, io, Fum, Ff);
+		} else {
+			double v[3], w[3], e3[3], tmp[3];
+			UNR for (int i = 0; i < 3; i++) {
+				v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];
+				w[i] = tk->Pori[3 * i] * vw[3] + tk->Pori[3 * i + 1] * vw[4] + tk->Pori[3 * i + 2] * vw[5];
+			}
+			UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G24[i];
+			UNR for (int i = 0; i < 3; i++) ip[i] += (tk->sig_p[3 * i] * e3[0] + tk->sig_p[3 * i + 1] * e3[1] + tk->sig_p[3 * i + 2] * e3[2]) * tk->dt;
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - tk->kp_pos[i] * e3[i] - tk->kv_pos[i] * (v[i] - G24[12 + i]) - tk->ki_pos[i] * ip[i];
+			UNR for (int i = 0; i < 3; i++) Fum[i] = tk->sig_p[3 * i] * tmp[0] + tk->sig_p[3 * i + 1] * tmp[1] + tk->sig_p[3 * i + 2] * tmp[2];
+			double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+			UNR for (int c = 0; c < 3; c++) {
+				const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
+				oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+				oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+				oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+			}
+			double dphi[3];
+			UNR for (int i = 0; i < 3; i++) dphi[i] = tk->sig_o[3 * i] * oe[0] + tk->sig_o[3 * i + 1] * oe[1] + tk->sig_o[3 * i + 2] * oe[2];
+			UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk->dt;
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
+			UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
 		}
-		double dphi[3];
-		UNR for (int i = 0; i < 3; i++) dphi[i] = tk->sig_o[3 * i] * oe[0] + tk->sig_o[3 * i + 1] * oe[1] + tk->sig_o[3 * i + 2] * oe[2];
-		UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk->dt;
-		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
-		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
 		if (track && live) {
 			UNR for (int i = 0; i < 3; i++) {
 				tk->integ[(size_t)i * ld + b] = ip[i];
 				tk->integ[(size_t)(3 + i) * ld + b] = io[i];
 			}
 		}
-		double fh[6];  // fhat = Bm^T F_um  (columns >= k of Bm are zero)
+		double fh[6], ff[6];  // fhat = Bm^T F_um, Bm^T F_f  (columns >= k of Bm are zero)
 		if (tk->bm_identity) {
-			UNR for (int a = 0; a < 6; a++) fh[a] = Fum[a];
+			UNR for (int a = 0; a < 6; a++) {
+				fh[a] = Fum[a];
+				ff[a] = Ff[a];
+			}
 		} else {
 			UNR for (int a = 0; a < 6; a++) {
-				double s = 0.0;
-				UNR for (int e = 0; e < 6; e++) s = fma(tk->Bm[e * 6 + a], Fum[e], s);
+				double s = 0.0, s2 = 0.0;
+				UNR for (int e = 0; e < 6; e++) {
+					s = fma(tk->Bm[e * 6 + a], Fum[e], s);
+					s2 = fma(tk->Bm[e * 6 + a], Ff[e], s2);
+				}
 				fh[a] = s;
+				ff[a] = s2;
 			}
 		}
-		UNR for (int a = 0; a < 6; a++) {  // g = Lambda_mod fhat  (SingularityHandler.cpp:307-309)
-			double s = 0.0;
+		UNR for (int a = 0; a < 6; a++) {  // g = Lambda_mod fhat + ffhat  (SingularityHandler.cpp:307-309)
+			double s = ff[a];
 			UNR for (int c = 0; c < 6; c++) s = fma(Lmod[a][c], fh[c], s);
 			g[a] = s;
 		}
@@ -591,7 +606,14 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
 				ie += e * tk->dt;  // :323-324
 				if (track && live) tk->integ[(size_t)i * ld + b] = ie;
-				const double fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : tk->goal[(size_t)(m + i) * ld + b])) - tk->ki[i] * ie;  // :342-345
+				double fi;
+				if (tk->vel_sat) {  // JointTask.cpp:327-341
+					double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;
+					vdes = fmin(fmax(vdes, -tk->sat[i]), tk->sat[i]);
+					fi = -tk->kv[i] * (vel - vdes);
+				} else {
+					fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : tk->goal[(size_t)(m + i) * ld + b])) - tk->ki[i] * ie;  // :342-345
+				}
 				const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : tk->goal[(size_t)(2 * m + i) * ld + b]) - sw;
 				UNR for (int c = 0; c < RJ; c++) {
 					a1[c] = fma(U[i][c], ai, a1[c]);

@@ -25,6 +25,7 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_law.h"
 #include "saip_wg_linalg.h"
 
 namespace saip {
@@ -41,8 +42,8 @@ struct WgSmem {
 	double body[NMAX * 10], comp[NMAX * 10];  // spatial inertia about the world origin: m, h(3)=m*c, Io(6: xx yy zz xy xz yz)
 	double Jw[6 * LD];
 	double q[NMAX], dq[NMAX], tau[NMAX], v0[NMAX], v1[NMAX], v2[NMAX], v3[NMAX], v4[NMAX], dv[NMAX];
-	double goal[3 * NMAX > 24 ? 3 * NMAX : 24];
-	double vw[6], Fum[6], xp[3], Rc[9];
+	double goal[3 * NMAX > 30 ? 3 * NMAX : 30];
+	double vw[6], Fum[6], Ff[6], xp[3], Rc[9];
 	double cs[4 * (NMAX / 2 + 1)];
 	int colidx[NMAX];
 	int flag, rank;
@@ -399,34 +400,15 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			const bool track = (tk.has_ki || P.integ_always);
 			if (tk.type == TASK_MOTION_FORCE) {
 				if (tid == 0) {
-					const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3
-					double v[3], w[3], e3[3], tmp[3], ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
-					mat3_mul_vec(tk.Ppos, sm.vw, v);
-					mat3_mul_vec(tk.Pori, sm.vw + 3, w);
+					const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3, f3, m3
+					double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
 					if (track)
 						for (int i = 0; i < 3; i++) {
 							ip[i] = tk.integ[(size_t)i * P.ld + b];
 							io[i] = tk.integ[(size_t)(3 + i) * P.ld + b];
 						}
-					for (int i = 0; i < 3; i++) e3[i] = sm.xp[i] - G[i];
-					mat3_mul_vec(tk.sig_p, e3, tmp);
-					for (int i = 0; i < 3; i++) ip[i] += tmp[i] * tk.dt;  // MotionForceTask.cpp:411-413
-					for (int i = 0; i < 3; i++) tmp[i] = G[18 + i] - tk.kp_pos[i] * e3[i] - tk.kv_pos[i] * (v[i] - G[12 + i]) - tk.ki_pos[i] * ip[i];
-					mat3_mul_vec(tk.sig_p, tmp, sm.Fum);  // :431-437
-					// orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
-					double oe[3] = {0, 0, 0};
-					const double* Rd = G + 3;
-					for (int c = 0; c < 3; c++) {
-						double a0 = sm.Rc[c], a1 = sm.Rc[3 + c], a2 = sm.Rc[6 + c], b0 = Rd[c], b1 = Rd[3 + c], b2 = Rd[6 + c];
-						oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
-						oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
-						oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
-					}
-					double dphi[3];
-					mat3_mul_vec(tk.sig_o, oe, dphi);  // :441-443
-					for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk.dt;  // :446
-					for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk.kp_ori[i] * dphi[i] - tk.kv_ori[i] * (w[i] - G[15 + i]) - tk.ki_ori[i] * io[i];
-					mat3_mul_vec(tk.sig_o, tmp, sm.Fum + 3);  // :463-468
+					// general law (velocity saturation, force/moment spaces) reduces to MotionForceTask.cpp:411-468 for the defaults
+					law_motion_force_general(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, sm.Fum, sm.Ff);
 					if (track)
 						for (int i = 0; i < 3; i++) {
 							tk.integ[(size_t)i * P.ld + b] = ip[i];
@@ -434,14 +416,18 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 						}
 				}
 				SYNC();
-				if (tid < r) {  // fhat = Bm^T F_um   (force-related terms are zero: sigma_force = sigma_moment = 0)
-					double s = 0.0;
-					for (int i = 0; i < 6; i++) s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
+				if (tid < r) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
+					double s = 0.0, s2 = 0.0;
+					for (int i = 0; i < 6; i++) {
+						s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
+						s2 = fma(tk.Bm[i * 6 + tid], sm.Ff[i], s2);
+					}
 					sm.v0[tid] = s;
+					sm.v1[tid] = s2;
 				}
 				SYNC();
-				if (tid < r) {  // g = Lambda_mod fhat   (SingularityHandler.cpp:307-309)
-					double s = 0.0;
+				if (tid < r) {  // g = Lambda_mod fhat + ffhat   (SingularityHandler.cpp:307-309)
+					double s = sm.v1[tid];
 					for (int i = 0; i < r; i++) s = fma(Lmod[tid * LD + i], sm.v0[i], s);
 					sm.v3[tid] = s;
 				}
@@ -465,7 +451,13 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					double ie = track ? tk.integ[(size_t)i * P.ld + b] : 0.0;
 					ie += e * tk.dt;  // JointTask.cpp:323-324
 					if (track) tk.integ[(size_t)i * P.ld + b] = ie;
-					sm.v0[i] = -tk.kp[i] * e - tk.kv[i] * (vel - sm.goal[m + i]) - tk.ki[i] * ie;  // :342-345
+					if (tk.vel_sat) {  // JointTask.cpp:327-341
+						double vdes = -tk.kp[i] * tk.kvinv[i] * e - tk.ki[i] * tk.kvinv[i] * ie;
+						vdes = fmin(fmax(vdes, -tk.sat[i]), tk.sat[i]);
+						sm.v0[i] = -tk.kv[i] * (vel - vdes);
+					} else {
+						sm.v0[i] = -tk.kp[i] * e - tk.kv[i] * (vel - sm.goal[m + i]) - tk.ki[i] * ie;  // :342-345
+					}
 				}
 				// w = Minv tau_prec
 				for (int i = tid; i < n; i += T) {
@@ -563,7 +555,9 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 	if (b >= P.B) return;
 	const ModelDev& md = *P.model;
 	const int n = P.n;
+	const int mask = P.reinit_mask;
 	for (int t = 0; t < P.nt; t++) {
+		if (P.reinit_task >= 0 && t != P.reinit_task) continue;
 		const TaskDev& tk = P.tasks[t];
 		if (tk.type == TASK_MOTION_FORCE) {
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
@@ -594,12 +588,26 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 			}
 			double p[3];
 			mat3_mul_vec(R, tk.pos, p);
-			for (int e = 0; e < 3; e++) tk.goal[(size_t)e * P.ld + b] = o[e] + p[e];
-			for (int r = 0; r < 3; r++)
-				for (int c = 0; c < 3; c++)
-					tk.goal[(size_t)(3 + 3 * r + c) * P.ld + b] = R[3 * r] * tk.rot[c] + R[3 * r + 1] * tk.rot[3 + c] + R[3 * r + 2] * tk.rot[6 + c];
-			for (int e = 12; e < 24; e++) tk.goal[(size_t)e * P.ld + b] = 0.0;
-			for (int e = 0; e < 6; e++) tk.integ[(size_t)e * P.ld + b] = 0.0;
+			if (mask & 1) {  // linear part: goal position := current, velocity/acceleration := 0, integrator := 0
+				for (int e = 0; e < 3; e++) {
+					tk.goal[(size_t)e * P.ld + b] = o[e] + p[e];
+					tk.goal[(size_t)(12 + e) * P.ld + b] = 0.0;
+					tk.goal[(size_t)(18 + e) * P.ld + b] = 0.0;
+					tk.integ[(size_t)e * P.ld + b] = 0.0;
+				}
+			}
+			if (mask & 2) {  // angular part
+				for (int r = 0; r < 3; r++)
+					for (int c = 0; c < 3; c++)
+						tk.goal[(size_t)(3 + 3 * r + c) * P.ld + b] = R[3 * r] * tk.rot[c] + R[3 * r + 1] * tk.rot[3 + c] + R[3 * r + 2] * tk.rot[6 + c];
+				for (int e = 0; e < 3; e++) {
+					tk.goal[(size_t)(15 + e) * P.ld + b] = 0.0;
+					tk.goal[(size_t)(21 + e) * P.ld + b] = 0.0;
+					tk.integ[(size_t)(3 + e) * P.ld + b] = 0.0;
+				}
+			}
+			if (mask & 4)  // goal force / moment (reInitializeTask, MotionForceTask.cpp:232-237)
+				for (int e = 24; e < 30; e++) tk.goal[(size_t)e * P.ld + b] = 0.0;
 		} else {
 			for (int i = 0; i < tk.m; i++) {
 				double cur = 0.0;

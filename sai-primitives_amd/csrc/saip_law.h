@@ -1,0 +1,125 @@
+// Task-space control laws shared by the cycle kernels (per-instance scalar code: one lane, or one thread of a workgroup).
+// MotionForceTask::computeTorques, /root/reference/src/tasks/MotionForceTask.cpp:286-509 with OTG off and open-loop force
+// control: sigma projectors (:892-971), open-loop force/moment damping + feed-forward (:350-354, :379-383, :471-487),
+// position / orientation PID with optional velocity saturation (:411-468).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace saip {
+
+#define LAW_UNR _Pragma("unroll")
+
+__device__ __forceinline__ void law_mat3_vec(const double* A, const double* v, double* o) {
+	o[0] = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+	o[1] = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+	o[2] = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+}
+
+// sigmaForce / sigmaMoment for space dimension `dim` (0..3) and unit axis `axis`, expressed through `rot` (:892-925, :932-966):
+// out = Pb * inner * Pb^T, inner = a a^T (dim 1) or I - a a^T (dim 2), a = rot * axis
+template <typename CP>
+__device__ __forceinline__ void law_sigma_space(CP Pb, const int dim, CP axis, const double* rot, double* out) {
+	if (dim == 0) {
+		LAW_UNR for (int i = 0; i < 9; i++) out[i] = 0.0;
+		return;
+	}
+	if (dim == 3) {
+		LAW_UNR for (int i = 0; i < 9; i++) out[i] = Pb[i];
+		return;
+	}
+	const double ax[3] = {axis[0], axis[1], axis[2]};
+	double a[3], in[9], T[9];
+	law_mat3_vec(rot, ax, a);
+	LAW_UNR for (int i = 0; i < 3; i++)
+		LAW_UNR for (int j = 0; j < 3; j++) in[3 * i + j] = (dim == 1) ? a[i] * a[j] : ((i == j) ? 1.0 : 0.0) - a[i] * a[j];
+	LAW_UNR for (int i = 0; i < 3; i++)
+		LAW_UNR for (int j = 0; j < 3; j++) T[3 * i + j] = Pb[3 * i] * in[j] + Pb[3 * i + 1] * in[3 + j] + Pb[3 * i + 2] * in[6 + j];
+	LAW_UNR for (int i = 0; i < 3; i++)
+		LAW_UNR for (int j = 0; j < 3; j++) out[3 * i + j] = T[3 * i] * Pb[3 * j] + T[3 * i + 1] * Pb[3 * j + 1] + T[3 * i + 2] * Pb[3 * j + 2];
+}
+
+// General motion-force law.  tk: task constants (any address space); vw = Jw dq (unprojected world twist of the control point);
+// xp, Rc: control point / control frame; G: goal block (30: x3 R9 v3 w3 a3 alpha3 f3 m3); ip, io: integrators (in/out).
+// Outputs F_um (unit-mass force, acts through Lambda_mod) and F_f (force-related terms, act directly).
+template <typename TK>
+__device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw, const double* xp, const double* Rc, const double* G,
+														 double* ip, double* io, double* Fum, double* Ff) {
+	const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	const double* rot = tk->param_in_compliant_frame ? Rc : I3;
+	double sig_f[9], sig_m[9], sig_p[9], sig_o[9], T[9], ImS[9];
+	law_sigma_space(tk->Ppos, tk->force_dim, tk->force_axis, rot, sig_f);
+	law_sigma_space(tk->Pori, tk->moment_dim, tk->moment_axis, rot, sig_m);
+	LAW_UNR for (int pass = 0; pass < 2; pass++) {  // sigmaPosition = Ppos (I - sigmaForce) Ppos^T, same for orientation (:927-930, :968-971)
+		const double* sg = pass ? sig_m : sig_f;
+		double* so = pass ? sig_o : sig_p;
+		LAW_UNR for (int i = 0; i < 9; i++) ImS[i] = ((i % 4) == 0 ? 1.0 : 0.0) - sg[i];
+		LAW_UNR for (int i = 0; i < 3; i++)
+			LAW_UNR for (int j = 0; j < 3; j++) {
+				const double p0 = pass ? tk->Pori[3 * i] : tk->Ppos[3 * i], p1 = pass ? tk->Pori[3 * i + 1] : tk->Ppos[3 * i + 1],
+							 p2 = pass ? tk->Pori[3 * i + 2] : tk->Ppos[3 * i + 2];
+				T[3 * i + j] = p0 * ImS[j] + p1 * ImS[3 + j] + p2 * ImS[6 + j];
+			}
+		LAW_UNR for (int i = 0; i < 3; i++)
+			LAW_UNR for (int j = 0; j < 3; j++) {
+				const double p0 = pass ? tk->Pori[3 * j] : tk->Ppos[3 * j], p1 = pass ? tk->Pori[3 * j + 1] : tk->Ppos[3 * j + 1],
+							 p2 = pass ? tk->Pori[3 * j + 2] : tk->Ppos[3 * j + 2];
+				so[3 * i + j] = T[3 * i] * p0 + T[3 * i + 1] * p1 + T[3 * i + 2] * p2;
+			}
+	}
+	double v[3], w[3], tmp[3], e3[3], gf[3], gm[3];
+	LAW_UNR for (int i = 0; i < 3; i++) {
+		v[i] = tk->Ppos[3 * i] * vw[0] + tk->Ppos[3 * i + 1] * vw[1] + tk->Ppos[3 * i + 2] * vw[2];  // J = P Jw (:293-298)
+		w[i] = tk->Pori[3 * i] * vw[3] + tk->Pori[3 * i + 1] * vw[4] + tk->Pori[3 * i + 2] * vw[5];
+	}
+	law_mat3_vec(rot, G + 24, gf);  // getGoalForce / getGoalMoment (:755-769)
+	law_mat3_vec(rot, G + 27, gm);
+	// open-loop force / moment terms + feed-forward (:350-354, :379-383, :471-487; no kff scaling in open loop)
+	LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gf[i] - tk->kv_force * v[i];
+	law_mat3_vec(sig_f, tmp, Ff);
+	LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gm[i] - tk->kv_moment * w[i];
+	law_mat3_vec(sig_m, tmp, Ff + 3);
+	// linear motion (:411-437)
+	double se[3];
+	LAW_UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G[i];
+	law_mat3_vec(sig_p, e3, se);
+	LAW_UNR for (int i = 0; i < 3; i++) ip[i] += se[i] * tk->dt;
+	if (tk->vel_sat) {
+		double vdes[3], nrm = 0.0;
+		LAW_UNR for (int i = 0; i < 3; i++) {
+			vdes[i] = -tk->kp_pos[i] * tk->kvinv_pos[i] * se[i] - tk->ki_pos[i] * tk->kvinv_pos[i] * ip[i];
+			nrm += vdes[i] * vdes[i];
+		}
+		nrm = sqrt(nrm);
+		const double sc = (nrm > tk->lin_sat) ? tk->lin_sat / nrm : 1.0;
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = G[18 + i] - tk->kv_pos[i] * (v[i] - sc * vdes[i]);
+	} else {
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = G[18 + i] - tk->kp_pos[i] * e3[i] - tk->kv_pos[i] * (v[i] - G[12 + i]) - tk->ki_pos[i] * ip[i];
+	}
+	law_mat3_vec(sig_p, tmp, Fum);
+	// angular motion (:441-468); orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+	double oe[3] = {0, 0, 0}, dphi[3];
+	LAW_UNR for (int c = 0; c < 3; c++) {
+		const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G[3 + c], b1 = G[6 + c], b2 = G[9 + c];
+		oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+		oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+		oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+	}
+	law_mat3_vec(sig_o, oe, dphi);
+	LAW_UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk->dt;
+	if (tk->vel_sat) {
+		double wdes[3], nrm = 0.0;
+		LAW_UNR for (int i = 0; i < 3; i++) {
+			wdes[i] = -tk->kp_ori[i] * tk->kvinv_ori[i] * dphi[i] - tk->ki_ori[i] * tk->kvinv_ori[i] * io[i];
+			nrm += wdes[i] * wdes[i];
+		}
+		nrm = sqrt(nrm);
+		const double sc = (nrm > tk->ang_sat) ? tk->ang_sat / nrm : 1.0;
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk->kv_ori[i] * (w[i] - sc * wdes[i]);
+	} else {
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G[15 + i]) - tk->ki_ori[i] * io[i];
+	}
+	law_mat3_vec(sig_o, tmp, Fum + 3);
+}
+
+}  // namespace saip

@@ -25,6 +25,8 @@ SCENARIOS = {
     "cfg7_ori_only_full_decoupling": (7, 32, {}),
     "cfg8_planar_impedance": (8, 32, {}),
     "cfg2_gravity_saturation": (2, 32, dict(gravity_comp=True, torque_saturation=True)),
+    "cfg9_hybrid_force_velsat": (9, 32, {}),
+    "cfg10_full_force_space": (10, 32, {}),
 }
 
 

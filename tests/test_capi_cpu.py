@@ -93,8 +93,26 @@ def test_task_constructor_validation(sp):
         t.setPosControlGains(-1.0, 1.0, 0.0)
     with pytest.raises(ValueError, match="size 1 or 3"):
         t.setPosControlGains([1.0, 2.0], [1.0, 2.0], [0.0, 0.0])
-    with pytest.raises(sp.SaipUnsupported):
-        t.enableVelocitySaturation()
+    t.enableVelocitySaturation()            # defaults 0.3, pi/3 (MotionForceTask.h:63-64)
+    t.enableVelocitySaturation(0.1, 0.5)
+    with pytest.raises(ValueError, match="strictly positive"):
+        t.enableVelocitySaturation(0.0, 0.5)
+    with pytest.raises(ValueError, match="between 0 and 3"):
+        t.parametrizeForceMotionSpaces(4, [0, 0, 1])
+    with pytest.raises(ValueError, match="non singular vector"):
+        t.parametrizeMomentRotMotionSpaces(1, [0, 0, 1e-3])
+    assert t.parametrizeForceMotionSpaces(2, [1, 0, 0]) is True and t.parametrizeForceMotionSpaces(2, [3, 0, 0]) is False
+    with pytest.raises(sp.SaipUnsupported, match="closed-loop"):
+        t.setClosedLoopForceControl(True)
+    r2 = _cfg_only(sp)
+    j2 = sp.JointTask(r2)
+    sp.RobotController(r2, [j2])
+    j2.enableVelocitySaturation(0.5)
+    j2.enableVelocitySaturation(np.full(7, 0.5))
+    with pytest.raises(ValueError, match="not consistent with task dof"):
+        j2.enableVelocitySaturation(np.full(3, 0.5))
+    with pytest.raises(ValueError, match="must be positive"):
+        j2.enableVelocitySaturation(-1.0)
 
 
 @pytest.mark.parametrize("cfg", [3, 7, 8])

@@ -50,7 +50,7 @@ def test_engine_matches_golden(path):
     assert err < TOL
 
 
-@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 4096), (5, 512), (6, 256)])
+@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 4096), (5, 512), (6, 256), (9, 1024), (10, 1024)])
 def test_engine_matches_oracle_full_size(cfg, B):
     from oracle import Oracle
     d = W.make_inputs(cfg, B)
@@ -169,3 +169,31 @@ def test_call_order_and_otg_are_loud():
     tasks[0].disableInternalOtg()
     ctrl.setGoals(d["goals"])
     assert np.isfinite(ctrl.computeControlTorques()).all()
+
+
+def test_force_space_reparametrisation_resets_linear_goal():
+    """parametrizeForceMotionSpaces returns whether it changed and, if so, snaps the linear goal to the current position
+    and clears the integrators (MotionForceTask.cpp:828-856); the angular goal is untouched."""
+    d = W.make_inputs(2, 64)
+    robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], 64)
+    _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    ori_before = tasks[0].getGoalOrientation()
+    assert tasks[0].parametrizeForceMotionSpaces(1, [0, 0, 1]) is True
+    assert tasks[0].parametrizeForceMotionSpaces(1, [0, 0, 2]) is False     # same normalised axis
+    model = d["model"]
+    fr = W.fk(model, d["q"])
+    li = model.link_index("end-effector")
+    p = fr[li][1] + fr[li][0] @ np.array([0, 0, 0.07])
+    assert np.abs(tasks[0].getGoalPosition() - p).max() < 1e-12
+    assert np.array_equal(tasks[0].getGoalOrientation(), ori_before)
+    # and the cycle now matches the oracle configured the same way, with the reset goals
+    from oracle import Oracle
+    spec = W.config_tasks(2)
+    spec[0].update(force_dim=1, force_axis=[0, 0, 1])
+    goals = [np.concatenate([tasks[0]._get_goal()], axis=1), d["goals"][1]]
+    tasks[0].setGoalForce(np.tile([1.0, -2.0, 3.0], (64, 1)))
+    goals[0][:, 24:27] = [1.0, -2.0, 3.0]
+    ctrl.updateControllerTaskModels()
+    tau = ctrl.computeControlTorques()
+    ref, _ = Oracle(model, spec).step(d["q"], d["dq"], goals)
+    assert W.torque_error(tau, ref) < TOL

@@ -248,7 +248,11 @@ def motion_force_task(name, link, pos_in_link=(0, 0, 0), rot_in_link=None, dirs_
              dirs_trans=dirs_trans, dirs_rot=dirs_rot,
              kp_pos=100.0, kv_pos=20.0, ki_pos=0.0, kp_ori=200.0, kv_ori=28.3, ki_ori=0.0,
              decoupling=BOUNDED_INERTIA_ESTIMATES, bie_threshold=0.1, s_min=6e-3, s_max=6e-2,
-             dt=0.001)
+             dt=0.001,
+             # MotionForceTask.h:50-66: force/moment gains (only kv acts in open loop), velocity saturation, force spaces
+             kv_force=10.0, kv_moment=10.0, vel_sat=False, lin_sat=0.3, ang_sat=np.pi / 3,
+             force_dim=0, force_axis=[0.0, 0.0, 1.0], moment_dim=0, moment_axis=[0.0, 0.0, 1.0],
+             param_in_compliant_frame=False)
     t.update(kw)
     return t
 
@@ -256,7 +260,8 @@ def motion_force_task(name, link, pos_in_link=(0, 0, 0), rot_in_link=None, dirs_
 def joint_task(name, S=None, **kw):
     """Task spec; defaults = JointTask.h:31-45 with OTG disabled. S = list of rows or None."""
     t = dict(type="joint", name=name, S=S, kp=50.0, kv=14.0, ki=0.0,
-             decoupling=BOUNDED_INERTIA_ESTIMATES, bie_threshold=0.1, dt=0.001)
+             decoupling=BOUNDED_INERTIA_ESTIMATES, bie_threshold=0.1, dt=0.001,
+             vel_sat=False, sat=np.pi / 3)  # JointTask.h:43-44
     t.update(kw)
     return t
 
@@ -301,8 +306,28 @@ def joint_selection(task, n):
 
 def goal_size(task, n):
     if task["type"] == "motion_force":
-        return 24  # x3, R9 (row-major), v3, w3, a3, alpha3
+        # x3, R9 (row-major), v3, w3, a3, alpha3 [, goal force 3, goal moment 3 when a force/moment space is active]
+        return 30 if (task.get("force_dim", 0) or task.get("moment_dim", 0)) else 24
     return 3 * joint_selection(task, n).shape[0]
+
+
+def pinv_diag(k, tol=1e-6):
+    """SaiModel::computePseudoInverse of a diagonal gain matrix (entries below tol are dropped)"""
+    k = np.atleast_1d(np.asarray(k, float))
+    return np.array([1.0 / x if abs(x) > tol else 0.0 for x in k])
+
+
+def sigma_space(Pblock, dim, axis, rotation):
+    """sigmaForce / sigmaMoment, MotionForceTask.cpp:892-925, 932-966"""
+    if dim == 0:
+        return np.zeros((3, 3))
+    if dim == 3:
+        return Pblock.copy()
+    a = np.asarray(axis, float)
+    a = rotation @ (a / np.linalg.norm(a))
+    aa = np.outer(a, a)
+    inner = aa if dim == 1 else np.eye(3) - aa
+    return Pblock @ inner @ Pblock.T
 
 
 # --------------------------------------------------- literal single-instance controller
@@ -386,21 +411,43 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             J, P = m["J"], m["P"]
             v = J[:3] @ dq                                           # MotionForceTask.cpp:293-298
             w = J[3:] @ dq
-            sig_p = P[:3, :3] @ np.eye(3) @ P[:3, :3].T              # :927-930 (sigma_force = 0)
-            sig_o = P[3:, 3:] @ np.eye(3) @ P[3:, 3:].T
+            Rcur = m["R"]
+            rot = Rcur if t["param_in_compliant_frame"] else np.eye(3)   # :894-897, 934-937, 755-769
+            sig_f = sigma_space(P[:3, :3], t["force_dim"], t["force_axis"], rot)
+            sig_m = sigma_space(P[3:, 3:], t["moment_dim"], t["moment_axis"], rot)
+            sig_p = P[:3, :3] @ (np.eye(3) - sig_f) @ P[:3, :3].T    # :927-930
+            sig_o = P[3:, 3:] @ (np.eye(3) - sig_m) @ P[3:, 3:].T    # :968-971
+            goal_force = rot @ (g[24:27] if g.size >= 30 else np.zeros(3))
+            goal_moment = rot @ (g[27:30] if g.size >= 30 else np.zeros(3))
             kp, kv, ki = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_pos", "kv_pos", "ki_pos"))
             kpo, kvo, kio = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_ori", "kv_ori", "ki_ori"))
+            F_force = sig_f @ (-t["kv_force"] * v)                   # open loop, :350-354
+            F_moment = sig_m @ (-t["kv_moment"] * w)                 # :379-383
             ipos = np.zeros(3) if st is None else st["int_pos"]
             iori = np.zeros(3) if st is None else st["int_ori"]
             ipos = ipos + sig_p @ (m["x"] - xd) * t["dt"]             # :411-413
-            F_p = sig_p @ (ad - kp @ (m["x"] - xd) - kv @ (v - vd) - ki @ ipos)   # :431-437
-            dphi = sig_o @ orientation_error(Rd, m["R"])             # :441-443
+            if t["vel_sat"]:                                         # :416-430
+                kvi = np.diag(pinv_diag(np.diag(kv)))
+                vdes = -kp @ kvi @ sig_p @ (m["x"] - xd) - ki @ kvi @ ipos
+                if np.linalg.norm(vdes) > t["lin_sat"]:
+                    vdes = vdes * t["lin_sat"] / np.linalg.norm(vdes)
+                F_p = sig_p @ (ad - kv @ (v - vdes))
+            else:
+                F_p = sig_p @ (ad - kp @ (m["x"] - xd) - kv @ (v - vd) - ki @ ipos)   # :431-437
+            dphi = sig_o @ orientation_error(Rd, Rcur)               # :441-443
             iori = iori + dphi * t["dt"]                             # :446
-            F_o = sig_o @ (ald - kpo @ dphi - kvo @ (w - wd) - kio @ iori)        # :463-468
+            if t["vel_sat"]:                                         # :449-462
+                kvi = np.diag(pinv_diag(np.diag(kvo)))
+                wdes = -kpo @ kvi @ dphi - kio @ kvi @ iori
+                if np.linalg.norm(wdes) > t["ang_sat"]:
+                    wdes = wdes * t["ang_sat"] / np.linalg.norm(wdes)
+                F_o = sig_o @ (ald - kvo @ (w - wdes))
+            else:
+                F_o = sig_o @ (ald - kpo @ dphi - kvo @ (w - wd) - kio @ iori)        # :463-468
             if st is not None:
                 st["int_pos"], st["int_ori"] = ipos, iori
-            F_um = np.concatenate([F_p, F_o])
-            F_f = np.zeros(6)                                        # sigma_force = sigma_moment = 0
+            F_um = np.concatenate([F_p, F_o])                        # :475-478
+            F_f = np.concatenate([F_force + sig_f @ goal_force, F_moment + sig_m @ goal_moment])   # :471-487 (open loop: no kff)
             tt = m["J_ns"].T @ (m["Lam_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)  # SH.cpp:307-309
             # computeTorques(tau_prec): _Lambda is never written => compensation == 0 (App. C-1)
             tau = tau + tt
@@ -420,7 +467,13 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             ie = ie + e * t["dt"]                                    # JointTask.cpp:323-324
             if st is not None:
                 st["int_err"] = ie
-            f = -kp @ e - kv @ (S @ dq - dqd) - ki @ ie              # :342-345
+            if t["vel_sat"]:                                         # :327-341 (clamp applied to the task dofs)
+                kvi = np.diag(pinv_diag(np.diag(kv)))
+                sat = np.broadcast_to(np.asarray(t["sat"], float), (mm,))
+                vdes = np.clip(-kp @ kvi @ e - ki @ kvi @ ie, -sat, sat)
+                f = -kv @ (S @ dq - vdes)
+            else:
+                f = -kp @ e - kv @ (S @ dq - dqd) - ki @ ie          # :342-345
             tr = m["Lam"] @ U.T @ ddqd + m["Lam_mod"] @ U.T @ f      # :348-351
             tt = Jp.T @ U @ tr                                       # :354-355
             comp = Jp.T @ U @ m["Lam"] @ U.T @ S @ Minv @ tau        # :287-291
@@ -472,6 +525,9 @@ CONFIGS = {
     6: dict(robot="panda_sliding_base", batch=256, desc="8-DoF sliding-base Panda, partial JointTask {0,7} above a full MotionForceTask (examples/06)"),
     7: dict(robot="panda_arm", batch=256, desc="Panda, orientation-only MotionForceTask (examples/09 style) + full JointTask, anisotropic gains, FULL_DYNAMIC_DECOUPLING"),
     8: dict(robot="panda_arm", batch=256, desc="Panda, planar (2 translation + 1 rotation dirs, non axis-aligned) MotionForceTask + JointTask, IMPEDANCE"),
+    9: dict(robot="panda_arm", batch=256, desc="Panda, hybrid motion/force: force space dim 1 (compliant-frame axis) + moment space dim 2, open-loop force "
+            "control with goal force/moment, velocity saturation on both tasks (examples/07-09 style)"),
+    10: dict(robot="panda_arm", batch=256, desc="Panda, full force space (dim 3) + motion-only rotation, world-frame parametrisation, joint velocity saturation"),
 }
 
 
@@ -504,6 +560,14 @@ def config_tasks(cfg: int):
                                   dirs_trans=[[1, 1, 0], [0, 0, 1], [2, 2, 1]], dirs_rot=[[1, -1, 0.5]],
                                   decoupling=IMPEDANCE),
                 joint_task("joint_task", decoupling=IMPEDANCE)]
+    if cfg == 9:
+        return [motion_force_task("hybrid_task", "end-effector", (0, 0, 0.07), force_dim=1, force_axis=[0.1, -0.2, 1.0],
+                                  moment_dim=2, moment_axis=[0.0, 1.0, 0.3], param_in_compliant_frame=True, vel_sat=True,
+                                  lin_sat=0.02, ang_sat=0.1, kv_force=12.0, kv_moment=8.0, ki_pos=3.0, ki_ori=2.0),
+                joint_task("joint_task", vel_sat=True, sat=0.15, ki=1.5)]
+    if cfg == 10:
+        return [motion_force_task("force_task", "end-effector", (0, 0, 0.07), force_dim=3, moment_dim=0),
+                joint_task("joint_task", vel_sat=True, sat=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])]
     raise ValueError(cfg)
 
 
@@ -583,7 +647,10 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
             wg = rng.uniform_range(-0.1, 0.1, 3)
             ag = rng.uniform_range(-0.5, 0.5, 3)
             alg = rng.uniform_range(-0.5, 0.5, 3)
-            goals.append(np.concatenate([xg, Rg.reshape(B, 9), vg, wg, ag, alg], axis=1))
+            blocks = [xg, Rg.reshape(B, 9), vg, wg, ag, alg]
+            if goal_size(t, n) == 30:
+                blocks += [rng.uniform_range(-5.0, 5.0, 3), rng.uniform_range(-1.0, 1.0, 3)]  # goal force, goal moment
+            goals.append(np.concatenate(blocks, axis=1))
         else:
             S = joint_selection(t, n)
             m = S.shape[0]
