@@ -16,6 +16,7 @@
 // Errors: std::invalid_argument where the reference throws it; std::runtime_error for device / unsupported / order errors.
 // Every array is struct-of-arrays, component-major: value of component c for instance b at [c * B + b].
 #pragma once
+#include <cmath>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -97,7 +98,6 @@ public:
 	void disableInternalOtg() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 0); }); }
 	void enableInternalOtgAccelerationLimited() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 1); }); }
 	void disableVelocitySaturation() { cfg([](saip_batch* b, int id) { return saip_batch_set_velocity_saturation(b, id, 0); }); }
-	void enableVelocitySaturation() { cfg([](saip_batch* b, int id) { return saip_batch_set_velocity_saturation(b, id, 1); }); }
 	// (B x dof x dof as [dof*dof][B]) nullspace projector of this task for the current state, TemplateTask.h:71-77
 	std::vector<double> getTaskNullspace() {
 		need();
@@ -160,6 +160,33 @@ public:
 	void setPosControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_pos_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void setSingularityHandlingBounds(double s_min, double s_max) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_bounds(b, id, s_min, s_max); }); }
+	// MotionForceTask::enableVelocitySaturation(linear, angular), MotionForceTask.cpp:771-792
+	void enableVelocitySaturation(double linear_vel_sat = 0.3, double angular_vel_sat = M_PI / 3) {
+		cfg([=](saip_batch* b, int id) {
+			const double v[2] = {linear_vel_sat, angular_vel_sat};
+			saip_status st = saip_batch_set_saturation_velocities(b, id, v, 2);
+			return st ? st : saip_batch_set_velocity_saturation(b, id, 1);
+		});
+	}
+	// hybrid motion/force control, MotionForceTask.h:560-600 (open-loop force control; closed loop is refused)
+	void parametrizeForceMotionSpaces(int force_space_dimension, double ax = 0, double ay = 0, double az = 0) {
+		cfg([=](saip_batch* b, int id) {
+			const double a[3] = {ax, ay, az};
+			return saip_batch_parametrize_force_motion_spaces(b, id, force_space_dimension, a, nullptr);
+		});
+	}
+	void parametrizeMomentRotMotionSpaces(int moment_space_dimension, double ax = 0, double ay = 0, double az = 0) {
+		cfg([=](saip_batch* b, int id) {
+			const double a[3] = {ax, ay, az};
+			return saip_batch_parametrize_moment_rot_motion_spaces(b, id, moment_space_dimension, a, nullptr);
+		});
+	}
+	void setGoalForce(const std::vector<double>& f) { setField(24, 3, f, "setGoalForce: expected [3][B]"); }
+	void setGoalMoment(const std::vector<double>& m) { setField(27, 3, m, "setGoalMoment: expected [3][B]"); }
+	void setForceControlGains(double kp, double kv, double ki) { cfg([=](saip_batch* b, int id) { return saip_batch_set_force_control_gains(b, id, kp, kv, ki); }); }
+	void setMomentControlGains(double kp, double kv, double ki) { cfg([=](saip_batch* b, int id) { return saip_batch_set_moment_control_gains(b, id, kp, kv, ki); }); }
+	void setClosedLoopForceControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_force_control(b, id, e); }); }
+	void setClosedLoopMomentControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_moment_control(b, id, e); }); }
 
 protected:
 	saip_status add(saip_batch* b, int* id) override {
@@ -190,6 +217,12 @@ public:
 	void setGoalVelocity(const std::vector<double>& dq) { setField(getTaskDof(), getTaskDof(), dq, "goal velocity vector size not consistent with task dof in JointTask::setGoalVelocity\n"); }
 	void setGoalAcceleration(const std::vector<double>& ddq) { setField(2 * getTaskDof(), getTaskDof(), ddq, "goal acceleration vector size not consistent with task dof in JointTask::setGoalAcceleration\n"); }
 	void setGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_joint_gains(b, id, &kp, &kv, &ki, 1); }); }
+	void enableVelocitySaturation(double saturation_velocity = M_PI / 3.0) {  // JointTask.cpp:410-421
+		cfg([=](saip_batch* b, int id) {
+			saip_status st = saip_batch_set_saturation_velocities(b, id, &saturation_velocity, 1);
+			return st ? st : saip_batch_set_velocity_saturation(b, id, 1);
+		});
+	}
 
 protected:
 	saip_status add(saip_batch* b, int* id) override {

@@ -931,6 +931,10 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	}
 	P.reinit_task = -1;
 	P.reinit_mask = 7;
+	P.lane_general = 0;
+	P.pad3_ = 0;
+	for (auto& T : b->tasks)
+		if (T.dev.general_law) P.lane_general = 1;
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
 						  b->tasks[1].dev.m == P.n && !b->tasks[0].dev.general_law) ? 1 : 0;
 	{

@@ -204,7 +204,7 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 	}
 }
 
-template <int N, bool PF, typename SMT>
+template <int N, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
@@ -377,8 +377,8 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 				io[i] = tk->integ[(size_t)(3 + i) * ld + b];
 			}
 		}
-		if (tk->general_law) {
-			// velocity saturation and/or force & moment spaces (open-loop force control)
+		if (GL) {
+			// velocity saturation and/or force & moment spaces (open-loop force control); reduces to the short law for the defaults
 			UNR for (int e = 24; e < 30; e++) G24[e] = tk->goal[(size_t)e * ld + b];
 			law_motion_force_general(tk, vw, xp, Rc, G24, ip, io, Fum, Ff);
 		} else {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 	PHASE_FENCE();
 }
 
-template <int N, int RJ, bool PF, typename SMT>
+template <int N, int RJ, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
@@ -607,7 +607,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				ie += e * tk->dt;  // :323-324
 				if (track && live) tk->integ[(size_t)i * ld + b] = ie;
 				double fi;
-				if (tk->vel_sat) {  // JointTask.cpp:327-341
+				if (GL && tk->vel_sat) {  // JointTask.cpp:327-341
 					double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;
 					vdes = fmin(fmax(vdes, -tk->sat[i]), tk->sat[i]);
 					fi = -tk->kv[i] * (vel - vdes);
@@ -632,7 +632,8 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 
 enum { SIG_GENERIC = 0, SIG_MF_JT = 1 };
 
-template <int N, int RJ, int SIG, bool PF, bool LEAN>
+// GL: general control laws (velocity saturation, force/moment spaces) compiled in; GL = false keeps the default-law fast path lean
+template <int N, int RJ, int SIG, bool PF, bool LEAN, bool GL>
 __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	static_assert(!PF || SIG == SIG_MF_JT, "the prefetch layout is defined for the MotionForce+Joint stack");
 	using SM = LaneSmem<N, PF, LEAN>;
@@ -855,14 +856,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 
 	if (SIG == SIG_MF_JT) {
 		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
-		lane_motion_force_task<N, PF, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
+		lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
 		PHASE_FENCE();
-		lane_joint_task<N, RJ, PF, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
+		lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
 	} else {
 		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 			const bool last = (t == P.nt - 1);
-			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
-			else lane_joint_task<N, RJ, PF, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			else lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
 			first = false;
 		}
 	}
@@ -907,18 +908,21 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	static const char* lean_env = getenv("SAIP_LANE_LEAN");  // "0"/"1" forces the choice (profiling)
 	const bool lean = lean_env ? (lean_env[0] == '1') : (P.B > 64 * 256 * 2);
 	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
-#define LAUNCH(NN, RR, SS, PP) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false>), grid, block, 0, stream, P)
-	if (P.n == 7 && inst == 1 && mf_jt && lean) hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true>), grid, block, 0, stream, P);
-	else if (P.n == 7 && inst == 1 && mf_jt && pf) LAUNCH(7, 1, SIG_MF_JT, true);
-	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false);
+#define LAUNCH(NN, RR, SS, PP, GG) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false, GG>), grid, block, 0, stream, P)
+	const bool gl = P.lane_general != 0;
+	if (P.n == 7 && inst == 1 && mf_jt && !gl && lean) hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true, false>), grid, block, 0, stream, P);
+	else if (P.n == 7 && inst == 1 && mf_jt && !gl && pf) LAUNCH(7, 1, SIG_MF_JT, true, false);
+	else if (P.n == 7 && inst == 1 && mf_jt && !gl) LAUNCH(7, 1, SIG_MF_JT, false, false);
 #ifndef SAIP_LANE_ONLY_71
-	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC, false);
-	else if (P.n == 7 && inst == 4 && mf_jt) LAUNCH(7, 4, SIG_MF_JT, false);
-	else if (P.n == 7 && inst == 4) LAUNCH(7, 4, SIG_GENERIC, false);
-	else if (P.n == 7) LAUNCH(7, 7, SIG_GENERIC, false);
-	else if (P.n == 8 && inst == 2) LAUNCH(8, 2, SIG_GENERIC, false);
-	else if (P.n == 8) LAUNCH(8, 8, SIG_GENERIC, false);
-	else LAUNCH(6, 6, SIG_GENERIC, false);
+	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false, true);
+	else if (P.n == 7 && inst == 1) LAUNCH(7, 1, SIG_GENERIC, false, true);
+	else if (P.n == 7 && inst == 4 && mf_jt && !gl) LAUNCH(7, 4, SIG_MF_JT, false, false);
+	else if (P.n == 7 && inst == 4 && mf_jt) LAUNCH(7, 4, SIG_MF_JT, false, true);
+	else if (P.n == 7 && inst == 4) LAUNCH(7, 4, SIG_GENERIC, false, true);
+	else if (P.n == 7) LAUNCH(7, 7, SIG_GENERIC, false, true);
+	else if (P.n == 8 && inst == 2) LAUNCH(8, 2, SIG_GENERIC, false, true);
+	else if (P.n == 8) LAUNCH(8, 8, SIG_GENERIC, false, true);
+	else LAUNCH(6, 6, SIG_GENERIC, false, true);
 #else
 	else { *supported = false; return hipSuccess; }
 #endif
