@@ -288,14 +288,62 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			// singular values of the projected Jacobian: eig(Jh Jh^T) = sigma^2   (SingularityHandler.cpp:78-121)
 			gemm<T>(sm.W[1], LD, Jh, LD, 1, Jh, 1, LD, k, n, k, tid);
 			SYNC();
-			jacobi_eig<T>(sm.W[1], nullptr, k, LD, sm.cs, &sm.flag, tid);
-			double lmax = 0.0;
-			for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
-			double s0 = sqrt(lmax);
-			bool sing = (s0 < tk.s_abs_tol);
-			for (int i = 0; i < k; i++) {
-				double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
-				if (si / s0 < tk.s_max) sing = true;
+			// fast path: certify "sigma_i/sigma_0 >= s_max for all i and sigma_0 >= s_abs_tol" without an eigen-solve
+			// (trace-power bound lambda_max <= ||Gs^8||_F^(1/8) + LDL^T pivots of Gs - s_max^2 u I; see saip_kernel_lane.hip)
+			bool sing = false;
+			{
+				double tr = 0.0;
+				for (int i = 0; i < k; i++) tr += sm.W[1][i * LD + i];
+				const double itr = 1.0 / tr;
+				double* Ga = sm.W[5];
+				double* Gb = sm.W[6];
+				for (int e = tid; e < k * k; e += T) {
+					int i = e / k, j = e - i * k;
+					Ga[i * LD + j] = sm.W[1][i * LD + j] * itr;
+				}
+				SYNC();
+				for (int rep = 0; rep < 3; rep++) {
+					gemm<T>(Gb, LD, Ga, LD, 1, Ga, LD, 1, k, k, k, tid);
+					SYNC();
+					double* t_ = Ga;
+					Ga = Gb;
+					Gb = t_;
+				}
+				double t16 = 0.0;
+				for (int i = 0; i < k; i++)
+					for (int j = 0; j < k; j++) t16 = fma(Ga[i * LD + j], Ga[i * LD + j], t16);
+				const double u = sqrt(sqrt(sqrt(sqrt(t16))));
+				const bool ok_s0 = (u * tk.cert_kroot * tr >= tk.s_abs_tol * tk.s_abs_tol);
+				if (tid == 0) {  // LDL^T of Gs - shift I, in place in Gb (k <= 6: serial)
+					const double shift = tk.s_max * tk.s_max * u;
+					for (int i = 0; i < k; i++)
+						for (int j = 0; j <= i; j++) Gb[i * LD + j] = sm.W[1][i * LD + j] * itr - (i == j ? shift : 0.0);
+					int pos = 1;
+					for (int kk = 0; kk < k; kk++) {
+						const double d = Gb[kk * LD + kk];
+						if (!(d > 1e-13)) pos = 0;
+						const double id = 1.0 / d;
+						for (int i = kk + 1; i < k; i++) {
+							const double lik = Gb[i * LD + kk] * id;
+							for (int j = kk + 1; j <= i; j++) Gb[i * LD + j] = fma(-lik, Gb[j * LD + kk], Gb[i * LD + j]);
+						}
+					}
+					sm.flag = (pos && ok_s0 && tr > 0.0) ? 1 : 0;
+				}
+				SYNC();
+				const bool certified = sm.flag != 0;
+				SYNC();
+				if (!certified) {  // exact path: singular values from the Gram eigenvalues (SingularityHandler.cpp:78-121)
+					jacobi_eig<T>(sm.W[1], nullptr, k, LD, sm.cs, &sm.flag, tid);
+					double lmax = 0.0;
+					for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
+					double s0 = sqrt(lmax);
+					sing = !(s0 >= tk.s_abs_tol);
+					for (int i = 0; i < k; i++) {
+						double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
+						if (si / s0 < tk.s_max) sing = true;
+					}
+				}
 			}
 			if (sing) singular = true;
 			r = k;
@@ -309,7 +357,74 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				Jp = sm.W[0];
 				SYNC();
 			}
-			// matrixRangeBasis(Jp): eigen-decomposition of the Gram matrix Jp Jp^T (m x m)
+			// matrixRangeBasis(Jp) (JointTask.cpp:233).  Fast path: column-pivoted Gram-Schmidt in LDS with a clean-gap
+			// acceptance rule (next pivot below 1e-10 or above 1e-2 of the first); the deflation coefficients are the rows of U^T Jp.
+			bool need_exact = false;
+			{
+				double* Wc = sm.W[5];
+				const int rb = P.rank_bound[t] < m ? P.rank_bound[t] : m;
+				for (int e = tid; e < m * n; e += T) {
+					int i = e / n, j = e - i * n;
+					Wc[i * LD + j] = Jp[i * LD + j];
+				}
+				SYNC();
+				double c0 = 1.0;
+				bool going = true;
+				int rank = 0;
+				for (int s = 0; s <= rb; s++) {
+					for (int j = tid; j < n; j += T) {
+						double a = 0.0;
+						for (int i = 0; i < m; i++) a = fma(Wc[i * LD + j], Wc[i * LD + j], a);
+						sm.v0[j] = a;
+					}
+					SYNC();
+					double best = -1.0, frob2 = 0.0;
+					int jb = 0;
+					for (int j = 0; j < n; j++) {
+						const double a = sm.v0[j];
+						frob2 += a;
+						if (a > best) {
+							best = a;
+							jb = j;
+						}
+					}
+					if (s == 0) {
+						c0 = best;
+						if (frob2 < 1e-6) going = false;  // ||Jp||_F < 1e-3: empty range
+						else if (best < 1e-5) { going = false; need_exact = true; }
+					} else if (going) {
+						const double ratio = best / c0;
+						if (ratio < 1e-20) going = false;
+						else if (ratio < 1e-4 || s == rb) { going = false; need_exact = true; }
+					}
+					if (!going || s == rb) break;
+					const double inv = rsqrt(best);
+					for (int i = tid; i < m; i += T) {
+						const double u = Wc[i * LD + jb] * inv;
+						sm.W[3][i * LD + s] = u;  // U[:, s]
+						sm.v1[i] = u;
+					}
+					SYNC();
+					for (int j = tid; j < n; j += T) {
+						double d = 0.0;
+						for (int i = 0; i < m; i++) d = fma(sm.v1[i], Wc[i * LD + j], d);
+						Jh[s * LD + j] = d;  // row s of U^T Jp
+						sm.v2[j] = d;
+					}
+					SYNC();
+					for (int e = tid; e < m * n; e += T) {
+						int i = e / n, j = e - i * n;
+						Wc[i * LD + j] = fma(-sm.v1[i], sm.v2[j], Wc[i * LD + j]);
+					}
+					SYNC();
+					rank = s + 1;
+				}
+				r = rank;
+				empty = (r == 0) && !need_exact;
+				u_identity = false;
+			}
+			if (need_exact) {
+			// exact path: eigen-decomposition of the Gram matrix Jp Jp^T (m x m), reference tolerances
 			gemm<T>(sm.W[1], LD, Jp, LD, 1, Jp, 1, LD, m, n, m, tid);
 			SYNC();
 			double tr = 0.0;
@@ -345,6 +460,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					SYNC();
 					gemm<T>(Jh, LD, sm.W[3], 1, LD, Jp, LD, 1, r, m, n, tid);
 				}
+			}
 			}
 			SYNC();
 		}

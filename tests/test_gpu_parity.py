@@ -37,10 +37,12 @@ def _load(path):
     return cfg, W.CONFIGS[cfg]["robot"], tasks, z["q"], z["dq"], goals, z["tau"], bool(z["gravity_comp"]), bool(z["torque_saturation"])
 
 
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "general"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_engine_matches_golden(path):
+def test_engine_matches_golden(path, kernel):
     cfg, robot_name, tasks, q, dq, goals, tau_ref, grav, sat = _load(path)
     robot, ctrl, _ = _engine(robot_name, tasks, q.shape[0])
+    ctrl.setKernel(kernel)   # 0: lane kernel where it applies; 1: force the general workgroup-per-instance kernel
     ctrl.enableGravityCompensation(grav)
     ctrl.enableTorqueSaturation(sat)
     tau = _run(robot, ctrl, q, dq, goals)
