@@ -148,7 +148,7 @@ saip_status saip_batch_set_closed_loop_force_control(saip_batch*, int task, int 
 saip_status saip_batch_set_closed_loop_moment_control(saip_batch*, int task, int enabled);
 /* RobotController::enable{GravityCompensation,JointLimitAvoidance,TorqueSaturation}, RobotController.h:64-75 */
 saip_status saip_batch_enable_gravity_compensation(saip_batch*, int enabled);
-saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* enabled -> SAIP_ERR_UNSUPPORTED (next row) */
+saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* JLA wrap, RobotController.cpp:96-112 */
 saip_status saip_batch_enable_torque_saturation(saip_batch*, int enabled);
 /* integrator state policy: 0 = advance the integral terms only while the task's ki != 0 (default; elides the
  * state traffic), 1 = advance every cycle like the reference does (MotionForceTask.cpp:411-413,446; JointTask.cpp:323) */

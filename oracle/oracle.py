@@ -61,7 +61,7 @@ def _vec3(v):
 class Oracle:
     """The oracle for one robot model + ordered task list (specs from workloads.py)."""
 
-    def __init__(self, model, tasks, *, gravity_comp=False, torque_saturation=False):
+    def __init__(self, model, tasks, *, gravity_comp=False, torque_saturation=False, joint_limit_avoidance=False):
         L = lib()
         links = model.links
         nl = len(links)
@@ -120,7 +120,7 @@ class Oracle:
             L.orc_set_decoupling(self._h, tid, int(t["decoupling"]), float(t["bie_threshold"]))
             L.orc_set_timestep(self._h, tid, float(t["dt"]))
             self.goal_sizes.append(L.orc_goal_size(self._h, tid))
-        if L.orc_set_options(self._h, int(gravity_comp), 0, int(torque_saturation)) != 0:
+        if L.orc_set_options(self._h, int(gravity_comp), int(joint_limit_avoidance), int(torque_saturation)) != 0:
             raise ValueError("unsupported option")
 
     def __del__(self):

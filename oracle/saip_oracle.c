@@ -14,7 +14,7 @@
  *   tasks/SingularityHandler.cpp:75-228        -> sh_update_task_model()   (non-singular branch; others flagged)
  *   tasks/SingularityHandler.cpp:297-309       -> sh_compute_torques()
  *   tasks/JointTask.cpp:218-283, 285-356       -> jt_update_task_model(), jt_compute_torques()
- *   tasks/JointLimitAvoidanceTask.cpp:124-252  -> jla_update_task_model()
+ *   tasks/JointLimitAvoidanceTask.cpp:16-36, 124-421 -> jla_update_limit_status(), jla_update_task_model(), jla_compute_torques()
  *   tasks/MotionForceTask.cpp:28,55-87,143-168 -> orc_add_motion_force_task() (partial task projector)
  * sai-model / RBDL / Eigen are NOT in /root/reference (un-vendored, unpinned @master dependency);
  * their semantics are restated from the algebraic definitions of SURVEY.md Appendix B:
@@ -645,36 +645,151 @@ static void jt_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	mTm(tm->jt_projected_jacobian, Ua, d, m, n, 1);
 	for (int i = 0; i < n; i++) tau[i] -= d[i];
 }
-/* JointLimitAvoidanceTask::updateTaskModel, JointLimitAvoidanceTask.cpp:124-252 (status only; the torque path
- * :258-421 is a "next" row and only entered when the controller enables JLA, RobotController.cpp:96) */
-static void jla_update_task_model(const orc_ctx* c, const robot_state* rs, const double* N_prec, double* N_constraints) {
-	int n = c->n;
-	const double pz1 = 9 * M_PI / 180.0, vz1 = 0.5;              /* JointLimitAvoidanceTask.h:29-32 */
-	int active[MAXN], na = 0;
-	for (int i = 0; i < n; i++) {                               /* updateLimitStatus :171-239 */
-		int on = 0, dir = +1;
-		int pos_valid = c->q_hi[i] - c->q_lo[i] > 2 * pz1, vel_valid = c->vel[i] > 2 * vz1;
-		if (pos_valid && rs->q[i] > c->q_hi[i] - pz1) { on = 1; dir = +1; }
-		if (pos_valid && rs->q[i] < c->q_lo[i] + pz1) { on = 1; dir = -1; }
-		if (vel_valid && (!on || dir < 0) && rs->dq[i] > c->vel[i] - vz1) { on = 1; dir = +1; }
-		if (vel_valid && (!on || dir > 0) && rs->dq[i] < -c->vel[i] + vz1) { on = 1; dir = -1; }
-		if (on) active[na++] = i;
+/* JointLimitAvoidanceTask, JointLimitAvoidanceTask.cpp.  Defaults of JointLimitAvoidanceTask.h:26-35 (RobotController owns the task
+ * privately, so they cannot be changed through the controller). */
+enum { LS_OFF = 0, LS_POS_Z1, LS_POS_Z2, LS_VEL_Z1, LS_VEL_Z2 };
+typedef struct {
+	int status[MAXN], direction[MAXN], active[MAXN], na; /* direction: +1 POSITIVE, -1 NEGATIVE */
+	double limit_value[MAXN], torque_limit_value[MAXN];
+	double N_prec[MAXN * MAXN], S[MAXN * MAXN], U[MAXN * MAXN];
+	int r, empty;
+} jla_model;
+static const double JLA_KV = 20.0, JLA_PZ1 = 9 * M_PI / 180.0, JLA_PZ2 = 6 * M_PI / 180.0, JLA_VZ1 = 0.5, JLA_VZ2 = 0.3, JLA_RP = 1.0,
+					JLA_RV = 0.05;
+
+/* updateLimitStatus :171-239 */
+static void jla_update_limit_status(const orc_ctx* c, const robot_state* rs, jla_model* jm) {
+	jm->na = 0;
+	for (int i = 0; i < c->n; i++) {
+		jm->status[i] = LS_OFF;
+		jm->direction[i] = +1;
+		jm->limit_value[i] = 0;
+		jm->torque_limit_value[i] = 0;
+		double q = rs->q[i], dq = rs->dq[i];
+		int pos_valid = c->q_hi[i] - c->q_lo[i] > 2 * JLA_PZ1, vel_valid = c->vel[i] > 2 * JLA_VZ1; /* verifyValidityPerJoint :95-117 */
+		if (pos_valid) {
+			if (q > c->q_hi[i] - JLA_PZ1) { jm->direction[i] = +1; jm->limit_value[i] = c->q_hi[i]; jm->torque_limit_value[i] = c->effort[i]; jm->status[i] = LS_POS_Z1; }
+			if (q > c->q_hi[i] - JLA_PZ2) jm->status[i] = LS_POS_Z2;
+		}
+		if (pos_valid) {
+			if (q < c->q_lo[i] + JLA_PZ1) { jm->direction[i] = -1; jm->limit_value[i] = c->q_lo[i]; jm->torque_limit_value[i] = c->effort[i]; jm->status[i] = LS_POS_Z1; }
+			if (q < c->q_lo[i] + JLA_PZ2) jm->status[i] = LS_POS_Z2;
+		}
+		if (vel_valid && (jm->status[i] == LS_OFF || jm->direction[i] == -1)) {
+			if (dq > c->vel[i] - JLA_VZ1) { jm->direction[i] = +1; jm->limit_value[i] = c->vel[i]; jm->torque_limit_value[i] = c->effort[i]; jm->status[i] = LS_VEL_Z1; }
+			if (dq > c->vel[i] - JLA_VZ2) jm->status[i] = LS_VEL_Z2;
+		}
+		if (vel_valid && (jm->status[i] == LS_OFF || jm->direction[i] == +1)) {
+			if (dq < -c->vel[i] + JLA_VZ1) { jm->direction[i] = -1; jm->limit_value[i] = -c->vel[i]; jm->torque_limit_value[i] = c->effort[i]; jm->status[i] = LS_VEL_Z1; }
+			if (dq < -c->vel[i] + JLA_VZ2) jm->status[i] = LS_VEL_Z2;
+		}
+		if (jm->status[i] != LS_OFF) jm->active[jm->na++] = i;
 	}
-	double S[MAXN * MAXN], Jp[MAXN * MAXN], U[MAXN * MAXN];
-	memset(S, 0, sizeof(double) * (na ? na : 1) * n);
-	for (int r = 0; r < na; r++) S[r * n + active[r]] = 1;     /* computeJointSelectionMatrix :241-252 */
-	mm(S, N_prec, Jp, na, n, n);                               /* :145 */
-	int r0 = matrix_range_basis(S, na, n, U, 1e-3);            /* :147-154 (N_unconstrained unused when JLA off) */
+}
+/* updateTaskModel :124-169 (runs every cycle, RobotController.cpp:71, also when the controller has JLA disabled) */
+static void jla_update_task_model(const orc_ctx* c, const robot_state* rs, const double* N_prec, double* N_constraints, jla_model* jm) {
+	int n = c->n;
+	jla_update_limit_status(c, rs, jm);
+	int na = jm->na;
+	memcpy(jm->N_prec, N_prec, sizeof(double) * n * n);
+	double Jp[MAXN * MAXN];
+	memset(jm->S, 0, sizeof(double) * (na ? na : 1) * n);
+	for (int r = 0; r < na; r++) jm->S[r * n + jm->active[r]] = 1;     /* computeJointSelectionMatrix :241-252 */
+	mm(jm->S, N_prec, Jp, na, n, n);                                  /* :145 */
+	int r0 = matrix_range_basis(jm->S, na, n, jm->U, 1e-3);           /* :147-154 (N_unconstrained is not used by the controller) */
 	(void)r0;
-	int r = matrix_range_basis(Jp, na, n, U, 1e-3);            /* :156 */
-	if (fro(U, na * r) == 0) {                                 /* :157-162 */
+	jm->r = matrix_range_basis(Jp, na, n, jm->U, 1e-3);               /* :156 */
+	jm->empty = fro(jm->U, na * jm->r) == 0;
+	if (jm->empty) {                                                  /* :157-162 */
 		eye(N_constraints, n);
 		return;
 	}
 	double Jh[MAXN * MAXN], Lam[MAXN * MAXN], Jbar[MAXN * MAXN], N[MAXN * MAXN];
-	mTm(U, Jp, Jh, na, r, n);
-	op_space_matrices(rs, n, Jh, r, Lam, Jbar, N);             /* :164-168 */
+	mTm(jm->U, Jp, Jh, na, jm->r, n);
+	op_space_matrices(rs, n, Jh, jm->r, Lam, Jbar, N);                /* :164-168 */
 	mm(N, N_prec, N_constraints, n, n, n);
+}
+/* computeBlendingCoefficient :16-36 */
+static double jla_blend(double z, double z1, double z2, int direction) {
+	if (direction < 0) {
+		if (z >= z1) return 0;
+		if (z <= z2) return 1;
+		return (z1 - z) / (z1 - z2);
+	}
+	if (z <= z1) return 0;
+	if (z >= z2) return 1;
+	return (z - z1) / (z2 - z1);
+}
+/* computeTorques(tau_tasks) :258-421 */
+static void jla_compute_torques(const orc_ctx* c, const robot_state* rs, const jla_model* jm, const double* tau_tasks, double* out) {
+	int n = c->n, na = jm->na;
+	for (int i = 0; i < n; i++) out[i] = 0;
+	if (na == 0 || jm->empty) return;                                 /* :261-263, :272-276 */
+	double lat[MAXN], Jp[MAXN * MAXN];
+	mm(jm->S, jm->N_prec, Jp, na, n, n);                              /* :266 */
+	int cn = 0;
+	for (int i = 0; i < n; i++) {
+		double alpha, z1t = 0, z2t = 0, q = rs->q[i], dq = rs->dq[i], lv = jm->limit_value[i], tl = jm->torque_limit_value[i], t = tau_tasks[i];
+		int d = jm->direction[i];
+		if (jm->status[i] == LS_OFF) continue;
+		if (d > 0) {
+			switch (jm->status[i]) {
+				case LS_POS_Z1:
+					alpha = jla_blend(q, lv - JLA_PZ1, lv - JLA_PZ2, d);
+					z1t = t - JLA_KV * dq;
+					lat[cn] = (1 - alpha) * t + alpha * z1t;
+					break;
+				case LS_POS_Z2:
+					alpha = jla_blend(q, lv - JLA_PZ2, lv, d);
+					z1t = t - JLA_KV * dq;
+					z2t = -tl * JLA_RP - JLA_KV * dq;
+					lat[cn] = (1 - alpha) * z1t + alpha * z2t;
+					break;
+				case LS_VEL_Z1:
+					alpha = jla_blend(dq, lv - JLA_VZ1, lv - JLA_VZ2, d);
+					z1t = -JLA_KV * dq;
+					lat[cn] = (1 - alpha) * t + alpha * z1t;
+					break;
+				default: /* VEL_Z2 */
+					alpha = jla_blend(dq, lv - JLA_VZ2, lv, d);
+					z1t = -JLA_KV * dq;
+					z1t = fmax(fmin(z1t, tl * JLA_RV), -tl * JLA_RV);
+					z2t = -alpha * tl * JLA_RV;
+					lat[cn] = (1 - alpha) * z1t + alpha * z2t;
+			}
+		} else {
+			switch (jm->status[i]) {
+				case LS_POS_Z1:
+					alpha = jla_blend(q, lv + JLA_PZ1, lv + JLA_PZ2, d);
+					z1t = t - JLA_KV * dq;
+					z1t = fmax(fmin(z1t, tl * JLA_RV), -tl * JLA_RV);
+					lat[cn] = alpha * t + (1 - alpha) * z1t;          /* as written, :349-361 */
+					break;
+				case LS_POS_Z2:
+					alpha = jla_blend(q, lv + JLA_PZ2, lv, d);
+					z1t = t - JLA_KV * dq;
+					z2t = tl * JLA_RP - JLA_KV * dq;
+					lat[cn] = (1 - alpha) * z1t + alpha * z2t;
+					break;
+				case LS_VEL_Z1:
+					alpha = jla_blend(dq, lv + JLA_VZ1, lv + JLA_VZ2, d);
+					z1t = -JLA_KV * dq;
+					z1t = fmax(fmin(z1t, tl * JLA_RV), -tl * JLA_RV);
+					lat[cn] = (1 - alpha) * t + alpha * z1t;
+					break;
+				default:
+					alpha = jla_blend(dq, lv + JLA_VZ2, lv, d);
+					z1t = -JLA_KV * dq;
+					z1t = fmax(fmin(z1t, tl * JLA_RV), -tl * JLA_RV);
+					z2t = tl * JLA_RV;
+					lat[cn] = (1 - alpha) * z1t + alpha * z2t;
+			}
+		}
+		cn++;
+	}
+	double Ul[MAXN];
+	mm(jm->U, lat, Ul, na, jm->r, 1);                                 /* :418-420: Jp^T U lat */
+	mTm(Jp, Ul, out, na, n, 1);
 }
 
 /* ------------------------------------------------------------------ RobotController cycle for one instance */
@@ -699,7 +814,8 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 	/* updateControllerTaskModels, RobotController.cpp:68-77 */
 	double N_prec[MAXN * MAXN], N_constraints[MAXN * MAXN], T[MAXN * MAXN];
 	eye(N_prec, n);
-	jla_update_task_model(c, &rs, N_prec, N_constraints); /* :71-72, runs even when JLA is disabled */
+	jla_model jm;
+	jla_update_task_model(c, &rs, N_prec, N_constraints, &jm); /* :71-72, runs even when JLA is disabled */
 	int status = ST_OK;
 	for (int t = 0; t < c->nt; t++) {
 		const orc_task* tk = &c->task[t];
@@ -737,7 +853,17 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 			if (tau[i] > c->effort[i]) tau[i] = c->effort[i];
 			else if (tau[i] < -c->effort[i]) tau[i] = -c->effort[i];
 		}
-	/* :96-112 JLA wrap: "next" row (not restated yet); orc_set_options rejects jla_enabled */
+	if (c->jla_enabled) { /* :96-112 */
+		double tj[MAXN], nt[MAXN];
+		jla_compute_torques(c, &rs, &jm, tau, tj);
+		mTm(N_constraints, tau, nt, n, n, 1);
+		for (int i = 0; i < n; i++) tau[i] = tj[i] + nt[i];
+		if (c->torque_sat)
+			for (int i = 0; i < n; i++) {
+				if (tau[i] > c->effort[i]) tau[i] = c->effort[i];
+				else if (tau[i] < -c->effort[i]) tau[i] = -c->effort[i];
+			}
+	}
 	if (c->gravity_comp) { /* :114-116 */
 		double g[MAXN];
 		joint_gravity_vector(c, &rs, g);
@@ -891,7 +1017,7 @@ void orc_set_singularity_bounds(orc_ctx* c, int task, double s_min, double s_max
 }
 void orc_set_timestep(orc_ctx* c, int task, double dt) { c->task[task].dt = dt; }
 int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
-	if (jla) return -1; /* JLA torque path not restated yet */
+	c->jla_enabled = jla;
 	c->gravity_comp = gravity_comp;
 	c->torque_sat = torque_sat;
 	return 0;

@@ -20,6 +20,7 @@ struct ModelDev {
 	double com[SAIP_MAXN][3];    // body frame
 	double inertia[SAIP_MAXN][6];// about the COM, body axes: xx yy zz xy xz yz
 	double effort[SAIP_MAXN];
+	double q_lower[SAIP_MAXN], q_upper[SAIP_MAXN], vel_limit[SAIP_MAXN];  // jointLimits(), used by the joint-limit-avoidance wrap
 	double gravity[3];
 };
 
@@ -62,6 +63,7 @@ struct TaskDev {
 struct CycleParams {
 	int B, ld, n, nt;
 	int gravity_comp, torque_sat, integ_always, diag;
+	int jla, pad4_;    // RobotController::enableJointLimitAvoidance
 	const double* q;   // [n][ld]
 	const double* dq;  // [n][ld]
 	double* tau;       // [n][ld]

@@ -228,6 +228,9 @@ extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* link
 			M->vel[j] = L.velocity_limit;
 			M->effort[j] = L.effort_limit;
 			M->dev.effort[j] = L.effort_limit;
+			M->dev.q_lower[j] = L.q_lower;
+			M->dev.q_upper[j] = L.q_upper;
+			M->dev.vel_limit[j] = L.velocity_limit;
 			m3_eye(Rp);
 			pp[0] = pp[1] = pp[2] = 0;
 		} else {
@@ -299,7 +302,7 @@ struct saip_batch {
 	const saip_model* model = nullptr;
 	int B = 0, ld = 0, device = -1;
 	bool finalized = false, models_valid = false, config_dirty = true, state_pushed = false;
-	bool gravity_comp = false, torque_sat = false, integ_always = false;
+	bool gravity_comp = false, torque_sat = false, integ_always = false, jla = false;
 	int kernel_choice = 0;
 	std::string kernel_name = "none";
 	std::vector<TaskHost> tasks;
@@ -800,7 +803,7 @@ extern "C" saip_status saip_batch_enable_gravity_compensation(saip_batch* b, int
 }
 extern "C" saip_status saip_batch_enable_joint_limit_avoidance(saip_batch* b, int e) {
 	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
-	if (e) return fail(SAIP_ERR_UNSUPPORTED, "joint limit avoidance torques (JointLimitAvoidanceTask.cpp:258-421) are not implemented on the device yet");
+	b->jla = e != 0;
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_enable_torque_saturation(saip_batch* b, int e) {
@@ -900,6 +903,8 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.gravity_comp = b->gravity_comp;
 	P.torque_sat = b->torque_sat;
 	P.integ_always = b->integ_always;
+	P.jla = b->jla;
+	P.pad4_ = 0;
 	P.diag = diag;
 	P.q = b->q;
 	P.dq = b->dq;

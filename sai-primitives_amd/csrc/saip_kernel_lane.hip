@@ -868,14 +868,48 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 	}
 
-	// ---------------------------------------------------------------- RobotController post-processing + store
+	// ---------------------------------------------------------------- RobotController post-processing (RobotController.cpp:86-116) + store
+	if (P.torque_sat) {
+		UNR for (int j = 0; j < N; j++) {
+			const double lim = md->effort[j];
+			tau[j] = tau[j] > lim ? lim : (tau[j] < -lim ? -lim : tau[j]);
+		}
+	}
+	if (P.jla) {
+		// tau = JLA.computeTorques(tau) + N_constraints^T tau with N_constraints^T = I - S^T (S M^-1 S^T)^-1 S M^-1, S = rows of the
+		// identity for the joints inside a limit zone (JointLimitAvoidanceTask.cpp:124-169 with N_prec = I).  Padded to N x N.
+		double lat[N];
+		bool act[N], any = false;
+		UNR for (int j = 0; j < N; j++) {
+			const double qj = P.q[(size_t)j * ld + b], dqj = P.dq[(size_t)j * ld + b];
+			lat[j] = jla_joint(qj, dqj, md->q_lower[j], md->q_upper[j], md->vel_limit[j], md->effort[j], tau[j], &act[j]);
+			any = any || act[j];
+		}
+		if (__any(any)) {  // wave-uniform: free when no instance of the wavefront touches a limit zone
+			double w[N], A[N][N], Ai[N][N];
+			UNR for (int i = 0; i < N; i++) {
+				double sacc = 0.0;
+				UNR for (int j = 0; j < N; j++) sacc = fma(Minv[i][j], tau[j], sacc);
+				w[i] = act[i] ? sacc : 0.0;
+				UNR for (int j = 0; j <= i; j++) A[i][j] = (act[i] && act[j]) ? Minv[i][j] : ((i == j) ? 1.0 : 0.0);
+			}
+			spd_inv_reg<N>(A, Ai);
+			UNR for (int i = 0; i < N; i++) {
+				double y = 0.0;
+				UNR for (int j = 0; j < N; j++) y = fma(Ai[i][j], w[j], y);
+				tau[i] = act[i] ? (lat[i] + tau[i] - y) : tau[i];
+			}
+			if (P.torque_sat) {
+				UNR for (int j = 0; j < N; j++) {
+					const double lim = md->effort[j];
+					tau[j] = tau[j] > lim ? lim : (tau[j] < -lim ? -lim : tau[j]);
+				}
+			}
+		}
+	}
 	if (live) {
 		UNR for (int j = 0; j < N; j++) {
 			double tv = tau[j];
-			if (P.torque_sat) {
-				const double lim = md->effort[j];
-				tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
-			}
 			if (P.gravity_comp) tv += taug[j];
 			if (singular) tv = __builtin_nan("");
 			P.tau[(size_t)j * ld + b] = tv;

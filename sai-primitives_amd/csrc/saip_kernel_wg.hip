@@ -637,12 +637,51 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	}
 
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
+	if (tid < n && P.torque_sat) {
+		const double lim = md.effort[tid];
+		const double tv = sm.tau[tid];
+		sm.tau[tid] = tv > lim ? lim : (tv < -lim ? -lim : tv);
+	}
+	if (P.jla && !singular) {
+		// tau = JLA.computeTorques(tau) + N_constraints^T tau,  N_constraints^T = I - S^T (S M^-1 S^T)^-1 S M^-1 (padded to n x n)
+		SYNC();
+		if (tid < n) {
+			bool act;
+			sm.v0[tid] = jla_joint(sm.q[tid], sm.dq[tid], md.q_lower[tid], md.q_upper[tid], md.vel_limit[tid], md.effort[tid], sm.tau[tid], &act);
+			sm.v1[tid] = act ? 1.0 : 0.0;
+		}
+		SYNC();
+		double nact = 0.0;
+		for (int j = 0; j < n; j++) nact += sm.v1[j];
+		if (nact > 0.0) {
+			for (int i = tid; i < n; i += T) {
+				double sacc = 0.0;
+				for (int j = 0; j < n; j++) sacc = fma(sm.Minv[i * LD + j], sm.tau[j], sacc);
+				sm.v2[i] = (sm.v1[i] != 0.0) ? sacc : 0.0;
+			}
+			for (int e = tid; e < n * n; e += T) {
+				int i = e / n, j = e - i * n;
+				sm.W[0][i * LD + j] = (sm.v1[i] != 0.0 && sm.v1[j] != 0.0) ? sm.Minv[i * LD + j] : ((i == j) ? 1.0 : 0.0);
+			}
+			SYNC();
+			spd_inverse<T>(sm.W[0], sm.W[1], sm.W[2], sm.W[3], sm.dv, n, LD, tid);
+			if (tid < n) {
+				double y = 0.0;
+				for (int j = 0; j < n; j++) y = fma(sm.W[1][tid * LD + j], sm.v2[j], y);
+				double tv = sm.tau[tid];
+				if (sm.v1[tid] != 0.0) tv = sm.v0[tid] + tv - y;
+				if (P.torque_sat) {
+					const double lim = md.effort[tid];
+					tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
+				}
+				sm.v3[tid] = tv;
+			}
+			SYNC();
+			if (tid < n) sm.tau[tid] = sm.v3[tid];
+		}
+	}
 	if (tid < n) {
 		double tv = sm.tau[tid];
-		if (P.torque_sat) {
-			double lim = md.effort[tid];
-			tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
-		}
 		if (P.gravity_comp) {
 			// jointGravityVector: tau_g[j] = -(d c_com / d q_j) . (m g) summed over the subtree = -S_j . (composite gravity wrench)
 			const double* Ic = sm.comp + 10 * tid;

@@ -122,4 +122,52 @@ __device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw
 	law_mat3_vec(sig_o, tmp, Fum + 3);
 }
 
+// JointLimitAvoidanceTask for ONE joint: limit status (updateLimitStatus, JointLimitAvoidanceTask.cpp:171-239) and the zone-blended
+// constraint torque (computeTorques :278-412) with the task defaults of JointLimitAvoidanceTask.h:26-35 (RobotController owns the
+// task privately: they cannot be changed through the controller).  Returns the constraint torque; *active = limit status != OFF.
+__device__ __forceinline__ double jla_joint(const double q, const double dq, const double lo, const double hi, const double vel,
+											 const double eff, const double t, bool* active) {
+	const double KV = 20.0, PZ1 = 9.0 * M_PI / 180.0, PZ2 = 6.0 * M_PI / 180.0, VZ1 = 0.5, VZ2 = 0.3, RP = 1.0, RV = 0.05;
+	int st = 0, dir = 1;  // 0 OFF, 1 POS_Z1, 2 POS_Z2, 3 VEL_Z1, 4 VEL_Z2
+	double lv = 0.0;
+	const bool pos_valid = (hi - lo > 2 * PZ1), vel_valid = (vel > 2 * VZ1);
+	if (pos_valid) {
+		if (q > hi - PZ1) { dir = 1; lv = hi; st = 1; }
+		if (q > hi - PZ2) st = 2;
+		if (q < lo + PZ1) { dir = -1; lv = lo; st = 1; }
+		if (q < lo + PZ2) st = 2;
+	}
+	if (vel_valid && (st == 0 || dir == -1)) {
+		if (dq > vel - VZ1) { dir = 1; lv = vel; st = 3; }
+		if (dq > vel - VZ2) st = 4;
+	}
+	if (vel_valid && (st == 0 || dir == 1)) {
+		if (dq < -vel + VZ1) { dir = -1; lv = -vel; st = 3; }
+		if (dq < -vel + VZ2) st = 4;
+	}
+	*active = (st != 0);
+	if (st == 0) return 0.0;
+	const double sgn = (double)dir;
+	const bool is_pos = (st <= 2);
+	const double z = is_pos ? q : dq;
+	const double za = (st == 1) ? PZ1 : (st == 2) ? PZ2 : (st == 3) ? VZ1 : VZ2;   // distance of the zone start to the limit
+	const double zb = (st == 1) ? PZ2 : (st == 3) ? VZ2 : 0.0;                        // distance of the zone end to the limit
+	const double z1 = lv - sgn * za, z2 = lv - sgn * zb;
+	double alpha;  // computeBlendingCoefficient :16-36
+	if (dir < 0) alpha = (z >= z1) ? 0.0 : (z <= z2) ? 1.0 : (z1 - z) / (z1 - z2);
+	else alpha = (z <= z1) ? 0.0 : (z >= z2) ? 1.0 : (z - z1) / (z2 - z1);
+	const double cl = eff * RV;
+	const double damp = -KV * dq, damp_c = fmax(fmin(damp, cl), -cl), td = t + damp, td_c = fmax(fmin(td, cl), -cl);
+	if (dir > 0) {
+		if (st == 1) return (1 - alpha) * t + alpha * td;
+		if (st == 2) return (1 - alpha) * td + alpha * (-eff * RP + damp);
+		if (st == 3) return (1 - alpha) * t + alpha * damp;
+		return (1 - alpha) * damp_c + alpha * (-alpha * cl);
+	}
+	if (st == 1) return alpha * t + (1 - alpha) * td_c;  // as written in the reference (:349-361)
+	if (st == 2) return (1 - alpha) * td + alpha * (eff * RP + damp);
+	if (st == 3) return (1 - alpha) * t + alpha * damp_c;
+	return (1 - alpha) * damp_c + alpha * cl;
+}
+
 }  // namespace saip

@@ -27,6 +27,8 @@ SCENARIOS = {
     "cfg2_gravity_saturation": (2, 32, dict(gravity_comp=True, torque_saturation=True)),
     "cfg9_hybrid_force_velsat": (9, 32, {}),
     "cfg10_full_force_space": (10, 32, {}),
+    "cfg11_joint_limit_avoidance": (11, 48, dict(joint_limit_avoidance=True, torque_saturation=True)),
+    "cfg11_jla_gravity": (11, 32, dict(joint_limit_avoidance=True, gravity_comp=True)),
 }
 
 
@@ -38,7 +40,8 @@ def main():
         assert status.sum() == 0, name
         arrs = dict(cfg=np.int64(cfg), q=d["q"], dq=d["dq"], tau=tau, status=status,
                     gravity_comp=np.bool_(opts.get("gravity_comp", False)),
-                    torque_saturation=np.bool_(opts.get("torque_saturation", False)))
+                    torque_saturation=np.bool_(opts.get("torque_saturation", False)),
+                    joint_limit_avoidance=np.bool_(opts.get("joint_limit_avoidance", False)))
         for i, g in enumerate(d["goals"]):
             arrs[f"goal{i}"] = g
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **{k: np.asarray(v, dtype=v.dtype.newbyteorder("<") if hasattr(v, "dtype") and v.dtype.kind == "f" else None) for k, v in arrs.items()})

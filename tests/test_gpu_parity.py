@@ -34,15 +34,17 @@ def _load(path):
     cfg = int(z["cfg"])
     tasks = W.config_tasks(cfg)
     goals = [z[f"goal{i}"] for i in range(len(tasks))]
-    return cfg, W.CONFIGS[cfg]["robot"], tasks, z["q"], z["dq"], goals, z["tau"], bool(z["gravity_comp"]), bool(z["torque_saturation"])
+    jla = bool(z["joint_limit_avoidance"]) if "joint_limit_avoidance" in z else False
+    return cfg, W.CONFIGS[cfg]["robot"], tasks, z["q"], z["dq"], goals, z["tau"], bool(z["gravity_comp"]), bool(z["torque_saturation"]), jla
 
 
 @pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "general"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_engine_matches_golden(path, kernel):
-    cfg, robot_name, tasks, q, dq, goals, tau_ref, grav, sat = _load(path)
+    cfg, robot_name, tasks, q, dq, goals, tau_ref, grav, sat, jla = _load(path)
     robot, ctrl, _ = _engine(robot_name, tasks, q.shape[0])
     ctrl.setKernel(kernel)   # 0: lane kernel where it applies; 1: force the general workgroup-per-instance kernel
+    ctrl.enableJointLimitAvoidance(jla)
     ctrl.enableGravityCompensation(grav)
     ctrl.enableTorqueSaturation(sat)
     tau = _run(robot, ctrl, q, dq, goals)
@@ -199,3 +201,23 @@ def test_force_space_reparametrisation_resets_linear_goal():
     tau = ctrl.computeControlTorques()
     ref, _ = Oracle(model, spec).step(d["q"], d["dq"], goals)
     assert W.torque_error(tau, ref) < TOL
+
+
+def test_joint_limit_avoidance_full_size():
+    """RobotController's JLA wrap (RobotController.cpp:96-112) on 2048 instances pushed into the limit zones, vs the oracle"""
+    from oracle import Oracle
+    d = W.make_inputs(11, 2048)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 2048)
+    ctrl.enableJointLimitAvoidance(True)
+    ctrl.enableTorqueSaturation(True)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    o = Oracle(d["model"], d["tasks"], joint_limit_avoidance=True, torque_saturation=True)
+    ref, st = o.step(d["q"], d["dq"], d["goals"], nthreads=8)
+    assert np.array_equal(ctrl.status, st)
+    ok = st == 0
+    assert ok.sum() > 1000
+    assert W.torque_error(tau[ok], ref[ok]) < TOL
+    # the wrap really acted: it differs from the un-wrapped torques on most instances
+    ctrl.enableJointLimitAvoidance(False)
+    tau0 = ctrl.computeControlTorques()
+    assert (np.abs(tau0[ok] - tau[ok]).max(axis=1) > 1e-6).mean() > 0.5

@@ -22,7 +22,8 @@ def load_golden(path):
     model = W.load_robot(W.CONFIGS[cfg]["robot"])
     tasks = W.config_tasks(cfg)
     goals = [z[f"goal{i}"] for i in range(len(tasks))]
-    opts = dict(gravity_comp=bool(z["gravity_comp"]), torque_saturation=bool(z["torque_saturation"]))
+    opts = dict(gravity_comp=bool(z["gravity_comp"]), torque_saturation=bool(z["torque_saturation"]),
+                joint_limit_avoidance=bool(z["joint_limit_avoidance"]) if "joint_limit_avoidance" in z else False)
     return model, tasks, z["q"], z["dq"], goals, z["tau"], opts
 
 

@@ -330,13 +330,101 @@ def sigma_space(Pblock, dim, axis, rotation):
     return Pblock @ inner @ Pblock.T
 
 
+# --------------------------------------------------- JointLimitAvoidanceTask (JointLimitAvoidanceTask.cpp:124-421)
+JLA = dict(kv=20.0, pz1=9 * np.pi / 180, pz2=6 * np.pi / 180, vz1=0.5, vz2=0.3, ratio_pos=1.0, ratio_vel=0.05)  # .h:26-35
+OFF, POS_Z1, POS_Z2, VEL_Z1, VEL_Z2 = range(5)
+
+
+def jla_limit_status(model, q, dq):
+    """updateLimitStatus, JointLimitAvoidanceTask.cpp:171-239 -> status, direction (+1/-1), limit value, torque limit per joint"""
+    n = model.dof
+    st, dr, lv, tl = [OFF] * n, [1] * n, [0.0] * n, [0.0] * n
+    for i in range(n):
+        lo, hi, vel, eff = model.q_lower[i], model.q_upper[i], model.vel_limit[i], model.effort[i]
+        pos_valid = hi - lo > 2 * JLA["pz1"]
+        vel_valid = vel > 2 * JLA["vz1"]
+        if pos_valid:
+            if q[i] > hi - JLA["pz1"]:
+                dr[i], lv[i], tl[i], st[i] = 1, hi, eff, POS_Z1
+            if q[i] > hi - JLA["pz2"]:
+                st[i] = POS_Z2
+            if q[i] < lo + JLA["pz1"]:
+                dr[i], lv[i], tl[i], st[i] = -1, lo, eff, POS_Z1
+            if q[i] < lo + JLA["pz2"]:
+                st[i] = POS_Z2
+        if vel_valid and (st[i] == OFF or dr[i] == -1):
+            if dq[i] > vel - JLA["vz1"]:
+                dr[i], lv[i], tl[i], st[i] = 1, vel, eff, VEL_Z1
+            if dq[i] > vel - JLA["vz2"]:
+                st[i] = VEL_Z2
+        if vel_valid and (st[i] == OFF or dr[i] == 1):
+            if dq[i] < -vel + JLA["vz1"]:
+                dr[i], lv[i], tl[i], st[i] = -1, -vel, eff, VEL_Z1
+            if dq[i] < -vel + JLA["vz2"]:
+                st[i] = VEL_Z2
+    return st, dr, lv, tl
+
+
+def _blend(z, z1, z2, direction):
+    """computeBlendingCoefficient, JointLimitAvoidanceTask.cpp:16-36"""
+    if direction < 0:
+        return 0.0 if z >= z1 else (1.0 if z <= z2 else (z1 - z) / (z1 - z2))
+    return 0.0 if z <= z1 else (1.0 if z >= z2 else (z - z1) / (z2 - z1))
+
+
+def jla_wrap(model, q, dq, Minv, tau_tasks):
+    """RobotController.cpp:96-101: tau = JLA.computeTorques(tau) + N_constraints^T tau  (JLA model :124-169 with N_prec = I)"""
+    n = model.dof
+    st, dr, lv, tl = jla_limit_status(model, q, dq)
+    act = [i for i in range(n) if st[i] != OFF]
+    if not act:
+        return tau_tasks.copy()
+    kv, pz1, pz2, vz1, vz2, rp, rv = (JLA[k] for k in ("kv", "pz1", "pz2", "vz1", "vz2", "ratio_pos", "ratio_vel"))
+    lat = []
+    for i in act:
+        t_i, d = tau_tasks[i], dr[i]
+        clampv = lambda x: max(min(x, tl[i] * rv), -tl[i] * rv)
+        if d > 0:
+            if st[i] == POS_Z1:
+                a = _blend(q[i], lv[i] - pz1, lv[i] - pz2, d)
+                v = (1 - a) * t_i + a * (t_i - kv * dq[i])
+            elif st[i] == POS_Z2:
+                a = _blend(q[i], lv[i] - pz2, lv[i], d)
+                v = (1 - a) * (t_i - kv * dq[i]) + a * (-tl[i] * rp - kv * dq[i])
+            elif st[i] == VEL_Z1:
+                a = _blend(dq[i], lv[i] - vz1, lv[i] - vz2, d)
+                v = (1 - a) * t_i + a * (-kv * dq[i])
+            else:
+                a = _blend(dq[i], lv[i] - vz2, lv[i], d)
+                v = (1 - a) * clampv(-kv * dq[i]) + a * (-a * tl[i] * rv)
+        else:
+            if st[i] == POS_Z1:
+                a = _blend(q[i], lv[i] + pz1, lv[i] + pz2, d)
+                v = a * t_i + (1 - a) * clampv(t_i - kv * dq[i])          # as written in the reference (:349-361)
+            elif st[i] == POS_Z2:
+                a = _blend(q[i], lv[i] + pz2, lv[i], d)
+                v = (1 - a) * (t_i - kv * dq[i]) + a * (tl[i] * rp - kv * dq[i])
+            elif st[i] == VEL_Z1:
+                a = _blend(dq[i], lv[i] + vz1, lv[i] + vz2, d)
+                v = (1 - a) * t_i + a * clampv(-kv * dq[i])
+            else:
+                a = _blend(dq[i], lv[i] + vz2, lv[i], d)
+                v = (1 - a) * clampv(-kv * dq[i]) + a * (tl[i] * rv)
+        lat.append(v)
+    S = np.zeros((len(act), n))
+    for r, i in enumerate(act):
+        S[r, i] = 1.0
+    Lam, _, N = op_space_matrices(S, Minv)      # range basis of S is the identity (rows of I: full row rank)
+    return S.T @ np.array(lat) + N.T @ tau_tasks
+
+
 # --------------------------------------------------- literal single-instance controller
 class Singular(Exception):
     pass
 
 
 def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_comp=False,
-                           torque_saturation=False, details=None):
+                           torque_saturation=False, joint_limit_avoidance=False, details=None):
     """One control cycle for ONE instance, literal reference path (SVDs, explicit inverses).
     goals[t]: flat vector (goal_size).  Returns tau (n,).  Raises Singular when an instance
     leaves the non-singular branch of SingularityHandler (alpha != 1)."""
@@ -483,6 +571,10 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
                 details.append(dict(tau=tt, **m))
     if torque_saturation:
         tau = np.clip(tau, -model.effort, model.effort)              # RobotController.cpp:86-94
+    if joint_limit_avoidance:                                        # :96-112
+        tau = jla_wrap(model, q, dq, Minv, tau)
+        if torque_saturation:
+            tau = np.clip(tau, -model.effort, model.effort)
     if gravity_comp:
         tau = tau + gravity_vector(model, frames)[0]                 # :114-116
     return tau
@@ -528,13 +620,15 @@ CONFIGS = {
     9: dict(robot="panda_arm", batch=256, desc="Panda, hybrid motion/force: force space dim 1 (compliant-frame axis) + moment space dim 2, open-loop force "
             "control with goal force/moment, velocity saturation on both tasks (examples/07-09 style)"),
     10: dict(robot="panda_arm", batch=256, desc="Panda, full force space (dim 3) + motion-only rotation, world-frame parametrisation, joint velocity saturation"),
+    11: dict(robot="panda_arm", batch=256, desc="config-2 tasks with joint states pushed into the joint-limit-avoidance zones (q within 2% of the limits, "
+             "|dq| up to the velocity limit): exercises RobotController's JLA wrap + torque saturation"),
 }
 
 
 def config_tasks(cfg: int):
     if cfg == 1:
         return [joint_task("joint_task", kp=100.0, kv=20.0)]          # examples/01-joint_control:133
-    if cfg in (2, 4):
+    if cfg in (2, 4, 11):
         return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07)),  # examples/05:111-117
                 joint_task("joint_task")]
     if cfg == 3:
@@ -620,7 +714,8 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
         return dict(model=model, tasks=tasks, q=q, dq=dq,
                     goals=[np.concatenate([qg, np.zeros((1, n)), np.zeros((1, n))], axis=1)])
     rngq = model.q_upper - model.q_lower
-    lo, hi = model.q_lower + 0.15 * rngq, model.q_upper - 0.15 * rngq
+    margin = 0.02 if cfg == 11 else 0.15
+    lo, hi = model.q_lower + margin * rngq, model.q_upper - margin * rngq
     q = lo + (hi - lo) * rng.uniform_range(0.0, 1.0, n)
     has_mf = any(t["type"] == "motion_force" for t in tasks)
     if has_mf:
@@ -633,6 +728,8 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
         else:
             raise RuntimeError("rejection sampling did not converge")
     dq = rng.uniform_range(-0.5, 0.5, n)
+    if cfg == 11:
+        dq = dq * 2.0 * model.vel_limit[None]    # up to +-vel_limit: velocity zones get entered
     frames = fk(model, q)
     goals = []
     for t in tasks:
