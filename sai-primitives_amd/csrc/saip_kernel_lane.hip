@@ -74,9 +74,30 @@ struct LaneSmem {
 	double pf[PFN][64];
 	static constexpr int PARK = 6 * N + 24 + (LEAN ? 0 : 10 * N);  // joint axes + origins, two control frames, (per-body spatial inertias)
 	double park[PARK][64];
+	static constexpr bool MINV_LDS = !LEAN;              // latency variant: M^-1 and M_BIE^-1 parked in LDS, rows streamed on use
+	double minv[MINV_LDS ? N * (N + 1) : 1][64];        // two symmetric matrices, N(N+1)/2 rows each
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
 	int flag, rank;
+};
+
+// Symmetric N x N matrix that lives either in registers or parked in LDS as N(N+1)/2 lane-interleaved rows (conflict-free).
+// row() streams one row into registers: consumers are written row-major so that an LDS-resident matrix costs N reads per N*R FMAs.
+template <int N, bool INLDS>
+struct SymMat {
+	const double (*reg)[N];
+	const double (*lds)[64];
+	int lane;
+	__device__ __forceinline__ void row(const int l, double (&r)[N]) const {
+		UNR for (int j = 0; j < N; j++) {
+			if (INLDS) {
+				const int a = l > j ? l : j, b = l > j ? j : l;
+				r[j] = lds[a * (a + 1) / 2 + b][lane];
+			} else {
+				r[j] = reg[l][j];
+			}
+		}
+	}
 };
 
 // Ainv = A^-1 for a symmetric positive definite R x R register matrix (lower triangle of A is read)
@@ -110,17 +131,19 @@ __device__ __forceinline__ void spd_inv_reg(const double (&A)[R][R], double (&Ai
 }
 
 // operationalSpaceMatrices in the range basis.  Jh: R x N (rows >= r_lane are zero).  Outputs Lambda, Lambda_mod, T1 = Jh Minv.
-template <int N, int R>
-__device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const double (&Minv)[N][N], const double (&MBinv)[N][N],
+template <int N, int R, bool INLDS>
+__device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const SymMat<N, INLDS>& Minv, const SymMat<N, INLDS>& MBinv,
 											   const int r_lane, const int decoupling, double (&Lam)[R][R], double (&Lmod)[R][R],
 											   double (&T1)[R][N]) {
 	double A[R][R];
 	UNR for (int a = 0; a < R; a++)
-		UNR for (int j = 0; j < N; j++) {
-			double s = 0.0;
-			UNR for (int l = 0; l < N; l++) s = fma(Jh[a][l], Minv[l][j], s);
-			T1[a][j] = s;
-		}
+		UNR for (int j = 0; j < N; j++) T1[a][j] = 0.0;
+	UNR for (int l = 0; l < N; l++) {
+		double mr[N];
+		Minv.row(l, mr);
+		UNR for (int a = 0; a < R; a++)
+			UNR for (int j = 0; j < N; j++) T1[a][j] = fma(Jh[a][l], mr[j], T1[a][j]);
+	}
 	UNR for (int a = 0; a < R; a++)
 		UNR for (int c = 0; c <= a; c++) {
 			double s = 0.0;
@@ -135,12 +158,30 @@ __device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const d
 	} else if (decoupling == DEC_IMPEDANCE) {
 		UNR for (int a = 0; a < R; a++)
 			UNR for (int c = 0; c < R; c++) Lmod[a][c] = (a == c) ? 1.0 : 0.0;
+	} else if (INLDS) {
+		double Tb[R][N];
+		UNR for (int a = 0; a < R; a++)
+			UNR for (int j = 0; j < N; j++) Tb[a][j] = 0.0;
+		UNR for (int l = 0; l < N; l++) {
+			double mr[N];
+			MBinv.row(l, mr);
+			UNR for (int a = 0; a < R; a++)
+				UNR for (int j = 0; j < N; j++) Tb[a][j] = fma(Jh[a][l], mr[j], Tb[a][j]);
+		}
+		UNR for (int a = 0; a < R; a++)
+			UNR for (int c = 0; c <= a; c++) {
+				double s = 0.0;
+				UNR for (int j = 0; j < N; j++) s = fma(Tb[a][j], Jh[c][j], s);
+				if (a == c) s = (a >= r_lane) ? 1.0 : s;
+				A[a][c] = s;
+			}
+		spd_inv_reg<R>(A, Lmod);
 	} else {
 		UNR for (int a = 0; a < R; a++) {
 			double tb[N];  // row a of Jh M_BIE^-1, consumed immediately
 			UNR for (int j = 0; j < N; j++) {
 				double s = 0.0;
-				UNR for (int l = 0; l < N; l++) s = fma(Jh[a][l], MBinv[l][j], s);
+				UNR for (int l = 0; l < N; l++) s = fma(Jh[a][l], MBinv.reg[l][j], s);
 				tb[j] = s;
 			}
 			UNR for (int c = 0; c <= a; c++) {
@@ -206,7 +247,7 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 
 template <int N, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
-		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
+		const bool live, const bool first, const bool last, const SymMat<N, SMT::MINV_LDS>& Minv, const SymMat<N, SMT::MINV_LDS>& MBinv,
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
 	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
@@ -359,7 +400,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 	}
 	PHASE_FENCE();
 	double Lam[6][6], Lmod[6][6], T1[6][N];
-	opspace_lambda<N, 6>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
+	opspace_lambda<N, 6, SMT::MINV_LDS>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
 
 	PHASE_FENCE();
 	tk = launder(tk);
@@ -441,7 +482,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 
 template <int N, int RJ, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
-		const bool live, const bool first, const bool last, const double (&Minv)[N][N], const double (&MBinv)[N][N],
+		const bool live, const bool first, const bool last, const SymMat<N, SMT::MINV_LDS>& Minv, const SymMat<N, SMT::MINV_LDS>& MBinv,
 		double (&Np)[N][N], double (&tau)[N], bool& singular) {
 	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
@@ -569,7 +610,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 	}
 	PHASE_FENCE();
 	double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
-	opspace_lambda<N, RJ>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
+	opspace_lambda<N, RJ, SMT::MINV_LDS>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
 
 	tk = launder(tk);
 	// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
@@ -577,8 +618,9 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 	{
 		double w[N], qv[N], dqv[N];
 		UNR for (int i = 0; i < N; i++) {  // w = M^-1 tau_prec (disturbance compensation, :287-291)
-			double s = 0.0;
-			UNR for (int j = 0; j < N; j++) s = fma(Minv[i][j], tau[j], s);
+			double mr[N], s = 0.0;
+			Minv.row(i, mr);
+			UNR for (int j = 0; j < N; j++) s = fma(mr[j], tau[j], s);
 			w[i] = s;
 		}
 		UNR for (int j = 0; j < N; j++) {
@@ -844,6 +886,16 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 	}
 
+	constexpr int NSYM = N * (N + 1) / 2;
+	if (SM::MINV_LDS) {
+		UNR for (int i = 0; i < N; i++)
+			UNR for (int j = 0; j <= i; j++) {
+				sm.minv[i * (i + 1) / 2 + j][lane] = Minv[i][j];
+				sm.minv[NSYM + i * (i + 1) / 2 + j][lane] = MBinv[i][j];
+			}
+	}
+	const SymMat<N, SM::MINV_LDS> MinvS = {Minv, SM::MINV_LDS ? &sm.minv[0] : nullptr, lane};
+	const SymMat<N, SM::MINV_LDS> MBinvS = {MBinv, SM::MINV_LDS ? &sm.minv[SM::MINV_LDS ? NSYM : 0] : nullptr, lane};
 	PHASE_FENCE();
 	// ---------------------------------------------------------------- task hierarchy
 	double Np[N][N], tau[N];
@@ -856,14 +908,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 
 	if (SIG == SIG_MF_JT) {
 		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
-		lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, Minv, MBinv, Np, tau, singular);
+		lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, MinvS, MBinvS, Np, tau, singular);
 		PHASE_FENCE();
-		lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, Minv, MBinv, Np, tau, singular);
+		lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, MinvS, MBinvS, Np, tau, singular);
 	} else {
 		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 			const bool last = (t == P.nt - 1);
-			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
-			else lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, Minv, MBinv, Np, tau, singular);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, Np, tau, singular);
+			else lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, Np, tau, singular);
 			first = false;
 		}
 	}
@@ -888,10 +940,11 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		if (__any(any)) {  // wave-uniform: free when no instance of the wavefront touches a limit zone
 			double w[N], A[N][N], Ai[N][N];
 			UNR for (int i = 0; i < N; i++) {
-				double sacc = 0.0;
-				UNR for (int j = 0; j < N; j++) sacc = fma(Minv[i][j], tau[j], sacc);
+				double mr[N], sacc = 0.0;
+				MinvS.row(i, mr);
+				UNR for (int j = 0; j < N; j++) sacc = fma(mr[j], tau[j], sacc);
 				w[i] = act[i] ? sacc : 0.0;
-				UNR for (int j = 0; j <= i; j++) A[i][j] = (act[i] && act[j]) ? Minv[i][j] : ((i == j) ? 1.0 : 0.0);
+				UNR for (int j = 0; j <= i; j++) A[i][j] = (act[i] && act[j]) ? mr[j] : ((i == j) ? 1.0 : 0.0);
 			}
 			spd_inv_reg<N>(A, Ai);
 			UNR for (int i = 0; i < N; i++) {
@@ -938,9 +991,9 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	// and its layout assumes a full joint task (3 dof goal rows) below one motion-force task.
 	static const bool want_pf = getenv("SAIP_LANE_PF") != nullptr;  // measured SLOWER (33.0 vs 28.9 us at cfg2): off unless asked for
 	const bool pf = mf_jt && P.lane_prefetch_ok && P.B <= 64 * 256 && want_pf;
-	// throughput variant once the batch needs more than two wavefronts per CU: 36 KB LDS per wavefront instead of 72 KB
+	// throughput variant once the batch needs more than one wavefront per CU: 36 KB LDS per wavefront instead of 100 KB
 	static const char* lean_env = getenv("SAIP_LANE_LEAN");  // "0"/"1" forces the choice (profiling)
-	const bool lean = lean_env ? (lean_env[0] == '1') : (P.B > 64 * 256 * 2);
+	const bool lean = lean_env ? (lean_env[0] == '1') : (P.B > 64 * 256);
 	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
 #define LAUNCH(NN, RR, SS, PP, GG) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false, GG>), grid, block, 0, stream, P)
 	const bool gl = P.lane_general != 0;
