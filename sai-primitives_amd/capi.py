@@ -39,7 +39,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(_DIR, h) for h in HEADERS]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "-o", LIB_PATH] + srcs
+    extra = os.environ.get("SAIP_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds only (e.g. -DSAIP_STAMP)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "-o", LIB_PATH] + extra + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

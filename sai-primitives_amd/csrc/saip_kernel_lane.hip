@@ -29,7 +29,19 @@ namespace saip {
 
 #define UNR _Pragma("unroll")
 #define CONSTANT_AS __attribute__((address_space(4)))
-#ifdef SAIP_NO_FENCE
+#if defined(SAIP_STAMP)
+// diagnostic build only (never shipped): s_memtime stamps of block 0 / lane 0 at every phase boundary
+__device__ unsigned long long saip_stamps[256];
+#define PHASE_FENCE()                                                                      \
+	do {                                                                                   \
+		__builtin_amdgcn_sched_barrier(0);                                                 \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+			saip_stamps[2 * __COUNTER__] = __builtin_amdgcn_s_memtime();                   \
+			saip_stamps[2 * (__COUNTER__ - 1) + 1] = __LINE__;                             \
+		}                                                                                  \
+		__builtin_amdgcn_sched_barrier(0);                                                 \
+	} while (0)
+#elif defined(SAIP_NO_FENCE)
 #define PHASE_FENCE()
 #else
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -79,6 +91,19 @@ struct LaneSmem {
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
 	int flag, rank;
+};
+
+// Bounded inertia estimate as a rank-one correction.  M_BIE = M + sum_c delta_c e_c e_c^T with delta_c = max(0, thr - M_cc).
+// When at most one joint of the instance is clamped (the usual case: a light wrist joint),
+//   M_BIE^-1 = M^-1 - coef v v^T,  v = sum_c delta_c M^-1[:,c] (= delta m_c),  coef = 1 / (delta (1 + delta M^-1_cc)),
+// so Jh M_BIE^-1 Jh^T = A - coef t t^T with t = Jh v, and Lambda_mod follows from Lambda by Sherman-Morrison: no second
+// Cholesky of M and no second k x k inverse.  use_sm is wave-uniform; wavefronts holding an instance with two or more
+// clamped joints take the full path (M_BIE^-1 by Cholesky) for all their lanes.
+template <int N>
+struct BieRankOne {
+	double v[N];
+	double coef;
+	bool use_sm;
 };
 
 // Symmetric N x N matrix that lives either in registers or parked in LDS as N(N+1)/2 lane-interleaved rows (conflict-free).
@@ -133,7 +158,7 @@ __device__ __forceinline__ void spd_inv_reg(const double (&A)[R][R], double (&Ai
 // operationalSpaceMatrices in the range basis.  Jh: R x N (rows >= r_lane are zero).  Outputs Lambda, Lambda_mod, T1 = Jh Minv.
 template <int N, int R, bool INLDS>
 __device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const SymMat<N, INLDS>& Minv, const SymMat<N, INLDS>& MBinv,
-											   const int r_lane, const int decoupling, double (&Lam)[R][R], double (&Lmod)[R][R],
+											   const BieRankOne<N>& bie, const int r_lane, const int decoupling, double (&Lam)[R][R], double (&Lmod)[R][R],
 											   double (&T1)[R][N]) {
 	double A[R][R];
 	UNR for (int a = 0; a < R; a++)
@@ -158,6 +183,27 @@ __device__ __forceinline__ void opspace_lambda(const double (&Jh)[R][N], const S
 	} else if (decoupling == DEC_IMPEDANCE) {
 		UNR for (int a = 0; a < R; a++)
 			UNR for (int c = 0; c < R; c++) Lmod[a][c] = (a == c) ? 1.0 : 0.0;
+	} else if (bie.use_sm) {
+		// Lambda_mod = (A - coef t t^T)^-1 = Lambda + gamma (Lambda t)(Lambda t)^T,  gamma = coef / (1 - coef t^T Lambda t)
+		double t[R], lt[R], q = 0.0;
+		UNR for (int a = 0; a < R; a++) {
+			double sacc = 0.0;
+			UNR for (int j = 0; j < N; j++) sacc = fma(Jh[a][j], bie.v[j], sacc);
+			t[a] = sacc;
+		}
+		UNR for (int a = 0; a < R; a++) {
+			double sacc = 0.0;
+			UNR for (int c = 0; c < R; c++) sacc = fma(Lam[a][c], t[c], sacc);
+			lt[a] = sacc;
+			q = fma(t[a], sacc, q);
+		}
+		const double gamma = bie.coef / (1.0 - bie.coef * q);
+		UNR for (int a = 0; a < R; a++)
+			UNR for (int c = 0; c <= a; c++) {
+				const double val = fma(gamma * lt[a], lt[c], Lam[a][c]);
+				Lmod[a][c] = val;
+				Lmod[c][a] = val;
+			}
 	} else if (INLDS) {
 		double Tb[R][N];
 		UNR for (int a = 0; a < R; a++)
@@ -248,7 +294,7 @@ __device__ __forceinline__ void apply_task(const double (&Jh)[R][N], const doubl
 template <int N, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const SymMat<N, SMT::MINV_LDS>& Minv, const SymMat<N, SMT::MINV_LDS>& MBinv,
-		double (&Np)[N][N], double (&tau)[N], bool& singular) {
+		const BieRankOne<N>& bie, double (&Np)[N][N], double (&tau)[N], bool& singular) {
 	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
@@ -400,7 +446,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 	}
 	PHASE_FENCE();
 	double Lam[6][6], Lmod[6][6], T1[6][N];
-	opspace_lambda<N, 6, SMT::MINV_LDS>(Jh, Minv, MBinv, k, tk->decoupling, Lam, Lmod, T1);
+	opspace_lambda<N, 6, SMT::MINV_LDS>(Jh, Minv, MBinv, bie, k, tk->decoupling, Lam, Lmod, T1);
 
 	PHASE_FENCE();
 	tk = launder(tk);
@@ -483,7 +529,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 template <int N, int RJ, bool PF, bool GL, typename SMT>
 __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, const ModelCPtr md, const TaskCPtr tasks, const int t, const int lane, const int b,
 		const bool live, const bool first, const bool last, const SymMat<N, SMT::MINV_LDS>& Minv, const SymMat<N, SMT::MINV_LDS>& MBinv,
-		double (&Np)[N][N], double (&tau)[N], bool& singular) {
+		const BieRankOne<N>& bie, double (&Np)[N][N], double (&tau)[N], bool& singular) {
 	constexpr int LD = SMT::LD;
 	constexpr int P_Z = 0, P_O = 3 * N, P_CAP = 6 * N;
 	const size_t ld = P.ld;
@@ -610,7 +656,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 	}
 	PHASE_FENCE();
 	double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
-	opspace_lambda<N, RJ, SMT::MINV_LDS>(Jh, Minv, MBinv, r_lane, tk->decoupling, Lam, Lmod, T1);
+	opspace_lambda<N, RJ, SMT::MINV_LDS>(Jh, Minv, MBinv, bie, r_lane, tk->decoupling, Lam, Lmod, T1);
 
 	tk = launder(tk);
 	// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
@@ -691,6 +737,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	const ModelCPtr md = (ModelCPtr)P.model;
 	const TaskCPtr tasks = (TaskCPtr)P.tasks;
 	const size_t ld = P.ld;
+	PHASE_FENCE();
 
 	// ---------------------------------------------------------------- latency variant: every per-instance input is fetched up front
 	// (59 independent coalesced loads in flight at once, one wait) and parked in LDS; nothing below touches HBM again
@@ -709,6 +756,10 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	// ---------------------------------------------------------------- forward kinematics (ONE rolled loop over the joints: one code copy,
 	// short live ranges); joint axes/origins, per-body spatial inertias and the control frames are parked in LDS
 	double Minv[N][N], MBinv[N][N], taug[N];
+	BieRankOne<N> bie;
+	bie.coef = 0.0;
+	bie.use_sm = false;
+	UNR for (int i = 0; i < N; i++) bie.v[i] = 0.0;
 	{
 		double Mm[N][N];
 		if (LEAN) {
@@ -719,11 +770,13 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 		{
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+			double q_next = PF ? 0.0 : P.q[b];  // software pipeline: the joint angle of iteration j+1 is in flight during iteration j
 			_Pragma("unroll 1") for (int j = 0; j < N; j++) {
 				const double CONSTANT_AS* R0 = md->R0[j];
 				const double CONSTANT_AS* p0 = md->p0[j];
 				const double ax = md->axis[j][0], ay = md->axis[j][1], az = md->axis[j][2];
-				const double qj = PF ? sm.pf[j][lane] : P.q[(size_t)j * ld + b];
+				const double qj = PF ? sm.pf[j][lane] : q_next;
+				if (!PF) q_next = P.q[(size_t)(j + 1 < N ? j + 1 : j) * ld + b];
 				double Rt[9];
 				UNR for (int r = 0; r < 3; r++) o[r] += R[3 * r] * p0[0] + R[3 * r + 1] * p0[1] + R[3 * r + 2] * p0[2];
 				UNR for (int r = 0; r < 3; r++)
@@ -878,8 +931,25 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		spd_inv_reg<N>(Mm, Minv);
 		PHASE_FENCE();
 		if (P.any_bie) {  // M_BIE: diagonal clamped from below (SingularityHandler.cpp:176-182, JointTask.cpp:254-259)
-			UNR for (int i = 0; i < N; i++) Mm[i][i] = fmax(Mm[i][i], P.bie_thr);
-			spd_inv_reg<N>(Mm, MBinv);
+			double dsum = 0.0, dd = 0.0;
+			int nclamp = 0;
+			UNR for (int i = 0; i < N; i++) bie.v[i] = 0.0;
+			UNR for (int c = 0; c < N; c++) {
+				const double delta = fmax(P.bie_thr - Mm[c][c], 0.0);
+				nclamp += (delta > 0.0) ? 1 : 0;
+				dsum += delta;
+				dd = fma(delta, Minv[c][c], dd);
+				UNR for (int i = 0; i < N; i++) bie.v[i] = fma(delta, Minv[i][c], bie.v[i]);
+			}
+			bie.coef = (dsum > 0.0) ? 1.0 / (dsum * (1.0 + dd)) : 0.0;
+			bie.use_sm = !__any(nclamp > 1);
+			if (!bie.use_sm) {
+				UNR for (int i = 0; i < N; i++) Mm[i][i] = fmax(Mm[i][i], P.bie_thr);
+				spd_inv_reg<N>(Mm, MBinv);
+			} else {
+				UNR for (int i = 0; i < N; i++)
+					UNR for (int j = 0; j < N; j++) MBinv[i][j] = Minv[i][j];  // not read on the rank-one path
+			}
 		} else {
 			UNR for (int i = 0; i < N; i++)
 				UNR for (int j = 0; j < N; j++) MBinv[i][j] = Minv[i][j];
@@ -908,14 +978,14 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 
 	if (SIG == SIG_MF_JT) {
 		// the common stack (motion-force task + joint task in its nullspace), straight-line: no loop-carried N_prec
-		lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, MinvS, MBinvS, Np, tau, singular);
+		lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, 0, lane, b, live, true, false, MinvS, MBinvS, bie, Np, tau, singular);
 		PHASE_FENCE();
-		lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, MinvS, MBinvS, Np, tau, singular);
+		lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, 1, lane, b, live, false, true, MinvS, MBinvS, bie, Np, tau, singular);
 	} else {
 		_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 			const bool last = (t == P.nt - 1);
-			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, Np, tau, singular);
-			else lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, Np, tau, singular);
+			if (tasks[t].type == TASK_MOTION_FORCE) lane_motion_force_task<N, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, bie, Np, tau, singular);
+			else lane_joint_task<N, RJ, PF, GL, SM>(P, sm, md, tasks, t, lane, b, live, first, last, MinvS, MBinvS, bie, Np, tau, singular);
 			first = false;
 		}
 	}
@@ -960,6 +1030,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 			}
 		}
 	}
+	PHASE_FENCE();
 	if (live) {
 		UNR for (int j = 0; j < N; j++) {
 			double tv = tau[j];
@@ -969,6 +1040,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 		P.status[b] = singular ? 1 : 0;
 	}
+	PHASE_FENCE();
 }
 
 // Smallest instantiated joint-rank bound >= rj for each dof; 0 = not covered.
@@ -1017,4 +1089,9 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	return hipGetLastError();
 }
 
+#if defined(SAIP_STAMP)
+extern "C" int saip_debug_stamps(unsigned long long* out, int n) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps), sizeof(unsigned long long) * (n < 256 ? n : 256));
+}
+#endif
 }  // namespace saip
