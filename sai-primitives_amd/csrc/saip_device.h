@@ -13,6 +13,8 @@ struct ModelDev {
 	int n;
 	int pad_;
 	int jtype[SAIP_MAXN];        // 1 revolute, 2 prismatic
+	int axis_is_z[SAIP_MAXN];    // joint axis == (0,0,1) exactly: the joint rotation touches two columns only
+	int iso_inertia[SAIP_MAXN];  // body inertia tensor = i * identity: invariant under rotation
 	double R0[SAIP_MAXN][9];     // joint origin rotation (parent body frame -> joint frame at q=0), row-major
 	double p0[SAIP_MAXN][3];     // joint origin translation in the parent body frame
 	double axis[SAIP_MAXN][3];   // unit joint axis in the body frame
@@ -39,7 +41,7 @@ struct TaskDev {
 	int bm_identity;   // motion force: Bm == I6 (full task)
 	int pad0_;
 	double dt, bie_threshold, s_min, s_max, s_abs_tol;
-	double cert_kroot; // k^(-1/16): lower/upper bound ratio of the trace-power bound on lambda_max (lane kernel certificate)
+	double cert_kroot; // k^(-1/8): lower/upper bound ratio of the trace-power bound on lambda_max (singular-value certificate)
 	double pos[3];     // control point in the body frame
 	double rot[9];     // control frame rotation in the body frame
 	double Bm[36];     // 6 x 6 row-major, first k columns = orthonormal basis of range(P)

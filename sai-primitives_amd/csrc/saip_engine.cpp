@@ -219,6 +219,7 @@ extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* link
 			memcpy(M->dev.R0[j], Rl, sizeof(Rl));
 			memcpy(M->dev.p0[j], pl, sizeof(pl));
 			for (int i = 0; i < 3; i++) M->dev.axis[j][i] = L.axis[i] / an;
+			M->dev.axis_is_z[j] = (M->dev.axis[j][0] == 0.0 && M->dev.axis[j][1] == 0.0 && M->dev.axis[j][2] == 1.0) ? 1 : 0;
 			Inertial in;
 			inertial_add(in, L.mass, L.com, Il);
 			if (L.mass <= 0) memcpy(in.c, L.com, sizeof(in.c));
@@ -259,6 +260,7 @@ extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* link
 		M->dev.inertia[j][3] = in.I[1];
 		M->dev.inertia[j][4] = in.I[2];
 		M->dev.inertia[j][5] = in.I[5];
+		M->dev.iso_inertia[j] = (in.I[0] == in.I[4] && in.I[0] == in.I[8] && in.I[1] == 0.0 && in.I[2] == 0.0 && in.I[5] == 0.0) ? 1 : 0;
 	}
 	M->dev.gravity[0] = 0;
 	M->dev.gravity[1] = 0;
@@ -433,7 +435,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.ang_sat = M_PI / 3;
 	T.dev.force_axis[2] = T.dev.moment_axis[2] = 1.0;
 	T.dev.bm_identity = (pr == 3 && orr == 3) ? 1 : 0;
-	T.dev.cert_kroot = pow((double)T.dev.k, -1.0 / 16.0);
+	T.dev.cert_kroot = pow((double)T.dev.k, -1.0 / 8.0);
 	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:44-49
 		T.dev.kp_pos[i] = 100.0; T.dev.kv_pos[i] = 20.0; T.dev.ki_pos[i] = 0.0;
 		T.dev.kp_ori[i] = 200.0; T.dev.kv_ori[i] = 28.3; T.dev.ki_ori[i] = 0.0;

@@ -10,7 +10,7 @@
 // Same arithmetic contract as the general kernel (saip_kernel_wg.hip) and the reference lines cited there, with two
 // cheaper replacements for the reference's SVDs on the common, well-conditioned case:
 //   * SingularityHandler's branch predicate (sigma_i/sigma_0 >= s_max for all i, sigma_0 >= 1e-3) is CERTIFIED without an
-//     eigen-solve: lambda_max(G) <= u := ||G^8||_F^(1/8) (trace-power bound, three squarings of the 6 x 6 Gram matrix G),
+//     eigen-solve: lambda_max(G) <= u := ||G^4||_F^(1/4) (trace-power bound, two squarings of the 6 x 6 Gram matrix G),
 //     and G - s_max^2 u I > 0 is checked by an LDL^T sweep.  Both hold => fully non-singular branch, rigorously.
 //   * matrixRangeBasis(S N_prec) is an orthonormal basis from a column-pivoted Gram-Schmidt sweep, accepted only when the
 //     rank gap is clean (next pivot below 1e-10 of the first, or above 1e-2).
@@ -389,7 +389,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 				Gs[a][c] = G[a][c] * itr;
 				G2[a][c] = Gs[a][c];
 			}
-		UNR for (int rep = 0; rep < 3; rep++) {  // G2 <- G2^2: Gs^2, Gs^4, Gs^8
+		UNR for (int rep = 0; rep < 2; rep++) {  // G2 <- G2^2: Gs^2, Gs^4
 			UNR for (int a = 0; a < 6; a++)
 				UNR for (int c = 0; c <= a; c++) {
 					double s = 0.0;
@@ -402,10 +402,10 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 					G2[c][a] = Gt[a][c];
 				}
 		}
-		double t16 = 0.0;  // trace(Gs^16) = ||Gs^8||_F^2
+		double t8 = 0.0;  // trace(Gs^8) = ||Gs^4||_F^2
 		UNR for (int a = 0; a < 6; a++)
-			UNR for (int c = 0; c < 6; c++) t16 = fma(G2[a][c], G2[a][c], t16);
-		const double u = sqrt(sqrt(sqrt(sqrt(t16))));  // lambda_max(Gs) <= u <= k^(1/16) lambda_max(Gs)
+			UNR for (int c = 0; c < 6; c++) t8 = fma(G2[a][c], G2[a][c], t8);
+		const double u = sqrt(sqrt(sqrt(t8)));  // lambda_max(Gs) <= u <= k^(1/8) lambda_max(Gs)
 		const bool ok_s0 = (u * tk->cert_kroot * tr >= tk->s_abs_tol * tk->s_abs_tol);
 		const double shift = tk->s_max * tk->s_max * u;
 		// LDL^T pivots of Gs - shift I on the k x k block (padded diagonal entries are set to 1)
@@ -784,12 +784,20 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 				if (md->jtype[j] == 1) {
 					double s, c;
 					sincos_joint(qj, &s, &c);
-					const double v = 1.0 - c;
-					const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
-										  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
-										  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
-					UNR for (int r = 0; r < 3; r++)
-						UNR for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rt[3 * r] * Rq[cc] + Rt[3 * r + 1] * Rq[3 + cc] + Rt[3 * r + 2] * Rq[6 + cc];
+					if (md->axis_is_z[j]) {  // rotation about the local z axis mixes the first two columns only
+						UNR for (int r = 0; r < 3; r++) {
+							R[3 * r] = fma(c, Rt[3 * r], s * Rt[3 * r + 1]);
+							R[3 * r + 1] = fma(c, Rt[3 * r + 1], -s * Rt[3 * r]);
+							R[3 * r + 2] = Rt[3 * r + 2];
+						}
+					} else {
+						const double v = 1.0 - c;
+						const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+											  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+											  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+						UNR for (int r = 0; r < 3; r++)
+							UNR for (int cc = 0; cc < 3; cc++) R[3 * r + cc] = Rt[3 * r] * Rq[cc] + Rt[3 * r + 1] * Rq[3 + cc] + Rt[3 * r + 2] * Rq[6 + cc];
+					}
 				} else {
 					UNR for (int r = 0; r < 3; r++) o[r] += (Rt[3 * r] * ax + Rt[3 * r + 1] * ay + Rt[3 * r + 2] * az) * qj;
 					UNR for (int e = 0; e < 9; e++) R[e] = Rt[e];
@@ -801,15 +809,21 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 				{  // spatial inertia of body j about the world origin: m, h = m c, Io (xx yy zz xy xz yz)
 					const double CONSTANT_AS* I6 = md->inertia[j];
 					const double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
-					double RI[9], Iw[6], c3[3];
-					UNR for (int r = 0; r < 3; r++)
-						UNR for (int cc = 0; cc < 3; cc++) RI[3 * r + cc] = R[3 * r] * Il[cc] + R[3 * r + 1] * Il[3 + cc] + R[3 * r + 2] * Il[6 + cc];
-					Iw[0] = RI[0] * R[0] + RI[1] * R[1] + RI[2] * R[2];
-					Iw[1] = RI[3] * R[3] + RI[4] * R[4] + RI[5] * R[5];
-					Iw[2] = RI[6] * R[6] + RI[7] * R[7] + RI[8] * R[8];
-					Iw[3] = RI[0] * R[3] + RI[1] * R[4] + RI[2] * R[5];
-					Iw[4] = RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8];
-					Iw[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];
+					double Iw[6], c3[3];
+					if (md->iso_inertia[j]) {  // i * identity is invariant under the body rotation
+						Iw[0] = Iw[1] = Iw[2] = I6[0];
+						Iw[3] = Iw[4] = Iw[5] = 0.0;
+					} else {
+						double RI[9];
+						UNR for (int r = 0; r < 3; r++)
+							UNR for (int cc = 0; cc < 3; cc++) RI[3 * r + cc] = R[3 * r] * Il[cc] + R[3 * r + 1] * Il[3 + cc] + R[3 * r + 2] * Il[6 + cc];
+						Iw[0] = RI[0] * R[0] + RI[1] * R[1] + RI[2] * R[2];
+						Iw[1] = RI[3] * R[3] + RI[4] * R[4] + RI[5] * R[5];
+						Iw[2] = RI[6] * R[6] + RI[7] * R[7] + RI[8] * R[8];
+						Iw[3] = RI[0] * R[3] + RI[1] * R[4] + RI[2] * R[5];
+						Iw[4] = RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8];
+						Iw[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];
+					}
 					UNR for (int r = 0; r < 3; r++) c3[r] = o[r] + R[3 * r] * md->com[j][0] + R[3 * r + 1] * md->com[j][1] + R[3 * r + 2] * md->com[j][2];
 					const double m = md->mass[j], cc2 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
 					const double bd[10] = {m, m * c3[0], m * c3[1], m * c3[2], Iw[0] + m * (cc2 - c3[0] * c3[0]), Iw[1] + m * (cc2 - c3[1] * c3[1]),

@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			gemm<T>(sm.W[1], LD, Jh, LD, 1, Jh, 1, LD, k, n, k, tid);
 			SYNC();
 			// fast path: certify "sigma_i/sigma_0 >= s_max for all i and sigma_0 >= s_abs_tol" without an eigen-solve
-			// (trace-power bound lambda_max <= ||Gs^8||_F^(1/8) + LDL^T pivots of Gs - s_max^2 u I; see saip_kernel_lane.hip)
+			// (trace-power bound lambda_max <= ||Gs^4||_F^(1/4) + LDL^T pivots of Gs - s_max^2 u I; see saip_kernel_lane.hip)
 			bool sing = false;
 			{
 				double tr = 0.0;
@@ -302,17 +302,17 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					Ga[i * LD + j] = sm.W[1][i * LD + j] * itr;
 				}
 				SYNC();
-				for (int rep = 0; rep < 3; rep++) {
+				for (int rep = 0; rep < 2; rep++) {
 					gemm<T>(Gb, LD, Ga, LD, 1, Ga, LD, 1, k, k, k, tid);
 					SYNC();
 					double* t_ = Ga;
 					Ga = Gb;
 					Gb = t_;
 				}
-				double t16 = 0.0;
+				double t8 = 0.0;
 				for (int i = 0; i < k; i++)
-					for (int j = 0; j < k; j++) t16 = fma(Ga[i * LD + j], Ga[i * LD + j], t16);
-				const double u = sqrt(sqrt(sqrt(sqrt(t16))));
+					for (int j = 0; j < k; j++) t8 = fma(Ga[i * LD + j], Ga[i * LD + j], t8);
+				const double u = sqrt(sqrt(sqrt(t8)));
 				const bool ok_s0 = (u * tk.cert_kroot * tr >= tk.s_abs_tol * tk.s_abs_tol);
 				if (tid == 0) {  // LDL^T of Gs - shift I, in place in Gb (k <= 6: serial)
 					const double shift = tk.s_max * tk.s_max * u;
