@@ -120,6 +120,20 @@ def main():
     tau = ctrl.getTorques()
     ok = bool(np.isfinite(tau).all() and ctrl.status.sum() == 0)
     ok = ok and bool(torch.equal(gathered[rank], tau_t))
+    # cross-check of the timed kernel against the engine's other, independently written kernel (general workgroup-per-instance
+    # path) on the same resident inputs: catches a wrong-but-finite result without touching the oracle
+    xerr = None
+    if args.kernel != 1 and ctrl.kernelName() != "" and not ctrl.kernelName().startswith("saip_cycle_wg"):
+        timed_kernel = ctrl.kernelName()
+        ctrl.setKernel(1)
+        ctrl.stepAsync()
+        ctrl.synchronize()
+        tau_wg = ctrl.getTorques()
+        ctrl.setKernel(args.kernel)
+        ctrl.stepAsync()
+        ctrl.synchronize()
+        xerr = W.torque_error(tau, tau_wg)
+        ok = ok and xerr < 1e-7 and ctrl.kernelName() == timed_kernel
 
     if rank == 0:
         traffic = args.traffic
@@ -158,7 +172,7 @@ def main():
                          "avg_launch_us": launch_s * 1e6, "kernel": ctrl.kernelName()},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_cycle": byts, "traffic": traffic},
-            "max_abs_tau": float(np.abs(tau).max()), "valid": ok,
+            "max_abs_tau": float(np.abs(tau).max()), "valid": ok, "cross_kernel_max_rel_err": xerr,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(d)

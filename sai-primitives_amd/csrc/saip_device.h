@@ -8,6 +8,15 @@
 
 namespace saip {
 
+// everything the forward-kinematics loop needs about ONE joint/body, packed into four consecutive 64-byte lines so that the
+// rolled loop of the lane kernel issues one burst of scalar loads per iteration (and a prewarm pass can touch all of it up front)
+struct alignas(256) JointRec {
+	double R0[9], p0[3], axis[3], com[3], inertia[6], mass;
+	int jtype, axis_is_z, iso_inertia, pad_;
+	double pad2_[5];
+};
+static_assert(sizeof(JointRec) == 256, "JointRec must be exactly four cache lines");
+
 // one movable body of the serial chain (fixed links already merged on the host, engine.cpp: merge_fixed_links)
 struct ModelDev {
 	int n;
@@ -24,6 +33,8 @@ struct ModelDev {
 	double effort[SAIP_MAXN];
 	double q_lower[SAIP_MAXN], q_upper[SAIP_MAXN], vel_limit[SAIP_MAXN];  // jointLimits(), used by the joint-limit-avoidance wrap
 	double gravity[3];
+	double pad_align_[5];
+	JointRec jrec[SAIP_MAXN];    // packed copy of the per-joint constants above (lane kernel FK loop)
 };
 
 enum { TASK_JOINT = 2, TASK_MOTION_FORCE = 3 };

@@ -265,6 +265,18 @@ extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* link
 	M->dev.gravity[0] = 0;
 	M->dev.gravity[1] = 0;
 	M->dev.gravity[2] = -9.81;
+	for (int j = 0; j < M->n; j++) {  // packed per-joint records
+		saip::JointRec& r = M->dev.jrec[j];
+		memcpy(r.R0, M->dev.R0[j], sizeof(r.R0));
+		memcpy(r.p0, M->dev.p0[j], sizeof(r.p0));
+		memcpy(r.axis, M->dev.axis[j], sizeof(r.axis));
+		memcpy(r.com, M->dev.com[j], sizeof(r.com));
+		memcpy(r.inertia, M->dev.inertia[j], sizeof(r.inertia));
+		r.mass = M->dev.mass[j];
+		r.jtype = M->dev.jtype[j];
+		r.axis_is_z = M->dev.axis_is_z[j];
+		r.iso_inertia = M->dev.iso_inertia[j];
+	}
 	*out = M;
 	return SAIP_OK;
 }

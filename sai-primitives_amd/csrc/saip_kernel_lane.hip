@@ -88,6 +88,7 @@ struct LaneSmem {
 	double park[PARK][64];
 	static constexpr bool MINV_LDS = !LEAN;              // latency variant: M^-1 and M_BIE^-1 parked in LDS, rows streamed on use
 	double minv[MINV_LDS ? N * (N + 1) : 1][64];        // two symmetric matrices, N(N+1)/2 rows each
+	double qsh[N][64];                                   // joint angles, fetched with one exposed memory latency for the rolled FK loop
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
 	int flag, rank;
@@ -737,6 +738,23 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	const ModelCPtr md = (ModelCPtr)P.model;
 	const TaskCPtr tasks = (TaskCPtr)P.tasks;
 	const size_t ld = P.ld;
+#ifndef SAIP_NO_PREWARM
+	{
+		// warm the scalar cache: one double of every 64-byte line of the per-joint records and of the head of the task constants,
+		// all loads in flight at once (one exposed L2 latency) instead of one cold miss per FK iteration / per task phase
+		double acc = 0.0;
+		UNR for (int j = 0; j < N; j++) {
+			const JointRec CONSTANT_AS* jr = md->jrec + j;
+			acc += jr->R0[0] + jr->R0[8] + jr->inertia[0] + jr->mass;
+		}
+		for (int t = 0; t < P.nt; t++) {
+			const TaskCPtr tk = tasks + t;
+			acc += tk->dt + tk->rot[0] + tk->Bm[0] + tk->Bm[8] + tk->Bm[16] + tk->Bm[24] + tk->Bm[32] + tk->Ppos[4] + tk->sig_p[0] + tk->sig_o[0] +
+				   tk->kp_pos[0] + tk->kp_ori[2] + tk->kp[0] + tk->kp[8];
+		}
+		asm volatile("" ::"s"(acc));
+	}
+#endif
 	PHASE_FENCE();
 
 	// ---------------------------------------------------------------- latency variant: every per-instance input is fetched up front
@@ -770,21 +788,25 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		}
 		{
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-			double q_next = PF ? 0.0 : P.q[b];  // software pipeline: the joint angle of iteration j+1 is in flight during iteration j
+			if (!PF) {  // all joint angles in flight at once (one exposed HBM latency instead of one per loop iteration)
+				double qv[N];
+				UNR for (int j = 0; j < N; j++) qv[j] = P.q[(size_t)j * ld + b];
+				UNR for (int j = 0; j < N; j++) sm.qsh[j][lane] = qv[j];
+			}
 			_Pragma("unroll 1") for (int j = 0; j < N; j++) {
-				const double CONSTANT_AS* R0 = md->R0[j];
-				const double CONSTANT_AS* p0 = md->p0[j];
-				const double ax = md->axis[j][0], ay = md->axis[j][1], az = md->axis[j][2];
-				const double qj = PF ? sm.pf[j][lane] : q_next;
-				if (!PF) q_next = P.q[(size_t)(j + 1 < N ? j + 1 : j) * ld + b];
+				const JointRec CONSTANT_AS* jr = md->jrec + j;
+				const double CONSTANT_AS* R0 = jr->R0;
+				const double CONSTANT_AS* p0 = jr->p0;
+				const double ax = jr->axis[0], ay = jr->axis[1], az = jr->axis[2];
+				const double qj = PF ? sm.pf[j][lane] : sm.qsh[j][lane];
 				double Rt[9];
 				UNR for (int r = 0; r < 3; r++) o[r] += R[3 * r] * p0[0] + R[3 * r + 1] * p0[1] + R[3 * r + 2] * p0[2];
 				UNR for (int r = 0; r < 3; r++)
 					UNR for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * R0[c] + R[3 * r + 1] * R0[3 + c] + R[3 * r + 2] * R0[6 + c];
-				if (md->jtype[j] == 1) {
+				if (jr->jtype == 1) {
 					double s, c;
 					sincos_joint(qj, &s, &c);
-					if (md->axis_is_z[j]) {  // rotation about the local z axis mixes the first two columns only
+					if (jr->axis_is_z) {  // rotation about the local z axis mixes the first two columns only
 						UNR for (int r = 0; r < 3; r++) {
 							R[3 * r] = fma(c, Rt[3 * r], s * Rt[3 * r + 1]);
 							R[3 * r + 1] = fma(c, Rt[3 * r + 1], -s * Rt[3 * r]);
@@ -807,10 +829,10 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 					sm.park[P_O + 3 * j + r][lane] = o[r];
 				}
 				{  // spatial inertia of body j about the world origin: m, h = m c, Io (xx yy zz xy xz yz)
-					const double CONSTANT_AS* I6 = md->inertia[j];
+					const double CONSTANT_AS* I6 = jr->inertia;
 					const double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
 					double Iw[6], c3[3];
-					if (md->iso_inertia[j]) {  // i * identity is invariant under the body rotation
+					if (jr->iso_inertia) {  // i * identity is invariant under the body rotation
 						Iw[0] = Iw[1] = Iw[2] = I6[0];
 						Iw[3] = Iw[4] = Iw[5] = 0.0;
 					} else {
@@ -824,8 +846,8 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 						Iw[4] = RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8];
 						Iw[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];
 					}
-					UNR for (int r = 0; r < 3; r++) c3[r] = o[r] + R[3 * r] * md->com[j][0] + R[3 * r + 1] * md->com[j][1] + R[3 * r + 2] * md->com[j][2];
-					const double m = md->mass[j], cc2 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
+					UNR for (int r = 0; r < 3; r++) c3[r] = o[r] + R[3 * r] * jr->com[0] + R[3 * r + 1] * jr->com[1] + R[3 * r + 2] * jr->com[2];
+					const double m = jr->mass, cc2 = c3[0] * c3[0] + c3[1] * c3[1] + c3[2] * c3[2];
 					const double bd[10] = {m, m * c3[0], m * c3[1], m * c3[2], Iw[0] + m * (cc2 - c3[0] * c3[0]), Iw[1] + m * (cc2 - c3[1] * c3[1]),
 										   Iw[2] + m * (cc2 - c3[2] * c3[2]), Iw[3] - m * c3[0] * c3[1], Iw[4] - m * c3[0] * c3[2], Iw[5] - m * c3[1] * c3[2]};
 					if (!LEAN) {
