@@ -123,7 +123,8 @@ def main():
     # cross-check of the timed kernel against the engine's other, independently written kernel (general workgroup-per-instance
     # path) on the same resident inputs: catches a wrong-but-finite result without touching the oracle
     xerr = None
-    if args.kernel != 1 and ctrl.kernelName() != "" and not ctrl.kernelName().startswith("saip_cycle_wg"):
+    stateful = any(np.any(np.asarray(t.get(k, 0.0)) != 0) for t in d["tasks"] for k in ("ki", "ki_pos", "ki_ori"))  # integrators advance per step
+    if not stateful and args.kernel != 1 and ctrl.kernelName() != "" and not ctrl.kernelName().startswith("saip_cycle_wg"):
         timed_kernel = ctrl.kernelName()
         ctrl.setKernel(1)
         ctrl.stepAsync()
