@@ -559,6 +559,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 		}
 		double c0 = 1.0;
 		bool going = true;
+		bool pending = false;  // an ambiguous pivot was met: keep sweeping, the full-row-rank certificate below decides
 		UNR for (int s = 0; s <= RJ; s++) {
 			double cn[N], best = -1.0, frob2 = 0.0;
 			UNR for (int j = 0; j < N; j++) {
@@ -575,8 +576,15 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				else if (best < 1e-5) { going = false; need_exact = true; }
 			} else if (going) {
 				const double ratio = best / c0;
-				if (ratio < 1e-20) going = false;                              // numerically exact rank
-				else if (ratio < 1e-4 || s == RJ) { going = false; need_exact = true; }  // ambiguous gap / bound exceeded: exact path decides
+				if (ratio < 1e-20) {  // numerically exact rank; ambiguous pivots before it are only certifiable when every row was kept
+					going = false;
+					need_exact = need_exact || (pending && s < m);
+				} else if (s == RJ) {  // rank bound exceeded: exact path decides
+					going = false;
+					need_exact = true;
+				} else if (ratio < 1e-4) {
+					pending = true;  // ambiguous gap: continue, see the certificate after the sweep
+				}
 			}
 			if (s < RJ) {
 				double pv[N], pbest = -1.0;
@@ -599,6 +607,42 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				}
 				if (going) r_lane = s + 1;
 			}
+		}
+		// Ambiguous pivots but every row direction kept (r == m): the reference keeps them too (matrixRangeBasis returns the
+		// identity) iff sigma_min/sigma_0 >= 1e-3.  Certified by lambda_min(Jp Jp^T) > 1e-6 trace(Jp Jp^T) >= 1e-6 sigma_0^2
+		// (LDL^T pivots of the shifted Gram matrix); any orthonormal basis of the full row space is then exact (invariance).
+		if (__any(pending && !need_exact)) {
+			bool cert = (r_lane == m);
+			double G[N][N];
+			{
+				double Jp[N][N];
+				UNR for (int i = 0; i < N; i++)
+					UNR for (int j = 0; j < N; j++) {
+						double sacc = 0.0;
+						UNR for (int l = 0; l < N; l++) sacc = fma((i < m) ? tk->S[i * N + l] : 0.0, Np[l][j], sacc);
+						Jp[i][j] = sacc;
+					}
+				double trg = 0.0;
+				UNR for (int a = 0; a < N; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						double sacc = 0.0;
+						UNR for (int j = 0; j < N; j++) sacc = fma(Jp[a][j], Jp[c][j], sacc);
+						G[a][c] = sacc;
+						if (a == c) trg += sacc;
+					}
+				const double shift = 1e-6 * trg;
+				UNR for (int a = 0; a < N; a++) G[a][a] = (a < m) ? G[a][a] - shift : 1.0;
+			}
+			UNR for (int kk = 0; kk < N; kk++) {
+				const double dpv = G[kk][kk];
+				cert = cert && (dpv > 0.0);
+				const double id = 1.0 / dpv;
+				UNR for (int i = kk + 1; i < N; i++) {
+					const double lik = G[i][kk] * id;
+					UNR for (int j = kk + 1; j <= i; j++) G[i][j] = fma(-lik, G[j][kk], G[i][j]);
+				}
+			}
+			if (pending && !cert) need_exact = true;
 		}
 	}
 	// exact path (rare): Gram eigen-decomposition by the whole wavefront, reference tolerance semantics

@@ -3,7 +3,9 @@ sys.path.insert(0, os.getcwd())
 import workloads as W
 from sai_primitives_amd.controller import controller_from_specs
 import sai_primitives_amd as sp
-d = W.make_inputs(2, 4096)
+import os
+cfg = int(os.environ.get("CFG", "2"))
+d = W.make_inputs(cfg, 4096)
 robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], 4096, device=0)
 robot.setQ(d["q"]); robot.setDq(d["dq"]); robot.updateModel(); ctrl.setGoals(d["goals"])
 ctrl.timeSteps(50, 0)
