@@ -221,3 +221,42 @@ def test_joint_limit_avoidance_full_size():
     ctrl.enableJointLimitAvoidance(False)
     tau0 = ctrl.computeControlTorques()
     assert (np.abs(tau0[ok] - tau[ok]).max(axis=1) > 1e-6).mean() > 0.5
+
+
+def test_closed_loop_tracking_toy_integrator():
+    """behavioural check of SURVEY 8(c)(iii): driving 64 Pandas with the engine's torques in a toy semi-implicit Euler loop
+    (zero gravity, dynamics M(q) ddq = tau from the NumPy model) brings the end-effector to its goal and holds the posture
+    task's nullspace motion bounded -- the scenario of examples/05-using_robot_controller (:150-207) without graphics."""
+    d = W.make_inputs(2, 64)
+    model = d["model"]
+    robot, ctrl, tasks = _engine(model.name, d["tasks"], 64)
+    q, dq = d["q"].copy(), np.zeros_like(d["dq"])
+    robot.setQ(q)
+    robot.setDq(dq)
+    robot.updateModel()
+    ctrl.reinitializeTasks()
+    li = model.link_index("end-effector")
+    fr = W.fk(model, q)
+    x0 = fr[li][1] + fr[li][0] @ np.array([0, 0, 0.07])
+    x_goal = x0 + np.array([0.03, -0.02, 0.02])
+    tasks[0].setGoalPosition(x_goal)
+    dt = 1e-3
+    err0 = np.linalg.norm(x_goal - x0, axis=1).max()
+    for step in range(600):
+        robot.setQ(q)
+        robot.setDq(dq)
+        robot.updateModel()
+        ctrl.updateControllerTaskModels()
+        tau = ctrl.computeControlTorques()
+        ok = ctrl.status == 0
+        assert ok.mean() > 0.9  # a few instances may wander into the singular band; they are flagged, not wrong
+        tau = np.where(ok[:, None], tau, 0.0)
+        M = W.mass_matrix(model, W.fk(model, q))
+        ddq = np.linalg.solve(M, tau[..., None])[..., 0]
+        dq = dq + dt * ddq
+        q = q + dt * dq
+    fr = W.fk(model, q)
+    x = fr[li][1] + fr[li][0] @ np.array([0, 0, 0.07])
+    err = np.linalg.norm(x_goal - x, axis=1)[ok]
+    print("closed loop: initial error", err0, "final max error", err.max())
+    assert err.max() < 0.1 * err0
