@@ -10,10 +10,41 @@ namespace saip {
 
 enum { GEMM_SET = 0, GEMM_I_MINUS = 1, GEMM_ADD = 2, GEMM_SUB = 3 };
 
+typedef double saip_f64x4 __attribute__((ext_vector_type(4)));
+
 // C(m x p) (op)= A(m x k) * B(k x p); A(i,l) = A[i*ars + l*acs], B(l,j) = B[l*brs + j*bcs]  (strides express transposes)
+// Four-wavefront workgroups (dof > 8) run products with at least 128 outputs on the FP64 matrix cores: the <= 32 x 32 result is
+// four 16 x 16 tiles, one per wavefront, accumulated by v_mfma_f64_16x16x4_f64 over k in steps of 4 (operands straight from LDS,
+// zero-filled outside the matrix).  f64 MFMA layout (cdna_hip_programming.md:160-161): A[l&15][l>>4], B[l>>4][l&15], D[(l>>4)+4r][l&15].
 template <int T>
 __device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ars, int acs, const double* Bm, int brs, int bcs,
 									 int m, int k, int p, int tid, int mode = GEMM_SET) {
+	if (T == 256 && m * p >= 128) {
+		const int wave = tid >> 6, lane = tid & 63;
+		const int r0 = 16 * (wave >> 1), c0 = 16 * (wave & 1);
+		if (r0 < m && c0 < p) {  // wave-uniform
+			saip_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+			const int ar = r0 + (lane & 15), bc = c0 + (lane & 15), kq = lane >> 4;
+			for (int kk = 0; kk < k; kk += 4) {
+				const int kx = kk + kq;
+				const double a = (ar < m && kx < k) ? A[ar * ars + kx * acs] : 0.0;
+				const double b = (kx < k && bc < p) ? Bm[kx * brs + bc * bcs] : 0.0;
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+			}
+			for (int r = 0; r < 4; r++) {
+				const int i = r0 + (lane >> 4) + 4 * r, j = bc;
+				if (i < m && j < p) {
+					const double s = acc[r];
+					double* c = C + i * ldc + j;
+					if (mode == GEMM_SET) *c = s;
+					else if (mode == GEMM_I_MINUS) *c = (i == j ? 1.0 : 0.0) - s;
+					else if (mode == GEMM_ADD) *c += s;
+					else *c -= s;
+				}
+			}
+		}
+		return;
+	}
 	for (int e = tid; e < m * p; e += T) {
 		int i = e / p, j = e - i * p;
 		double s = 0.0;
