@@ -28,6 +28,20 @@
 #include "saip_law.h"
 #include "saip_wg_linalg.h"
 
+#if defined(SAIP_STAMP_WG)
+// diagnostic build only (never shipped): s_memtime stamp of block 0 / thread 0 after every barrier of the kernel body
+__device__ unsigned long long saip_stamps_wg[512];
+#undef SYNC
+#define SYNC()                                                                 \
+	do {                                                                       \
+		__syncthreads();                                                       \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                             \
+			saip_stamps_wg[2 * __COUNTER__] = __builtin_amdgcn_s_memtime();    \
+			saip_stamps_wg[2 * (__COUNTER__ - 1) + 1] = __LINE__;              \
+		}                                                                      \
+	} while (0)
+#endif
+
 namespace saip {
 
 template <int NMAX>
@@ -361,31 +375,45 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			// acceptance rule (next pivot below 1e-10 or above 1e-2 of the first); the deflation coefficients are the rows of U^T Jp.
 			bool need_exact = false;
 			{
+				// Thread (j, g) = (tid % NMAX, tid / NMAX) owns column j, rows g, g+G, ...: column norms and deflation dot products are
+				// G-way partial sums through LDS, the arg-max is a butterfly inside each NMAX-lane group (every thread gets the same
+				// pivot, so no broadcast barrier) -> two barriers per accepted column.
+				constexpr int G = T / NMAX;
 				double* Wc = sm.W[5];
+				double* pn = sm.W[1];            // [G][NMAX] partial squared column norms
+				double* pd = sm.W[1] + T;        // [G][NMAX] partial deflation dot products
 				const int rb = P.rank_bound[t] < m ? P.rank_bound[t] : m;
-				for (int e = tid; e < m * n; e += T) {
-					int i = e / n, j = e - i * n;
-					Wc[i * LD + j] = Jp[i * LD + j];
+				const int cj = tid % NMAX, cg = tid / NMAX;
+				{
+					double acc = 0.0;
+					if (cj < n)
+						for (int i = cg; i < m; i += G) {
+							const double v = Jp[i * LD + cj];
+							Wc[i * LD + cj] = v;
+							acc = fma(v, v, acc);
+						}
+					pn[tid] = acc;
 				}
 				SYNC();
 				double c0 = 1.0;
 				bool going = true;
 				int rank = 0;
 				for (int s = 0; s <= rb; s++) {
-					for (int j = tid; j < n; j += T) {
-						double a = 0.0;
-						for (int i = 0; i < m; i++) a = fma(Wc[i * LD + j], Wc[i * LD + j], a);
-						sm.v0[j] = a;
-					}
-					SYNC();
 					double best = -1.0, frob2 = 0.0;
-					int jb = 0;
-					for (int j = 0; j < n; j++) {
-						const double a = sm.v0[j];
-						frob2 += a;
-						if (a > best) {
-							best = a;
-							jb = j;
+					int jb = cj;
+					if (cj < n) {
+						double a = 0.0;
+						for (int g = 0; g < G; g++) a += pn[g * NMAX + cj];
+						best = a;
+						frob2 = a;
+					}
+					for (int off = 1; off < NMAX; off <<= 1) {
+						const double ob = __shfl_xor(best, off);
+						const int oj = __shfl_xor(jb, off);
+						frob2 += __shfl_xor(frob2, off);
+						if (ob > best || (ob == best && oj < jb)) {
+							best = ob;
+							jb = oj;
 						}
 					}
 					if (s == 0) {
@@ -399,22 +427,31 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					}
 					if (!going || s == rb) break;
 					const double inv = rsqrt(best);
-					for (int i = tid; i < m; i += T) {
-						const double u = Wc[i * LD + jb] * inv;
-						sm.W[3][i * LD + s] = u;  // U[:, s]
-						sm.v1[i] = u;
+					{
+						double acc = 0.0;
+						if (cj < n)
+							for (int i = cg; i < m; i += G) acc = fma(Wc[i * LD + jb], Wc[i * LD + cj], acc);
+						pd[tid] = acc * inv;
+					}
+					if (tid < m) {
+						const double u = Wc[tid * LD + jb] * inv;
+						sm.W[3][tid * LD + s] = u;  // U[:, s]
+						sm.v1[tid] = u;
 					}
 					SYNC();
-					for (int j = tid; j < n; j += T) {
-						double d = 0.0;
-						for (int i = 0; i < m; i++) d = fma(sm.v1[i], Wc[i * LD + j], d);
-						Jh[s * LD + j] = d;  // row s of U^T Jp
-						sm.v2[j] = d;
-					}
-					SYNC();
-					for (int e = tid; e < m * n; e += T) {
-						int i = e / n, j = e - i * n;
-						Wc[i * LD + j] = fma(-sm.v1[i], sm.v2[j], Wc[i * LD + j]);
+					{
+						double acc = 0.0;
+						if (cj < n) {
+							double d = 0.0;
+							for (int g = 0; g < G; g++) d += pd[g * NMAX + cj];
+							if (cg == 0) Jh[s * LD + cj] = d;  // row s of U^T Jp
+							for (int i = cg; i < m; i += G) {
+								const double v = fma(-sm.v1[i], d, Wc[i * LD + cj]);
+								Wc[i * LD + cj] = v;
+								acc = fma(v, v, acc);
+							}
+						}
+						pn[tid] = acc;
 					}
 					SYNC();
 					rank = s + 1;
@@ -790,4 +827,9 @@ hipError_t launch_reinit(const CycleParams& P, hipStream_t stream) {
 	return hipGetLastError();
 }
 
+#if defined(SAIP_STAMP_WG)
+extern "C" int saip_debug_stamps_wg(unsigned long long* out, int n) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_wg), sizeof(unsigned long long) * (n < 512 ? n : 512));
+}
+#endif
 }  // namespace saip

@@ -57,49 +57,41 @@ __device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ar
 	}
 }
 
-// Aout = Ain^-1 for a symmetric positive definite n x n matrix.  WL, WX: n x n work (ld), dv: n doubles.
-// Cholesky (right-looking, 2 barriers per column) -> L^-1 by column-parallel forward substitution -> L^-T L^-1.
+// Aout = Ain^-1 for a symmetric positive definite n x n matrix.  WL, WX: n x n work (ld); none of the four may alias.
+// Symmetric sweep operator: sweeping pivot k maps  a_kk -> -1/a_kk,  a_ik -> a_ik/a_kk,  a_ij -> a_ij - a_ik a_kj / a_kk;
+// after all n pivots (each a positive Schur-complement diagonal) the matrix is -A^-1.  Every step is one full-matrix
+// rank-one update by all T threads reading the previous buffer and writing the other one: ONE barrier per pivot, no
+// serial triangular solves.  The product a_ik*a_kj is formed first so that (i,j) and (j,i) stay bitwise equal.
+// n <= 8 for the one-wavefront variant, n <= 32 for the four-wavefront variant: at most EPT elements per thread, whose (i, j) are
+// fixed across pivots and computed once.
 template <int T>
-__device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double* WX, double* dv, int n, int ld, int tid) {
-	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
-		WL[i * ld + j] = Ain[i * ld + j];
+__device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double* WX, double* /*dv*/, int n, int ld, int tid) {
+	constexpr int EPT = (T == 64) ? 1 : 4;
+	int ei[EPT], ej[EPT];
+	for (int r = 0; r < EPT; r++) {
+		const int e = tid + r * T;
+		ei[r] = e < n * n ? e / n : -1;
+		ej[r] = e - ei[r] * n;
 	}
-	SYNC();
+	const double* src = Ain;
 	for (int k = 0; k < n; k++) {
-		double d = sqrt(WL[k * ld + k]);
-		double rd = 1.0 / d;
-		for (int i = k + 1 + tid; i < n; i += T) WL[i * ld + k] *= rd;
-		if (tid == 0) dv[k] = d;
-		SYNC();
-		int rem = n - k - 1;
-		for (int e = tid; e < rem * rem; e += T) {
-			int a = e / rem, b = e - a * rem;
-			if (b <= a) {
-				int i = k + 1 + a, j = k + 1 + b;
-				WL[i * ld + j] = fma(-WL[i * ld + k], WL[j * ld + k], WL[i * ld + j]);
-			}
+		const bool last = (k == n - 1);
+		double* dst = last ? Aout : ((k & 1) ? WX : WL);
+		const double sgn = last ? -1.0 : 1.0;
+		const double rd = 1.0 / src[k * ld + k];
+#pragma unroll
+		for (int r = 0; r < EPT; r++) {
+			const int i = ei[r], j = ej[r];
+			if (i < 0) continue;
+			const double aik = src[i * ld + k], akj = src[k * ld + j], aij = src[i * ld + j];
+			double v = fma(-(aik * akj), rd, aij);
+			if (i == k) v = (j == k) ? -rd : akj * rd;
+			else if (j == k) v = aik * rd;
+			dst[i * ld + j] = sgn * v;
 		}
 		SYNC();
+		src = dst;
 	}
-	// X = L^-1 (lower); thread c owns column c
-	for (int c = tid; c < n; c += T) {
-		WX[c * ld + c] = 1.0 / dv[c];
-		for (int i = c + 1; i < n; i++) {
-			double s = 0.0;
-			for (int k = c; k < i; k++) s = fma(WL[i * ld + k], WX[k * ld + c], s);
-			WX[i * ld + c] = -s / dv[i];
-		}
-	}
-	SYNC();
-	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
-		int k0 = i > j ? i : j;
-		double s = 0.0;
-		for (int k = k0; k < n; k++) s = fma(WX[k * ld + i], WX[k * ld + j], s);
-		Aout[i * ld + j] = s;
-	}
-	SYNC();
 }
 
 // Symmetric eigen-decomposition by parallel-ordered (round-robin) Jacobi: A -> diag (eigenvalues), V (optional) <- eigenvectors.
