@@ -4,11 +4,11 @@ Same class and method names as the reference (camelCase kept on purpose so that 
 /root/reference/examples/05-using_robot_controller/05-using_robot_controller.cpp:103-196), with every
 per-robot Eigen vector replaced by a (B, size) NumPy array.  Differences from the reference, all loud:
   * one SaiModel object = B robot instances of the same robot (state arrays are (B, dof));
-  * the internal OTG is ENABLED by default like in the reference, but not implemented on the device:
-    computeControlTorques raises until disableInternalOtg() is called on every task;
-  * singular / blended SingularityHandler branches, velocity saturation, closed-loop force control and the
-    JointLimitAvoidance torques are "next" rows: requesting them raises SaipUnsupported; instances that
-    leave the non-singular branch get status 1 and NaN torques.
+  * the internal OTG is ENABLED by default like in the reference.  JointTask: the acceleration-limited OTG (the reference
+    default mode) runs on the device; the jerk-limited mode raises SaipUnsupported.  MotionForceTask: the Cartesian OTG is
+    not on the device yet, computeControlTorques raises until disableInternalOtg() is called on those tasks;
+  * singular / blended SingularityHandler branches and closed-loop force control are "next" rows: requesting them raises
+    SaipUnsupported; instances that leave the non-singular branch get status 1 and NaN torques.
 """
 from __future__ import annotations
 
@@ -146,6 +146,7 @@ class _Task:
 
     def __init__(self, robot: SaiModel, task_name: str, loop_timestep: float):
         self._robot, self._name, self._dt = robot, task_name, float(loop_timestep)
+        self._otg_enabled = True  # reference default (JointTask.h:38, MotionForceTask.h:67)
         self._ctrl = None
         self._id = -1
         self._pending = []  # configuration calls issued before the controller exists
@@ -187,13 +188,21 @@ class _Task:
         self._cfg("saip_batch_set_bie_threshold", float(thr))
 
     def disableInternalOtg(self):
+        self._otg_enabled = False
         self._cfg("saip_batch_set_internal_otg", 0)
 
     def enableInternalOtgAccelerationLimited(self, *a):
+        """MotionForceTask (max_lin_vel, max_lin_acc, max_ang_vel, max_ang_acc): not on the device yet -> raises at the next cycle"""
         self._cfg("saip_batch_set_internal_otg", 1)
 
     def enableInternalOtgJerkLimited(self, *a):
-        self._cfg("saip_batch_set_internal_otg", 1)
+        """third-order (jerk-limited) Ruckig profiles are not implemented on the device"""
+        z = np.zeros(1)
+        self._keepalive.append(z)
+        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(z), _dptr(z), _dptr(z), 1)
+
+    def getInternalOtgEnabled(self):
+        return self._otg_enabled
 
     def enableVelocitySaturation(self, *values):
         """MotionForceTask: (linear_vel_sat, angular_vel_sat); JointTask: (value) or (vector of task dof); () keeps the defaults"""
@@ -213,13 +222,13 @@ class _Task:
 
     def _set_field(self, first, comps, value, what):
         ctrl = self._need_ctrl()
-        a = _soa(value, ctrl.batch_size, comps, what)
+        a = _soa(value, ctrl._robot.batch_size, comps, what)
         capi.check(capi.lib().saip_batch_set_goal_field_host(ctrl._h, self._id, first, comps, _dptr(a)))
 
     def _get_goal(self):
         ctrl = self._need_ctrl()
         gs = capi.lib().saip_batch_goal_components(ctrl._h, self._id)
-        out = np.empty((gs, ctrl.batch_size))
+        out = np.empty((gs, ctrl._robot.batch_size))
         capi.check(capi.lib().saip_batch_get_goal_host(ctrl._h, self._id, _dptr(out)))
         return out.T.copy()
 
@@ -227,9 +236,9 @@ class _Task:
         """(B, dof, dof) nullspace projector N of this task for the current state (TemplateTask.h:71-77)"""
         ctrl = self._need_ctrl()
         n = self._robot.dof()
-        out = np.empty((n * n, ctrl.batch_size))
+        out = np.empty((n * n, ctrl._robot.batch_size))
         capi.check(capi.lib().saip_batch_get_task_nullspace_host(ctrl._h, self._id, _dptr(out)))
-        return out.T.reshape(ctrl.batch_size, n, n).copy()
+        return out.T.reshape(ctrl._robot.batch_size, n, n).copy()
 
 
 class MotionForceTask(_Task):
@@ -384,6 +393,42 @@ class JointTask(_Task):
 
     def setGains(self, kp, kv, ki=0.0):  # JointTask.h:237-257
         self._gains("saip_batch_set_joint_gains", kp, kv, ki)
+
+    # internal OTG, JointTask.h:272-327.  Acceleration-limited mode (the reference default) runs on the device.
+    def enableInternalOtgAccelerationLimited(self, max_velocity=np.pi / 3.0, max_acceleration=2.0 * np.pi):
+        v, a = np.atleast_1d(np.asarray(max_velocity, float)), np.atleast_1d(np.asarray(max_acceleration, float))
+        m = self.getTaskDof()
+        if v.shape != a.shape or v.ndim != 1 or v.shape[0] not in (1, m):  # JointTask.cpp:367-373
+            raise ValueError("max velocity or max acceleration vector size not consistent with task dof in JointTask::enableInternalOtgAccelerationLimited")
+        v, a = np.ascontiguousarray(v), np.ascontiguousarray(a)
+        self._keepalive.append((v, a))
+        self._otg_enabled = True
+        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), int(v.shape[0]))
+
+    def _desired(self):
+        ctrl = self._need_ctrl()
+        out = np.empty((3 * self.getTaskDof(), ctrl._robot.batch_size))
+        ctrl._call("saip_batch_get_desired_host", self._id, _dptr(out))
+        return out.T
+
+    def getDesiredPosition(self):  # JointTask.h:185-200: the OTG output when enabled, else the goal
+        return self._desired()[:, :self.getTaskDof()]
+
+    def getDesiredVelocity(self):
+        m = self.getTaskDof()
+        return self._desired()[:, m:2 * m]
+
+    def getDesiredAcceleration(self):
+        m = self.getTaskDof()
+        return self._desired()[:, 2 * m:]
+
+    def getInternalOtgStatus(self):
+        """(goal_reached (B,) bool, flags (B,) int, result (B,) int = ruckig::Result of the last cycle)"""
+        ctrl = self._need_ctrl()
+        fl, res = np.zeros(ctrl._robot.batch_size, np.int32), np.zeros(ctrl._robot.batch_size, np.int32)
+        ip = C.POINTER(C.c_int)
+        ctrl._call("saip_batch_get_otg_status_host", self._id, fl.ctypes.data_as(ip), res.ctypes.data_as(ip))
+        return (fl & 1).astype(bool), fl, res
 
 
 class RobotController:

@@ -97,4 +97,25 @@ struct CycleParams {
 	double bie_thr;
 };
 
+// Internal OTG of one joint task (saip_otg.hip).  Passed to the kernel by value.
+enum { OTG_FLAG_GOAL_REACHED = 1, OTG_FLAG_RUCKIG_INIT = 2, OTG_FLAG_STATE_VALID = 4, OTG_FLAG_ERROR = 8, OTG_FLAG_FINISHED_MOVING = 16 };
+struct OtgDev {
+	int m, gs;             // task dof; lanes per robot (8 or 32)
+	int epoch, pad_;       // bumped when the limits change: forces a new trajectory like InputParameter::operator!= does
+	long long lanes;       // B * gs = stride of one state field
+	double dt;             // control period (Ruckig delta_time)
+	double vmax[SAIP_MAXN], amax[SAIP_MAXN];
+	double* state;         // [fields][lanes], lane-major
+	double* time;          // [ld] OutputParameter::time
+	double* duration;      // [ld] Trajectory::duration
+	int* flags;            // [ld] OTG_FLAG_*
+	int* seen_epoch;       // [ld]
+	int* result;           // [ld] ruckig::Result of the last cycle
+	const double* goal;    // [3m][ld] user goal (position, velocity, acceleration rows)
+	double* desired;       // [3m][ld] desired state fed to the control law
+	const double* q;       // [n][ld] (re-initialisation only)
+	const TaskDev* task;   // selection matrix S (re-initialisation only)
+	int n, pad2_;
+};
+
 }  // namespace saip

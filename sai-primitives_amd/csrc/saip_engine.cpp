@@ -17,10 +17,13 @@ namespace saip {
 hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
+hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
+int otg_state_fields();
 }  // namespace saip
 
 using saip::CycleParams;
 using saip::ModelDev;
+using saip::OtgDev;
 using saip::TaskDev;
 
 static thread_local std::string g_err;
@@ -305,6 +308,10 @@ struct TaskHost {
 	TaskDev dev;
 	double P[36];
 	bool otg_enabled = true;  // reference default (MotionForceTask.h:67, JointTask.h:38)
+	// internal OTG of a joint task (saip_otg.hip): acceleration-limited, defaults JointTask.h:39-41
+	bool otg_alloc = false, otg_inited = false;
+	OtgDev otg;
+	double* desired_dev = nullptr;
 	bool vel_sat = false;
 	bool full_joint = false;
 	double* goal_dev = nullptr;
@@ -525,6 +532,13 @@ extern "C" saip_status saip_batch_add_joint_task(saip_batch* b, const char* task
 	T.dev.goal_comps = 3 * T.dev.m;
 	T.integ_rows = T.dev.m;
 	refresh_has_ki(T.dev);
+	memset(&T.otg, 0, sizeof(T.otg));
+	T.otg.m = T.dev.m;
+	T.otg.gs = T.dev.m <= 8 ? 8 : 32;
+	for (int i = 0; i < SAIP_MAXN; i++) {
+		T.otg.vmax[i] = M_PI / 3.0;   // DefaultParameters::otg_max_velocity, JointTask.h:40
+		T.otg.amax[i] = 2.0 * M_PI;   // DefaultParameters::otg_max_acceleration, JointTask.h:41
+	}
 	b->tasks.push_back(T);
 	b->config_dirty = true;
 	if (task_id) *task_id = (int)b->tasks.size() - 1;
@@ -710,8 +724,37 @@ extern "C" saip_status saip_batch_set_internal_otg(saip_batch* b, int t, int ena
 	saip_status st = check_batch(b, t, "saip_batch_set_internal_otg");
 	if (st) return st;
 	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
-	b->tasks[t].otg_enabled = enabled != 0;
+	TaskHost& T = b->tasks[t];
+	if (enabled && !T.otg_enabled) T.otg_inited = false;  // enableInternalOtg* re-initialises a disabled OTG (JointTask.cpp:374-376)
+	T.otg_enabled = enabled != 0;
+	b->config_dirty = true;
 	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_otg_acceleration_limited(saip_batch* b, int t, const double* max_velocity, const double* max_acceleration, int count) {
+	saip_status st = need_type(b, t, saip::TASK_JOINT, "saip_batch_set_otg_acceleration_limited");
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	const int m = T.dev.m;
+	if (!max_velocity || !max_acceleration || (count != 1 && count != m))
+		return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity or max acceleration vector size not consistent with task dof in JointTask::enableInternalOtgAccelerationLimited");
+	for (int i = 0; i < count; i++) {
+		if (!(max_velocity[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity");
+		if (!(max_acceleration[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration");
+	}
+	for (int i = 0; i < m; i++) {
+		T.otg.vmax[i] = max_velocity[count == 1 ? 0 : i];
+		T.otg.amax[i] = max_acceleration[count == 1 ? 0 : i];
+	}
+	T.otg.epoch++;
+	if (!T.otg_enabled) T.otg_inited = false;
+	T.otg_enabled = true;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_otg_jerk_limited(saip_batch* b, int t, const double*, const double*, const double*, int) {
+	saip_status st = check_batch(b, t, "saip_batch_set_otg_jerk_limited");
+	if (st) return st;
+	return fail(SAIP_ERR_UNSUPPORTED, "jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented on the device; use the acceleration-limited mode");
 }
 extern "C" saip_status saip_batch_set_velocity_saturation(saip_batch* b, int t, int enabled) {
 	saip_status st = check_batch(b, t, "saip_batch_set_velocity_saturation");
@@ -894,16 +937,51 @@ extern "C" saip_status saip_batch_bind_tau_device(saip_batch* b, double* tau_dev
 }
 extern "C" void* saip_batch_stream(saip_batch* b) { return b ? (void*)b->stream : nullptr; }
 
+// lazily allocate the OTG state of a joint task: [fields][B*gs] lane-major doubles + per-instance scalars
+static saip_status ensure_otg(saip_batch* b, TaskHost& T) {
+	if (T.otg_alloc) return SAIP_OK;
+	saip_status st;
+	OtgDev& O = T.otg;
+	O.lanes = (long long)b->B * O.gs;
+	O.dt = T.dev.dt;
+	O.n = b->model->n;
+	if ((st = dev_alloc(b, &O.state, (size_t)saip::otg_state_fields() * (size_t)O.lanes)) || (st = dev_alloc(b, &O.time, (size_t)b->ld)) ||
+		(st = dev_alloc(b, &O.duration, (size_t)b->ld)) || (st = dev_alloc(b, &O.flags, (size_t)b->ld)) || (st = dev_alloc(b, &O.seen_epoch, (size_t)b->ld)) ||
+		(st = dev_alloc(b, &O.result, (size_t)b->ld)) || (st = dev_alloc(b, &T.desired_dev, (size_t)T.dev.goal_comps * b->ld)))
+		return st;
+	O.desired = T.desired_dev;
+	O.goal = T.goal_dev;
+	O.q = b->q;
+	T.otg_alloc = true;
+	T.otg_inited = false;
+	return SAIP_OK;
+}
+// mode 1: OTG_joints::reInitialize(S q) for every instance; mode 0: one cycle of setGoal + update
+static saip_status run_otg(saip_batch* b, int t, int mode) {
+	TaskHost& T = b->tasks[t];
+	T.otg.task = b->tasks_dev + t;
+	T.otg.dt = T.dev.dt;
+	hipError_t e = saip::launch_otg_joints(T.otg, b->B, b->ld, mode, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "OTG kernel launch failed: %s", hipGetErrorString(e));
+	if (mode == 1) T.otg_inited = true;
+	return SAIP_OK;
+}
+
 static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	for (auto& T : b->tasks) {
-		if (T.otg_enabled)  // reference default; the device has no OTG
-			return fail(SAIP_ERR_UNSUPPORTED, "task [%s]: internal OTG is enabled (reference default) but not implemented on the device; call saip_batch_set_internal_otg(batch, task, 0) (disableInternalOtg)", T.name.c_str());
+		if (T.otg_enabled && T.dev.type != saip::TASK_JOINT)  // reference default; the Cartesian OTG (OTG_6dof_cartesian) is not on the device yet
+			return fail(SAIP_ERR_UNSUPPORTED, "task [%s]: internal OTG is enabled (reference default) but the Cartesian OTG is not implemented on the device; call saip_batch_set_internal_otg(batch, task, 0) (disableInternalOtg)", T.name.c_str());
+		if (T.otg_enabled) {
+			saip_status st = ensure_otg(b, T);
+			if (st) return st;
+		}
 	}
 	if (b->config_dirty || diag) {
 		std::vector<TaskDev> tmp;
 		for (auto& T : b->tasks) {
 			TaskDev d = T.dev;
 			d.diag_N = diag ? T.diag_dev : nullptr;
+			if (T.otg_enabled && T.dev.type == saip::TASK_JOINT) d.goal = T.desired_dev;  // the law tracks the OTG output (JointTask.cpp:317-319)
 			tmp.push_back(d);
 		}
 		HIP_TRY(hipMemcpyAsync(b->tasks_dev, tmp.data(), tmp.size() * sizeof(TaskDev), hipMemcpyHostToDevice, b->stream));
@@ -982,6 +1060,12 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;
 	saip_status st = make_params(b, P, diag);
 	if (st) return st;
+	for (size_t t = 0; t < b->tasks.size(); t++) {
+		TaskHost& T = b->tasks[t];
+		if (!T.otg_enabled || T.dev.type != saip::TASK_JOINT) continue;
+		if (!T.otg_inited && (st = run_otg(b, (int)t, 1))) return st;
+		if (!diag && (st = run_otg(b, (int)t, 0))) return st;  // a diagnostic re-launch must not advance the trajectory
+	}
 	bool lane_ok = false;
 	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
 		hipError_t e = saip::launch_cycle_lane(P, b->stream, &lane_ok);
@@ -1009,6 +1093,11 @@ static saip_status launch_reinit_masked(saip_batch* b, int task, int mask) {
 	P.reinit_mask = mask;
 	hipError_t e = saip::launch_reinit(P, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "reinit launch failed: %s", hipGetErrorString(e));
+	for (size_t t = 0; t < b->tasks.size(); t++) {  // JointTask::reInitializeTask -> _otg->reInitialize (JointTask.cpp:106)
+		TaskHost& T = b->tasks[t];
+		if ((task >= 0 && (int)t != task) || T.dev.type != saip::TASK_JOINT || !T.otg_enabled || !(mask & 1)) continue;
+		if ((st = ensure_otg(b, T)) || (st = run_otg(b, (int)t, 1))) return st;
+	}
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	return SAIP_OK;
 }
@@ -1082,6 +1171,28 @@ extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
 	return SAIP_OK;
 }
 extern "C" const char* saip_batch_kernel_name(saip_batch* b) { return b ? b->kernel_name.c_str() : ""; }
+
+// desired state of a task = what its control law tracks: the internal OTG's output when enabled, else the goal (JointTask.h:185-200)
+extern "C" saip_status saip_batch_get_desired_host(saip_batch* b, int t, double* desired) {
+	saip_status st = need_ready(b, "saip_batch_get_desired_host");
+	if (st) return st;
+	if ((st = check_batch(b, t, "saip_batch_get_desired_host"))) return st;
+	if (t < 0 || !desired) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_get_desired_host: bad argument");
+	TaskHost& T = b->tasks[t];
+	const bool otg = T.otg_enabled && T.dev.type == saip::TASK_JOINT && T.otg_alloc && T.otg_inited;
+	return copy_d2h(b, desired, otg ? T.desired_dev : T.goal_dev, T.dev.goal_comps);
+}
+extern "C" saip_status saip_batch_get_otg_status_host(saip_batch* b, int t, int* flags, int* result) {
+	saip_status st = need_type(b, t, saip::TASK_JOINT, "saip_batch_get_otg_status_host");
+	if (st) return st;
+	if ((st = need_ready(b, "saip_batch_get_otg_status_host"))) return st;
+	TaskHost& T = b->tasks[t];
+	if (!T.otg_alloc) return fail(SAIP_ERR_ORDER, "saip_batch_get_otg_status_host: the internal OTG of task [%s] has not run", T.name.c_str());
+	if (flags) HIP_TRY(hipMemcpyAsync(flags, T.otg.flags, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+	if (result) HIP_TRY(hipMemcpyAsync(result, T.otg.result, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
 
 extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmup, double* elapsed_ms) {
 	saip_status st = need_ready(b, "saip_batch_time_steps");

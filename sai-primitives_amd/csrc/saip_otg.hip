@@ -1,0 +1,737 @@
+// Batched online trajectory generation (internal OTG of JointTask, acceleration-limited mode -- the reference default).
+//
+// Reference call stack, one control cycle of one robot (JointTask.cpp:313-319):
+//   OTG_joints::setGoalPositionAndVelocity   /root/reference/src/helper_modules/OTG_joints.cpp:98-114
+//   OTG_joints::update                       OTG_joints.cpp:116-150
+//     ruckig::Ruckig::update                 /root/reference/ruckig/include/ruckig/ruckig.hpp:184-221
+//       TargetCalculator::calculate          ruckig/include/ruckig/calculator_target.hpp:228-524   (only when the input changed)
+//         BrakeProfile (second order)        ruckig/src/ruckig/brake.cpp:82-102, include/ruckig/brake.hpp:65-75
+//         PositionSecondOrderStep1           ruckig/src/ruckig/position-second-step1.cpp:11-136, block.hpp:60-134
+//         synchronize                        calculator_target.hpp:128-207
+//         phase synchronization              calculator_target.hpp:44-126, 381-455
+//         PositionSecondOrderStep2           ruckig/src/ruckig/position-second-step2.cpp:13-117
+//       Trajectory::at_time                  ruckig/include/ruckig/trajectory.hpp:65-143
+//
+// MI355X mapping: ONE LANE PER (instance, task dof).  A group of GS = 8 (dof <= 8) or 32 lanes is one robot, so a wavefront
+// carries 8 (or 2) robots; the per-dof extremal profiles (step 1) and the time-synchronised profiles (step 2) are computed
+// independently in every lane, and the three cross-dof steps of the algorithm -- the choice of the synchronisation time among the
+// 3*dof candidate durations, the collinearity test of phase synchronisation, and the wrapper's norm tests -- are ballots and
+// xor-butterflies inside the lane group.  No LDS, no barriers, no divergence between robots except where their trajectories
+// really differ.  State lives in HBM lane-major ([field][instance*GS + dof]) so that every load and store of the cycle is one
+// fully coalesced 512-byte access per wavefront.
+//
+// Arithmetic: the expressions below are evaluated in the same order as the reference's, with FMA contraction switched off, so
+// branch decisions that compare against 1e-8 ... 2^-52 thresholds see (almost always bit-) identical numbers.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "saip_device.h"
+
+#pragma clang fp contract(off)
+
+namespace saip {
+
+namespace {
+
+constexpr double OTG_DBL_EPS = 2.220446049250313e-16;  // std::numeric_limits<double>::epsilon() / DBL_EPSILON
+constexpr double OTG_INF = __builtin_huge_val();
+
+// ruckig::Profile restricted to what the second-order position interface touches: segment durations t[0..6] and accelerations
+// a[0..6] (a[7] = af = 0, jerk = 0), the direction flag, and t_sum.back().  p[0], v[0], pf, vf are held by the caller.
+struct Prof {
+	double t[7], a[7];
+	double tsum;  // t_sum.back()
+	int dir;      // 0 UP, 1 DOWN
+};
+
+__device__ __forceinline__ double dabs(double x) { return __builtin_fabs(x); }
+
+// Profile::check_for_second_order<UDDU, *>, profile.hpp:308-350.  Fills a[], dir, tsum; optionally returns p.back(), v.back().
+__device__ __forceinline__ bool prof_check(Prof& pr, double p0, double v0, double pf, double vf, double aUp, double aDown, double vMax, double vMin,
+											double* p_back = nullptr, double* v_back = nullptr) {
+	if (pr.t[0] < 0) return false;
+	double ts = pr.t[0];
+#pragma unroll
+	for (int i = 0; i < 6; i++) {
+		if (pr.t[i + 1] < 0) return false;
+		ts = ts + pr.t[i + 1];
+	}
+	pr.tsum = ts;
+	if (ts > 1e12) return false;
+	pr.a[0] = pr.t[0] > 0 ? aUp : 0.0;
+	pr.a[1] = 0.0;
+	pr.a[2] = pr.t[2] > 0 ? aDown : 0.0;
+	pr.a[3] = 0.0;
+	pr.a[4] = pr.t[4] > 0 ? aDown : 0.0;
+	pr.a[5] = 0.0;
+	pr.a[6] = pr.t[6] > 0 ? aUp : 0.0;
+	pr.dir = (vMax > 0) ? 0 : 1;
+	const double vUppLim = (pr.dir == 0 ? vMax : vMin) + 1e-12;
+	const double vLowLim = (pr.dir == 0 ? vMin : vMax) - 1e-12;
+	double v[8], p = p0;
+	v[0] = v0;
+#pragma unroll
+	for (int i = 0; i < 7; i++) {
+		v[i + 1] = v[i] + pr.t[i] * pr.a[i];
+		p = p + pr.t[i] * (v[i] + pr.t[i] * pr.a[i] / 2);
+	}
+	if (p_back) *p_back = p;
+	if (v_back) *v_back = v[7];
+	return dabs(p - pf) < 1e-8 && dabs(v[7] - vf) < 1e-8 && v[2] <= vUppLim && v[3] <= vUppLim && v[4] <= vUppLim && v[5] <= vUppLim &&
+		   v[6] <= vUppLim && v[2] >= vLowLim && v[3] >= vLowLim && v[4] >= vLowLim && v[5] >= vLowLim && v[6] >= vLowLim;
+}
+
+__device__ __forceinline__ void prof_zero_t(Prof& pr) {
+#pragma unroll
+	for (int i = 0; i < 7; i++) pr.t[i] = 0.0;
+}
+
+// Block (block.hpp:14-134) for at most three valid profiles: the fastest profile and at most one blocked interval
+struct Block {
+	Prof pmin, aprof;
+	double t_min, a_left, a_right;
+	bool has_a;
+};
+
+struct Step1 {  // PositionSecondOrderStep1, position-second-step1.cpp
+	double p0, v0, pf, vf, pd, brake_dur;
+	Prof cand[3];
+	int cnt;
+	bool overflow;
+
+	__device__ __forceinline__ void add(const Prof& pr) {
+		if (cnt < 3) cand[cnt] = pr;
+		else overflow = true;  // the reference's std::array<Profile, 3> would be overrun
+		cnt++;
+	}
+	__device__ __forceinline__ void time_acc0(double vMax, double vMin, double aMax, double aMin) {  // :11-25
+		Prof pr;
+		prof_zero_t(pr);
+		pr.t[0] = (-v0 + vMax) / aMax;
+		pr.t[1] = (aMin * v0 * v0 - aMax * vf * vf) / (2 * aMax * aMin * vMax) + vMax * (aMax - aMin) / (2 * aMax * aMin) + pd / vMax;
+		pr.t[2] = (vf - vMax) / aMin;
+		if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) add(pr);
+	}
+	__device__ __forceinline__ void time_none(double vMax, double vMin, double aMax, double aMin, bool return_after_found) {  // :27-63
+		double h1 = (aMax * vf * vf - aMin * v0 * v0 - 2 * aMax * aMin * pd) / (aMax - aMin);
+		if (h1 >= 0.0) {
+			h1 = sqrt(h1);
+			Prof pr;
+			prof_zero_t(pr);
+			pr.t[0] = -(v0 + h1) / aMax;
+			pr.t[2] = (vf + h1) / aMin;
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) {
+				add(pr);
+				if (return_after_found) return;
+			}
+			pr.t[0] = (-v0 + h1) / aMax;
+			pr.t[1] = 0.0;
+			pr.t[2] = (vf - h1) / aMin;
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) add(pr);
+		}
+	}
+	// get_profile, :99-136 (the zero-velocity-limit special case :101-114 cannot occur: the wrappers reject limits <= 0)
+	__device__ __forceinline__ bool run(double _vMax, double _vMin, double _aMax, double _aMin, Block& blk) {
+		cnt = 0;
+		overflow = false;
+		pd = pf - p0;
+		if (dabs(vf) < OTG_DBL_EPS) {
+			const bool up = (pd >= 0);
+			const double vMax = up ? _vMax : _vMin, vMin = up ? _vMin : _vMax, aMax = up ? _aMax : _aMin, aMin = up ? _aMin : _aMax;
+			time_none(vMax, vMin, aMax, aMin, true);
+			if (cnt == 0) time_acc0(vMax, vMin, aMax, aMin);
+			if (cnt == 0) time_none(vMin, vMax, aMin, aMax, true);
+			if (cnt == 0) time_acc0(vMin, vMax, aMin, aMax);
+		} else {
+			time_none(_vMax, _vMin, _aMax, _aMin, false);
+			time_none(_vMin, _vMax, _aMin, _aMax, false);
+			time_acc0(_vMax, _vMin, _aMax, _aMin);
+			time_acc0(_vMin, _vMax, _aMin, _aMax);
+		}
+		if (overflow) return false;
+		return calculate_block(blk);
+	}
+	__device__ __forceinline__ Prof pick(int i) const { return i == 0 ? cand[0] : (i == 1 ? cand[1] : cand[2]); }
+	__device__ __forceinline__ void interval(Block& blk, int il, int ir) const {  // Block::Interval(profile_left, profile_right), block.hpp:30-42
+		const Prof L = pick(il), R = pick(ir);
+		const double ld = L.tsum + brake_dur + 0.0, rd = R.tsum + brake_dur + 0.0;
+		blk.has_a = true;
+		if (ld < rd) {
+			blk.a_left = ld;
+			blk.a_right = rd;
+			blk.aprof = R;
+		} else {
+			blk.a_left = rd;
+			blk.a_right = ld;
+			blk.aprof = L;
+		}
+	}
+	__device__ __forceinline__ void set_min(Block& blk, int i) const {  // block.hpp:45-50
+		blk.pmin = pick(i);
+		blk.t_min = blk.pmin.tsum + brake_dur + 0.0;
+		blk.has_a = false;
+		blk.a_left = blk.a_right = OTG_INF;
+	}
+	__device__ __forceinline__ bool calculate_block(Block& blk) const {  // block.hpp:60-134 for counter <= 3
+		if (cnt == 1) {
+			set_min(blk, 0);
+			return true;
+		}
+		if (cnt == 2) {
+			if (dabs(cand[0].tsum - cand[1].tsum) < 8 * OTG_DBL_EPS) {
+				set_min(blk, 0);
+				return true;
+			}
+			const int idx_min = (cand[0].tsum < cand[1].tsum) ? 0 : 1;
+			const int idx_else = (idx_min + 1) % 2;
+			set_min(blk, idx_min);
+			interval(blk, idx_min, idx_else);
+			return true;
+		}
+		if (cnt == 3) {
+			int idx_min = 0;  // std::min_element: first minimal
+			if (cand[1].tsum < cand[idx_min].tsum) idx_min = 1;
+			if (cand[2].tsum < (idx_min == 0 ? cand[0].tsum : cand[1].tsum)) idx_min = 2;
+			set_min(blk, idx_min);
+			interval(blk, (idx_min + 1) % 3, (idx_min + 2) % 3);
+			return true;
+		}
+		return false;
+	}
+};
+
+struct Step2 {  // PositionSecondOrderStep2, position-second-step2.cpp
+	double tf, p0, v0, pf, vf, pd, vd;
+
+	__device__ __forceinline__ bool time_acc0(Prof& pr, double vMax, double vMin, double aMax, double aMin) const {  // :13-66
+		{
+			const double h1 = sqrt((2 * aMax * (pd - tf * vf) - 2 * aMin * (pd - tf * v0) + vd * vd) / (aMax * aMin) + tf * tf);
+			prof_zero_t(pr);
+			pr.t[0] = (aMax * vd - aMax * aMin * (tf - h1)) / (aMax * (aMax - aMin));
+			pr.t[1] = h1;
+			pr.t[2] = tf - (pr.t[0] + h1);
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) return true;
+		}
+		{
+			const double h1 = (-vd + aMax * tf);
+			prof_zero_t(pr);
+			pr.t[0] = -vd * vd / (2 * aMax * h1) + (pd - v0 * tf) / h1;
+			pr.t[1] = -vd / aMax + tf;
+			pr.t[6] = tf - (pr.t[0] + pr.t[1]);
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) return true;
+		}
+		{
+			prof_zero_t(pr);
+			pr.t[1] = -vd / aMax + tf;
+			pr.t[6] = vd / aMax;
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) return true;
+		}
+		return false;
+	}
+	__device__ __forceinline__ bool time_none(Prof& pr, double vMax, double vMin, double aMax, double aMin) const {  // :68-106
+		if (dabs(v0) < OTG_DBL_EPS && dabs(vf) < OTG_DBL_EPS && dabs(pd) < OTG_DBL_EPS) {
+			prof_zero_t(pr);
+			pr.t[1] = tf;
+			if (prof_check(pr, p0, v0, pf, vf, aMax, aMin, vMax, vMin)) return true;
+		}
+		{
+			const double h1 = 2 * (vf * tf - pd);
+			prof_zero_t(pr);
+			pr.t[0] = h1 / vd;
+			pr.t[1] = tf - pr.t[0];
+			const double af = vd * vd / h1;
+			if ((aMin - 1e-12 < af) && (af < aMax + 1e-12) && prof_check(pr, p0, v0, pf, vf, af, -af, vMax, vMin)) return true;
+		}
+		return false;
+	}
+	__device__ __forceinline__ bool check_all(Prof& pr, double vMax, double vMin, double aMax, double aMin) const {
+		return time_acc0(pr, vMax, vMin, aMax, aMin) || time_none(pr, vMax, vMin, aMax, aMin);
+	}
+	__device__ __forceinline__ bool run(Prof& pr, double _vMax, double _vMin, double _aMax, double _aMin) {  // :108-117
+		pd = pf - p0;
+		vd = vf - v0;
+		if (pd > 0) return check_all(pr, _vMax, _vMin, _aMax, _aMin) || check_all(pr, _vMin, _vMax, _aMin, _aMax);
+		return check_all(pr, _vMin, _vMax, _aMin, _aMax) || check_all(pr, _vMax, _vMin, _aMax, _aMin);
+	}
+};
+
+// ---------------------------------------------------------------- lane-group collectives (GS lanes = one robot)
+template <int GS>
+struct Grp {
+	int lane, base, dof;
+	__device__ __forceinline__ Grp() {
+		lane = threadIdx.x & 63;
+		dof = lane & (GS - 1);
+		base = lane - dof;
+	}
+	__device__ __forceinline__ unsigned long long bits(bool pred) const {
+		const unsigned long long m = __ballot(pred ? 1 : 0);
+		const unsigned long long gm = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+		return (m >> base) & gm;
+	}
+	__device__ __forceinline__ bool any(bool pred) const { return bits(pred) != 0ull; }
+	__device__ __forceinline__ double sum(double x) const {
+#pragma unroll
+		for (int off = 1; off < GS; off <<= 1) x = x + __shfl_xor(x, off);
+		return x;
+	}
+	__device__ __forceinline__ double bcast(double x, int src_dof) const { return __shfl(x, base + src_dof); }
+	__device__ __forceinline__ int bcast(int x, int src_dof) const { return __shfl(x, base + src_dof); }
+};
+
+// state arena fields, each [ngroups * GS] doubles, lane-major
+enum {
+	F_IN_P, F_IN_V, F_IN_A,      // wrapper _input.current_*          (OTG_joints.h:187)
+	F_TG_P, F_TG_V,              // wrapper _input.target_*
+	F_CI_P, F_CI_V, F_CI_A,      // ruckig current_input.current_*    (ruckig.hpp:31)
+	F_CI_TP, F_CI_TV,            // ruckig current_input.target_*
+	F_OUT_P, F_OUT_V, F_OUT_A,   // wrapper _output.new_*
+	F_T0, F_T1, F_T2, F_T6,      // chosen profile: the segment durations the second-order interface can make non-zero
+	F_A0, F_A2, F_A6,            //                 and their accelerations
+	F_P0, F_V0,                  // profile start (after the brake pre-trajectory)
+	F_BR_T, F_BR_A, F_BR_P, F_BR_V,  // brake pre-trajectory: duration, acceleration, start state
+	F_COUNT
+};
+
+struct Sample {
+	double p, v, a;
+};
+// Trajectory::state_to_integrate_from + integrate for one dof (trajectory.hpp:65-143, utils.hpp:43-49), single section, jerk 0
+__device__ __forceinline__ Sample sample_profile(double time, double duration, const double t[7], const double a[7], double p0, double v0, double br_t,
+												  double br_a, double br_p, double br_v) {
+	// p[i], v[i], t_sum[i] exactly as check_for_second_order left them
+	double p[8], v[8], ts[7];
+	p[0] = p0;
+	v[0] = v0;
+#pragma unroll
+	for (int i = 0; i < 7; i++) {
+		v[i + 1] = v[i] + t[i] * a[i];
+		p[i + 1] = p[i] + t[i] * (v[i] + t[i] * a[i] / 2);
+		ts[i] = (i == 0) ? t[0] : ts[i - 1] + t[i];
+	}
+	double td, ps, vs, as;
+	if (time >= duration) {
+		td = time - (br_t + ts[6]);
+		ps = p[7];
+		vs = v[7];
+		as = 0.0;  // a.back() = af
+	} else {
+		td = time;
+		bool in_brake = false;
+		if (br_t > 0) {
+			if (td < br_t) in_brake = true;
+			else td = td - br_t;
+		}
+		if (in_brake) {
+			ps = br_p;
+			vs = br_v;
+			as = br_a;
+		} else if (td >= ts[6]) {
+			td = td - ts[6];
+			ps = p[7];
+			vs = v[7];
+			as = 0.0;
+		} else {
+			int idx = 0;  // std::upper_bound(t_sum, td): first i with t_sum[i] > td
+#pragma unroll
+			for (int i = 6; i >= 0; i--)
+				if (ts[i] > td) idx = i;
+			double tprev = 0.0;
+			ps = p[0];
+			vs = v[0];
+			as = a[0];
+#pragma unroll
+			for (int i = 1; i < 7; i++)
+				if (idx == i) {
+					tprev = ts[i - 1];
+					ps = p[i];
+					vs = v[i];
+					as = a[i];
+				}
+			if (idx > 0) td = td - tprev;
+		}
+	}
+	Sample s;
+	s.p = ps + td * (vs + td * (as / 2 + td * 0.0 / 6));
+	s.v = vs + td * (as + td * 0.0 / 2);
+	s.a = as + td * 0.0;
+	return s;
+}
+
+}  // namespace
+
+// One control cycle of the internal OTG of one joint task for the whole batch.  mode 0: cycle (JointTask.cpp:313-319);
+// mode 1: OTG_joints::reInitialize from the task's current position, which the task re-initialisation has just written to the
+// goal rows (JointTask.cpp:95-106, OTG_joints.cpp:28-42).
+template <int GS>
+__global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, int ld, int mode) {
+	const Grp<GS> g;
+	const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int inst = gtid / GS;
+	const int dof = g.dof;
+	const int m = O.m;
+	const bool inst_ok = inst < B;
+	const bool act = inst_ok && dof < m;
+	const size_t stride = (size_t)O.lanes;  // ngroups * GS
+	const size_t li = (size_t)gtid;         // lane-major slot (gtid < lanes by construction of the grid)
+	double* S = O.state;
+#define ST(f) S[(size_t)(f) * stride + li]
+
+	const size_t gi = (size_t)(act ? dof : 0) * ld + (inst_ok ? inst : 0);  // row `dof` of the task's goal / desired arrays
+	const double goal_p = (act && mode == 0) ? O.goal[gi] : 0.0;
+	const double goal_v = (act && mode == 0) ? O.goal[gi + (size_t)m * ld] : 0.0;
+
+	if (mode == 1) {
+		// current task position S q (JointTask.cpp:98), then setGoalPosition(initial): OTG_joints.cpp:36, 98-114
+		double cur = 0.0;
+		if (act) {
+			const TaskDev& tk = *O.task;
+			if (tk.s_identity) cur = O.q[(size_t)dof * ld + inst];
+			else
+				for (int j = 0; j < O.n; j++) cur = fma(tk.S[dof * O.n + j], O.q[(size_t)j * ld + inst], cur);
+		}
+		const double tp = act ? ST(F_TG_P) : 0.0, tv = act ? ST(F_TG_V) : 0.0;
+		const double dp2 = g.sum((cur - tp) * (cur - tp)), gp2 = g.sum(cur * cur), tp2 = g.sum(tp * tp);
+		const double tv2 = g.sum(tv * tv);
+		const bool same = (dp2 <= 1e-24 * fmin(gp2, tp2)) && (tv2 <= 0.0);
+		if (act) {
+			if (!same) {
+				ST(F_TG_P) = cur;
+				ST(F_TG_V) = 0.0;
+			}
+			ST(F_OUT_P) = cur;  // :38-41
+			ST(F_OUT_V) = 0.0;
+			ST(F_OUT_A) = 0.0;
+			ST(F_IN_P) = cur;
+			ST(F_IN_V) = 0.0;
+			ST(F_IN_A) = 0.0;
+			O.desired[gi] = cur;  // JointTask.cpp:100-105
+			O.desired[gi + (size_t)m * ld] = 0.0;
+			O.desired[gi + (size_t)2 * m * ld] = 0.0;
+			if (dof == 0) {
+				int fl = O.flags[inst] & ~(OTG_FLAG_ERROR | OTG_FLAG_FINISHED_MOVING);
+				if (!same) fl &= ~OTG_FLAG_GOAL_REACHED;
+				O.flags[inst] = fl | OTG_FLAG_STATE_VALID;
+				O.result[inst] = 1;
+			}
+		}
+		return;
+	}
+
+	// ------------------------------------------------------------ wrapper + ruckig state of this lane
+	double in_p = 0, in_v = 0, in_a = 0, tg_p = 0, tg_v = 0, out_p = 0, out_v = 0, out_a = 0;
+	int flags = 0;
+	if (inst_ok) flags = O.flags[inst];
+	if (act) {
+		in_p = ST(F_IN_P);
+		in_v = ST(F_IN_V);
+		in_a = ST(F_IN_A);
+		tg_p = ST(F_TG_P);
+		tg_v = ST(F_TG_V);
+		out_p = ST(F_OUT_P);
+		out_v = ST(F_OUT_V);
+		out_a = ST(F_OUT_A);
+	}
+	const double vMax = act ? O.vmax[dof] : 1.0, aMax = act ? O.amax[dof] : 1.0;
+	const double vMin = -vMax, aMin = -aMax;
+	// new limits since the last cycle: enableInternalOtgAccelerationLimited -> disableJerkLimits() zeroes the current acceleration
+	// of the wrapper's input (OTG_joints.cpp:90-93); the changed limits themselves force a new trajectory (ruckig.hpp:197)
+	const bool new_limits = inst_ok && (O.epoch != O.seen_epoch[inst]);
+	if (new_limits) in_a = 0.0;
+
+	// setGoalPositionAndVelocity, OTG_joints.cpp:98-114 (Eigen isApprox: ||a-b||^2 <= 1e-24 min(||a||^2, ||b||^2))
+	{
+		const double dp2 = g.sum((goal_p - tg_p) * (goal_p - tg_p)), gp2 = g.sum(goal_p * goal_p), tp2 = g.sum(tg_p * tg_p);
+		const double dv2 = g.sum((goal_v - tg_v) * (goal_v - tg_v)), gv2 = g.sum(goal_v * goal_v), tv2 = g.sum(tg_v * tg_v);
+		const bool same = (dp2 <= 1e-24 * fmin(gp2, tp2)) && (dv2 <= 1e-24 * fmin(gv2, tv2));
+		if (!same) {
+			flags &= ~OTG_FLAG_GOAL_REACHED;
+			tg_p = goal_p;
+			tg_v = goal_v;
+		}
+	}
+
+	int result = 0;  // ruckig::Result of this cycle: 0 Working, 1 Finished, < 0 error
+	const bool run = inst_ok && !(flags & OTG_FLAG_GOAL_REACHED);  // OTG_joints.cpp:117-119
+	if (g.any(run)) {  // wave-level skip when every robot of the wavefront has reached its goal
+		// ---------------------------------------------------- Ruckig::update, ruckig.hpp:184-221
+		double ci_p = 0, ci_v = 0, ci_a = 0, ci_tp = 0, ci_tv = 0;
+		double t[7] = {0, 0, 0, 0, 0, 0, 0}, a[7] = {0, 0, 0, 0, 0, 0, 0};
+		double P0 = 0, V0 = 0, br_t = 0, br_a = 0, br_p = 0, br_v = 0;
+		double time = 0, duration = 0;
+		if (act) {
+			ci_p = ST(F_CI_P);
+			ci_v = ST(F_CI_V);
+			ci_a = ST(F_CI_A);
+			ci_tp = ST(F_CI_TP);
+			ci_tv = ST(F_CI_TV);
+			t[0] = ST(F_T0);
+			t[1] = ST(F_T1);
+			t[2] = ST(F_T2);
+			t[6] = ST(F_T6);
+			a[0] = ST(F_A0);
+			a[2] = ST(F_A2);
+			a[6] = ST(F_A6);
+			P0 = ST(F_P0);
+			V0 = ST(F_V0);
+			br_t = ST(F_BR_T);
+			br_a = ST(F_BR_A);
+			br_p = ST(F_BR_P);
+			br_v = ST(F_BR_V);
+		}
+		if (inst_ok) {
+			time = O.time[inst];
+			duration = O.duration[inst];
+		}
+		const bool differs = act && !(in_p == ci_p && in_v == ci_v && in_a == ci_a && tg_p == ci_tp && tg_v == ci_tv);
+		const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
+
+		if (g.any(need_calc)) {
+			// validate_input (input_parameter.hpp:155-330, check_target_state_within_limits only): NaNs and |vf| beyond the limits
+			bool bad = act && need_calc && (isnan(in_p) || isnan(in_v) || isnan(in_a) || isnan(tg_p) || isnan(tg_v) || tg_v > vMax || tg_v < vMin);
+			int err = g.any(bad) ? -100 : 0;
+
+			// ------------------------------------------------ per-dof: brake pre-trajectory + step 1 (calculator_target.hpp:235-318)
+			Block blk;
+			blk.t_min = 0.0;
+			blk.has_a = false;
+			blk.a_left = blk.a_right = OTG_INF;
+			double nb_t = 0.0, nb_a = 0.0, np0 = in_p, nv0 = in_v;
+			{
+				if (in_v > vMax) {  // brake.cpp:82-102
+					nb_a = aMin;
+					nb_t = (vMax - in_v) / aMin + 2.2e-14;
+				} else if (in_v < vMin) {
+					nb_a = aMax;
+					nb_t = (vMin - in_v) / aMax + 2.2e-14;
+				}
+				if (nb_t > 0.0) {  // finalize_second_order, brake.hpp:65-75
+					np0 = in_p + nb_t * (in_v + nb_t * (nb_a / 2 + nb_t * 0.0 / 6));
+					nv0 = in_v + nb_t * (nb_a + nb_t * 0.0 / 2);
+				} else {
+					nb_t = 0.0;
+				}
+				Step1 s1;
+				s1.p0 = np0;
+				s1.v0 = nv0;
+				s1.pf = tg_p;
+				s1.vf = tg_v;
+				s1.brake_dur = nb_t;
+				const bool found = s1.run(vMax, vMin, aMax, aMin, blk);
+				if (err == 0 && g.any(act && need_calc && !found)) err = -110;  // ErrorExecutionTimeCalculation
+			}
+
+			// ------------------------------------------------ synchronize (calculator_target.hpp:128-207): the smallest candidate
+			// duration {t_min, a.right} of any dof that no dof blocks; ties resolved towards the lower candidate index
+			double t_sync = OTG_INF;
+			int lim_idx = -1;  // candidate index = quot * m + dof
+			for (int c = 0; c < 2; c++) {
+				const double mine = (c == 0) ? blk.t_min : (blk.has_a ? blk.a_right : OTG_INF);
+				for (int s = 0; s < m; s++) {
+					const double cand = g.bcast(mine, s);
+					const bool blocked = act && ((cand < blk.t_min) || (blk.has_a && blk.a_left < cand && cand < blk.a_right));
+					const bool is_blocked = g.any(blocked);
+					if (!is_blocked && !isinf(cand) && !(cand < 0.0) && cand < t_sync) {
+						t_sync = cand;
+						lim_idx = c * m + s;
+					}
+				}
+			}
+			if (err == 0 && lim_idx < 0) err = -111;  // ErrorSynchronizationCalculation
+			const int lim_dof = lim_idx < 0 ? 0 : lim_idx % m;
+			const int lim_quot = lim_idx < 0 ? 0 : lim_idx / m;
+			if (err == 0 && t_sync > 7.6e3) err = -101;  // ErrorTrajectoryDuration, :354-358
+
+			Prof mine = blk.pmin;  // profile of this dof
+			if (dof == lim_dof && lim_quot == 1) mine = blk.aprof;
+			bool done = (t_sync == 0.0);  // :360-366: every dof keeps its p_min
+
+			// ------------------------------------------------ phase synchronisation (calculator_target.hpp:44-126, 373-455)
+			if (err == 0 && !done) {
+				const double pdv = tg_p - in_p;
+				// the scale dof: the first dof with a non-zero pd, else v0, else a0, else vf (af = 0)
+				int which = 0;  // 1 pd, 2 v0, 3 a0, 4 vf
+				if (dabs(pdv) > OTG_DBL_EPS) which = 1;
+				else if (dabs(in_v) > OTG_DBL_EPS) which = 2;
+				else if (dabs(in_a) > OTG_DBL_EPS) which = 3;
+				else if (dabs(tg_v) > OTG_DBL_EPS) which = 4;
+				const unsigned long long cand_bits = g.bits(act && which != 0);
+				bool collinear = cand_bits != 0ull;
+				const int sdof = collinear ? __builtin_ctzll(cand_bits) : 0;
+				const int swhich = g.bcast(which, sdof);
+				const double sv = swhich == 1 ? pdv : (swhich == 2 ? in_v : (swhich == 3 ? in_a : tg_v));  // scale_vector[dof]
+				const double scale = g.bcast(sv, sdof);
+				const double pd_scale = g.bcast(pdv, sdof) / scale, v0_scale = g.bcast(in_v, sdof) / scale, vf_scale = g.bcast(tg_v, sdof) / scale;
+				const double a0_scale = g.bcast(in_a, sdof) / scale, af_scale = 0.0 / scale;
+				const double scale_limiting = g.bcast(sv, lim_dof);
+				const int lim_dir = g.bcast(mine.dir, lim_dof);
+				const double control_limiting = (lim_dir == 0) ? g.bcast(aMax, lim_dof) : g.bcast(aMin, lim_dof);
+				const bool off = act && (dabs(pdv - pd_scale * sv) > OTG_DBL_EPS || dabs(in_v - v0_scale * sv) > OTG_DBL_EPS ||
+										 dabs(in_a - a0_scale * sv) > OTG_DBL_EPS || dabs(tg_v - vf_scale * sv) > OTG_DBL_EPS ||
+										 dabs(0.0 - af_scale * sv) > OTG_DBL_EPS);
+				if (g.any(off)) collinear = false;
+				const double phase_control = control_limiting * sv / scale_limiting;
+				if (collinear) {
+					Prof ph;
+#pragma unroll
+					for (int i = 0; i < 7; i++) ph.t[i] = g.bcast(mine.t[i], lim_dof);  // p.t = p_limiting.t
+					bool okp = true;
+					if (dof != lim_dof) {
+						const double aUp = phase_control, aDown = -phase_control;
+						okp = (aMin - 1e-12 < aUp) && (aUp < aMax + 1e-12) && (aMin - 1e-12 < aDown) && (aDown < aMax + 1e-12) &&
+							  prof_check(ph, np0, nv0, tg_p, tg_v, aUp, aDown, vMax, vMin);
+					}
+					if (!g.any(act && !okp)) {
+						if (dof != lim_dof) mine = ph;
+						done = true;
+					}
+				}
+			}
+			// ------------------------------------------------ time synchronisation (calculator_target.hpp:457-521)
+			if (err == 0 && !done) {
+				bool ok2 = true;
+				if (dof != lim_dof) {
+					const double t_profile = t_sync - nb_t - 0.0;
+					if (dabs(t_profile - blk.t_min) < 2 * OTG_DBL_EPS) mine = blk.pmin;
+					else if (blk.has_a && dabs(t_profile - blk.a_right) < 2 * OTG_DBL_EPS) mine = blk.aprof;
+					else {
+						Step2 s2;
+						s2.tf = t_profile;
+						s2.p0 = np0;
+						s2.v0 = nv0;
+						s2.pf = tg_p;
+						s2.vf = tg_v;
+						ok2 = s2.run(mine, vMax, vMin, aMax, aMin);
+					}
+				}
+				if (g.any(act && !ok2)) err = -111;
+			}
+
+			if (need_calc) {
+				if (err != 0) {
+					result = err;  // ruckig.hpp:199-201: returns before touching current_input / output
+				} else {
+#pragma unroll
+					for (int i = 0; i < 7; i++) {
+						t[i] = mine.t[i];
+						a[i] = mine.a[i];
+					}
+					P0 = np0;
+					V0 = nv0;
+					br_t = nb_t;
+					br_a = nb_a;
+					br_p = in_p;
+					br_v = in_v;
+					duration = t_sync;
+					time = 0.0;
+					ci_p = in_p;  // current_input = input, ruckig.hpp:203
+					ci_v = in_v;
+					ci_a = in_a;
+					ci_tp = tg_p;
+					ci_tv = tg_v;
+					flags |= OTG_FLAG_RUCKIG_INIT;
+				}
+			}
+		}
+
+		if (run && result == 0) {
+			// ruckig.hpp:209-220: advance one control period along the stored trajectory
+			time = time + O.dt;
+			const Sample s = sample_profile(time, duration, t, a, P0, V0, br_t, br_a, br_p, br_v);
+			const double pv_p = out_p, pv_v = out_v, pv_a = out_a;
+			(void)pv_p; (void)pv_v; (void)pv_a;
+			out_p = s.p;
+			out_v = s.v;
+			out_a = s.a;
+			ci_p = out_p;  // output.pass_to_input(current_input)
+			ci_v = out_v;
+			ci_a = out_a;
+			if (time > duration) result = 1;  // Finished
+		}
+		// ---------------------------------------------------- OTG_joints::update after the ruckig call, OTG_joints.cpp:125-149
+		if (run) {
+			if (result == 1) {
+				const double vn2 = g.sum(act ? out_v * out_v : 0.0);
+				if (sqrt(vn2) < 1e-3) {
+					flags |= OTG_FLAG_GOAL_REACHED;
+				} else {
+					// :131-133 would throw in the reference (a never-assigned member is passed on); the documented intent and the 6-dof
+					// wrapper (OTG_6dof_cartesian.cpp:209-210) are "same target position, zero target velocity".  Counted in the status.
+					flags |= OTG_FLAG_FINISHED_MOVING;
+					const double tv2 = g.sum(act ? tg_v * tg_v : 0.0);
+					if (!(tv2 <= 0.0)) {
+						flags &= ~OTG_FLAG_GOAL_REACHED;
+						tg_v = 0.0;
+					}
+				}
+			} else if (result == 0) {
+				in_p = out_p;  // _output.pass_to_input(_input)
+				in_v = out_v;
+				in_a = out_a;
+			} else {
+				// error: keep the previous output (never overwritten above), zero the input velocity and acceleration
+				in_v = 0.0;
+				in_a = 0.0;
+				flags |= OTG_FLAG_ERROR;
+			}
+		}
+		if (act && run) {
+			ST(F_CI_P) = ci_p;
+			ST(F_CI_V) = ci_v;
+			ST(F_CI_A) = ci_a;
+			ST(F_CI_TP) = ci_tp;
+			ST(F_CI_TV) = ci_tv;
+			ST(F_T0) = t[0];
+			ST(F_T1) = t[1];
+			ST(F_T2) = t[2];
+			ST(F_T6) = t[6];
+			ST(F_A0) = a[0];
+			ST(F_A2) = a[2];
+			ST(F_A6) = a[6];
+			ST(F_P0) = P0;
+			ST(F_V0) = V0;
+			ST(F_BR_T) = br_t;
+			ST(F_BR_A) = br_a;
+			ST(F_BR_P) = br_p;
+			ST(F_BR_V) = br_v;
+			if (dof == 0) {
+				O.time[inst] = time;
+				O.duration[inst] = duration;
+			}
+		}
+	}
+	if (act) {
+		ST(F_IN_P) = in_p;
+		ST(F_IN_V) = in_v;
+		ST(F_IN_A) = in_a;
+		ST(F_TG_P) = tg_p;
+		ST(F_TG_V) = tg_v;
+		ST(F_OUT_P) = out_p;
+		ST(F_OUT_V) = out_v;
+		ST(F_OUT_A) = out_a;
+		// JointTask.cpp:317-319: the desired state the control law tracks
+		O.desired[gi] = out_p;
+		O.desired[gi + (size_t)m * ld] = out_v;
+		O.desired[gi + (size_t)2 * m * ld] = out_a;
+		if (dof == 0) {
+			O.flags[inst] = flags;
+			O.result[inst] = run ? result : 1;
+			if (new_limits && (run ? result == 0 || result == 1 : true)) O.seen_epoch[inst] = O.epoch;
+		}
+	}
+#undef ST
+}
+
+int otg_state_fields() { return F_COUNT; }
+
+hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream) {
+	const int gs = O.gs;
+	const long long lanes = (long long)O.lanes;
+	const int block = 256;
+	const int grid = (int)((lanes + block - 1) / block);
+	if (gs == 8) hipLaunchKernelGGL((saip_otg_joints<8>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	else hipLaunchKernelGGL((saip_otg_joints<32>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	return hipGetLastError();
+}
+
+}  // namespace saip

@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Golden vectors for the internal joint OTG, produced by the REFERENCE ITSELF:
+oracle/_ref/libsaip_otg_ref.so = the vendored Ruckig 0.10.1 of /root/reference compiled in place (make -C oracle ref) behind the
+C-ABI driver oracle/ref_ruckig/otg_ref_shim.cpp (which restates the thin OTG_joints wrapper, file:line cited there).
+
+    python tests/golden/make_otg_golden.py            # rewrites tests/golden/otg_*.npz (needs /root/reference)
+
+A fixture is data only: the scenario (initial task positions, limits, a schedule of goal / limit / re-initialisation events) and
+the desired position / velocity / acceleration the reference produced at the sampled control cycles."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+DT = 1e-3
+
+
+def scenarios():
+    """name -> dict(robot, S rows or None, B, K, vmax, amax, events); events: (step, kind, payload) applied BEFORE that cycle"""
+    out = {}
+    rng = np.random.default_rng(0x07C0)
+    q_nom = np.array([0.0, -0.436, 0.0, -2.356, 0.0, 1.833, 0.0])
+    B = 12
+
+    # 1: from rest, default limits; first 4 instances move along a line through q0 (phase synchronisation keeps the line),
+    #    the rest have independent per-joint displacements; one unchanged goal (zero-duration trajectory)
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    g = q0 + rng.uniform(-0.6, 0.6, (B, 7))
+    g[:4] = q0[:4] + rng.uniform(-0.6, 0.6, (4, 1)) * rng.uniform(0.2, 1.0, (4, 7))
+    g[4] = q0[4]
+    out["otg_rest_to_goal"] = dict(robot="panda_arm", S=None, q0=q0, K=1250, vmax=np.pi / 3, amax=2 * np.pi,
+                                   events=[(0, "goal", (g, np.zeros((B, 7))))])
+
+    # 2: goal changes in flight (time synchronisation from a moving state), then a goal equal to the current one
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    g1 = q0 + rng.uniform(-0.5, 0.5, (B, 7))
+    g2 = g1 + rng.uniform(-0.4, 0.4, (B, 7))
+    g3 = q0.copy()
+    out["otg_goal_changes"] = dict(robot="panda_arm", S=None, q0=q0, K=1700, vmax=np.pi / 3, amax=2 * np.pi,
+                                   events=[(0, "goal", (g1, np.zeros((B, 7)))), (180, "goal", (g2, np.zeros((B, 7)))),
+                                           (420, "goal", (g3, np.zeros((B, 7))))])
+
+    # 3: per-joint limits, lowered in flight below the current speed (brake pre-trajectory), re-initialisation in flight
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    g1 = q0 + rng.uniform(-0.8, 0.8, (B, 7))
+    vm = np.array([1.0, 0.8, 1.2, 0.9, 1.5, 1.1, 2.0])
+    am = np.array([4.0, 3.0, 6.0, 5.0, 8.0, 7.0, 9.0])
+    q_re = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    g2 = q_re + rng.uniform(-0.3, 0.3, (B, 7))
+    out["otg_limits_brake_reinit"] = dict(robot="panda_arm", S=None, q0=q0, K=2100, vmax=vm, amax=am,
+                                          events=[(0, "goal", (g1, np.zeros((B, 7)))), (250, "limits", (0.35 * vm, 0.5 * am)),
+                                                  (900, "reinit", q_re), (900, "goal", (g2, np.zeros((B, 7))))])
+
+    # 4: partial joint task (rows 0,2,4,6 of I7, BASELINE config 3), non-zero goal velocities inside the limits.
+    #    A trajectory that FINISHES with non-zero velocity makes the reference throw (OTG_joints.cpp:131-133 passes a never-assigned
+    #    member on); the driver (and the engine) implement the documented intent instead, so this scenario pins that restated branch.
+    S = np.eye(7)[[0, 2, 4, 6]]
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    g1 = q0 @ S.T + rng.uniform(-0.5, 0.5, (B, 4))
+    gv = rng.uniform(-0.3, 0.3, (B, 4))
+    gv[:3] = 0.0
+    out["otg_partial_goal_velocity"] = dict(robot="panda_arm", S=S, q0=q0, K=900, vmax=np.pi / 3, amax=2 * np.pi,
+                                            events=[(0, "goal", (g1, gv)), (500, "goal", (g1, np.zeros((B, 4))))],
+                                            reference_throws=True)
+
+    # 5: 30-dof chain (32-lane groups)
+    B5 = 6
+    q0 = rng.uniform(-0.6, 0.6, (B5, 30))
+    g1 = q0 + rng.uniform(-0.5, 0.5, (B5, 30))
+    g1[0] = q0[0] + 0.4 * rng.uniform(0.1, 1.0, 30)
+    g2 = g1 + rng.uniform(-0.3, 0.3, (B5, 30))
+    out["otg_chain30"] = dict(robot="chain30", S=None, q0=q0, K=1300, vmax=np.pi / 3, amax=2 * np.pi,
+                              events=[(0, "goal", (g1, np.zeros((B5, 30)))), (300, "goal", (g2, np.zeros((B5, 30))))])
+    return out
+
+
+def sample_steps(K, events):
+    """cycles whose outputs are stored: every 7th, the last one, and 12 cycles after every event"""
+    s = set(range(0, K, 7)) | {K - 1}
+    for st, _, _ in events:
+        s |= set(range(st, min(K, st + 12)))
+    return np.array(sorted(s))
+
+
+def run_reference(sc):
+    import otg_ref as R
+    S = sc["S"]
+    q0 = sc["q0"]
+    x0 = q0 if S is None else q0 @ S.T
+    B, m = x0.shape
+    vm = np.broadcast_to(np.asarray(sc["vmax"], float), (m,))
+    am = np.broadcast_to(np.asarray(sc["amax"], float), (m,))
+    otg = [R.JointsOtgRef(x0[i], DT, vm, am) for i in range(B)]
+    gp, gv = x0.copy(), np.zeros_like(x0)   # JointTask::reInitializeTask: goal = current position, zero velocity
+    steps = sample_steps(sc["K"], sc["events"])
+    want = set(steps.tolist())
+    out = np.zeros((len(steps), 3, B, m))
+    reached = np.zeros((len(steps), B), bool)
+    moving = 0
+    row = 0
+    for k in range(sc["K"]):
+        for st, kind, payload in sc["events"]:
+            if st != k:
+                continue
+            if kind == "goal":
+                gp, gv = payload[0].copy(), payload[1].copy()
+            elif kind == "limits":
+                for o in otg:
+                    o.set_limits(np.broadcast_to(payload[0], (m,)), np.broadcast_to(payload[1], (m,)))
+            elif kind == "reinit":
+                xr = payload if S is None else payload @ S.T
+                for i, o in enumerate(otg):
+                    o.reinitialize(xr[i])
+                gp, gv = xr.copy(), np.zeros_like(xr)
+        for i, o in enumerate(otg):
+            p, v, a, g, res = o.step(gp[i], gv[i])
+            if k in want:
+                out[row, 0, i], out[row, 1, i], out[row, 2, i] = p, v, a
+                reached[row, i] = g
+        if k in want:
+            row += 1
+    moving = sum(o.finished_with_velocity for o in otg)
+    return steps, out, reached, moving
+
+
+def pack(sc, steps, out, reached, moving):
+    d = dict(robot=sc["robot"], S=np.zeros((0, 0)) if sc["S"] is None else sc["S"], q0=sc["q0"], K=sc["K"], dt=DT,
+             vmax=np.asarray(sc["vmax"], float), amax=np.asarray(sc["amax"], float), steps=steps, desired=out, goal_reached=reached,
+             finished_with_velocity=moving, reference_throws=bool(sc.get("reference_throws", False)), n_events=len(sc["events"]))
+    for i, (st, kind, payload) in enumerate(sc["events"]):
+        d[f"ev{i}_step"] = st
+        d[f"ev{i}_kind"] = kind
+        if kind == "reinit":
+            d[f"ev{i}_a"] = payload
+        else:
+            d[f"ev{i}_a"], d[f"ev{i}_b"] = np.asarray(payload[0], float), np.asarray(payload[1], float)
+    return d
+
+
+def load(path):
+    """fixture -> (scenario dict in the scenarios() format, steps, desired, goal_reached, meta)"""
+    z = np.load(path)
+    ev = []
+    for i in range(int(z["n_events"])):
+        kind = str(z[f"ev{i}_kind"])
+        ev.append((int(z[f"ev{i}_step"]), kind, z[f"ev{i}_a"] if kind == "reinit" else (z[f"ev{i}_a"], z[f"ev{i}_b"])))
+    S = z["S"]
+    sc = dict(robot=str(z["robot"]), S=None if S.size == 0 else S, q0=z["q0"], K=int(z["K"]), vmax=z["vmax"], amax=z["amax"], events=ev,
+              reference_throws=bool(z["reference_throws"]))
+    return sc, z["steps"], z["desired"], z["goal_reached"], dict(finished_with_velocity=int(z["finished_with_velocity"]), dt=float(z["dt"]))
+
+
+if __name__ == "__main__":
+    import otg_ref as R
+    if R.build() is None:
+        raise SystemExit("the reference build oracle/_ref/libsaip_otg_ref.so is not available (needs /root/reference)")
+    for name, sc in scenarios().items():
+        steps, out, reached, moving = run_reference(sc)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(sc, steps, out, reached, moving))
+        print(f"{name}: B={sc['q0'].shape[0]} K={sc['K']} samples={len(steps)} reached_at_end={int(reached[-1].sum())} finished_with_velocity={moving}")

@@ -12,7 +12,7 @@ import workloads as W
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))
 
 
 def _engine(model_name, tasks, B, **kw):
@@ -167,10 +167,12 @@ def test_call_order_and_otg_are_loud():
     with pytest.raises(sp.SaipError):  # compute before update
         ctrl.computeControlTorques()
     ctrl.updateControllerTaskModels()
-    tasks[0].enableInternalOtgAccelerationLimited()
+    tasks[0].enableInternalOtgAccelerationLimited()   # Cartesian OTG of the motion-force task: not on the device
     with pytest.raises(sp.SaipUnsupported):
         ctrl.computeControlTorques()
     tasks[0].disableInternalOtg()
+    with pytest.raises(sp.SaipUnsupported):           # jerk-limited joint OTG: not on the device
+        tasks[1].enableInternalOtgJerkLimited(1.0, 2.0, 10.0)
     ctrl.setGoals(d["goals"])
     assert np.isfinite(ctrl.computeControlTorques()).all()
 

@@ -13,7 +13,7 @@ import pytest
 import workloads as W
 from oracle import Oracle
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))
 
 
 def load_golden(path):
