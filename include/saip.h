@@ -124,23 +124,27 @@ saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold
 /* MotionForceTask::setSingularityHandlingBounds (.h:736) */
 saip_status saip_batch_set_singularity_bounds(saip_batch*, int task, double s_min, double s_max);
 /* disableInternalOtg / enableInternalOtg* (MotionForceTask.h:423, JointTask.h:323).  The reference default is ENABLED.
- * Joint tasks: the acceleration-limited OTG (the reference default mode; OTG_joints.cpp + Ruckig second-order position
- * interface with phase synchronisation) runs on the device, one launch ahead of the cycle kernel, and the control law tracks its
- * output (JointTask.cpp:313-319).  Motion-force tasks: the Cartesian OTG (OTG_6dof_cartesian) is not on the device yet, a cycle
- * with it enabled fails with SAIP_ERR_UNSUPPORTED -- call this with enabled = 0 (disableInternalOtg). */
+ * The acceleration-limited OTG (the reference default mode; Ruckig second-order position interface with phase
+ * synchronisation) runs on the device, one launch ahead of the cycle kernel, and the control law tracks its output:
+ * joint tasks OTG_joints.cpp (JointTask.cpp:313-319), motion-force tasks OTG_6dof_cartesian.cpp (MotionForceTask.cpp:394-406). */
 saip_status saip_batch_set_internal_otg(saip_batch*, int task, int enabled);
 /* JointTask::enableInternalOtgAccelerationLimited(max_velocity, max_acceleration) (JointTask.cpp:358-381): count = 1 (scalar) or
  * task dof; values <= 0 -> SAIP_ERR_INVALID_ARGUMENT (OTG_joints.cpp:44-74).  Defaults pi/3 rad/s, 2 pi rad/s^2 (JointTask.h:40-41).
- * Enabling a previously disabled OTG re-initialises it at the current task position on the next cycle. */
+ * MotionForceTask::enableInternalOtgAccelerationLimited(max_lin_vel, max_lin_acc, max_ang_vel, max_ang_acc)
+ * (MotionForceTask.cpp:510-523): count = 2, max_velocity = {linear, angular}, max_acceleration = {linear, angular}; defaults
+ * 0.3 m/s, 2 m/s^2, pi/3 rad/s, 2 pi rad/s^2 (MotionForceTask.h:68-71).
+ * Enabling a previously disabled OTG re-initialises it at the current task position / pose on the next cycle. */
 saip_status saip_batch_set_otg_acceleration_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, int count);
 /* JointTask::enableInternalOtgJerkLimited (JointTask.cpp:383-406): third-order Ruckig profiles are not implemented -> SAIP_ERR_UNSUPPORTED */
 saip_status saip_batch_set_otg_jerk_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, const double* max_jerk, int count);
 /* getDesiredPosition/Velocity/Acceleration (JointTask.h:185-200; MotionForceTask desired* likewise): [goal_components][B] in the
  * goal layout -- the internal OTG's output of the last cycle when it is enabled, otherwise the goal itself. */
 saip_status saip_batch_get_desired_host(saip_batch*, int task, double* desired);
-/* per-instance OTG state of a joint task after the last cycle: flags (bit 0 goal reached = OTG_joints::isGoalReached, bit 3 an
+/* per-instance OTG state of a task after the last cycle: flags (bit 0 goal reached = OTG_joints::isGoalReached, bit 3 an
  * error occurred since the last re-initialisation, bit 4 a trajectory finished with non-zero velocity) and the ruckig::Result of
- * the last cycle (0 Working, 1 Finished, < 0 error codes of ruckig/result.hpp).  Either pointer may be NULL. */
+ * the last cycle (0 Working, 1 Finished, < 0 error codes of ruckig/result.hpp).  Motion-force tasks additionally: bit 6 = the
+ * goal orientation of the last cycle was not a rotation matrix (the reference throws, OTG_6dof_cartesian.cpp:158-162; the goal
+ * is ignored).  Either pointer may be NULL. */
 saip_status saip_batch_get_otg_status_host(saip_batch*, int task, int* flags, int* result);
 /* velocity saturation: MotionForceTask::enableVelocitySaturation(linear, angular) / disableVelocitySaturation
  * (MotionForceTask.cpp:771-792, law :416-430, :449-462); JointTask::enableVelocitySaturation(value | vector) (JointTask.cpp:410-436,

@@ -41,6 +41,13 @@ def lib():
         L.otgref_joints_set_limits.argtypes = [C.c_void_p, dp, dp]
         L.otgref_joints_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, ip]
         L.otgref_joints_finished_with_velocity.argtypes = [C.c_void_p]
+        L.otgref_cart_create.restype = C.c_void_p
+        L.otgref_cart_create.argtypes = [C.c_double, dp, dp, dp]
+        L.otgref_cart_destroy.argtypes = [C.c_void_p]
+        L.otgref_cart_set_limits.argtypes = [C.c_void_p, dp]
+        L.otgref_cart_reinitialize.argtypes = [C.c_void_p, dp, dp, C.c_int]
+        L.otgref_cart_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, ip]
+        L.otgref_cart_finished_with_velocity.argtypes = [C.c_void_p]
         L.otgref_calculate.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp]
         _LIB = L
     return _LIB
@@ -85,6 +92,43 @@ class JointsOtgRef:
     @property
     def finished_with_velocity(self):
         return lib().otgref_joints_finished_with_velocity(self._h)
+
+
+class CartesianOtgRef:
+    """one OTG_6dof_cartesian instance (acceleration-limited), /root/reference/src/helper_modules/OTG_6dof_cartesian.cpp.
+    limits = (max linear velocity, max linear acceleration, max angular velocity, max angular acceleration)"""
+
+    def __init__(self, pos0, R0, dt, limits=(0.3, 2.0, np.pi / 3, 2 * np.pi)):
+        p, R, lim = (np.ascontiguousarray(x, float) for x in (pos0, np.asarray(R0).reshape(9), limits))
+        self._h = lib().otgref_cart_create(float(dt), _p(p), _p(R), _p(lim))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().otgref_cart_destroy(self._h)
+            self._h = None
+
+    def set_limits(self, limits):
+        lim = np.ascontiguousarray(limits, float)
+        lib().otgref_cart_set_limits(self._h, _p(lim))
+
+    def reinitialize(self, pos, R, mask=3):
+        p, Rm = np.ascontiguousarray(pos, float), np.ascontiguousarray(np.asarray(R).reshape(9), float)
+        lib().otgref_cart_reinitialize(self._h, _p(p), _p(Rm), int(mask))
+
+    def step(self, goal_pos, goal_R, goal_linvel=None, goal_angvel=None):
+        """-> (desired[24] in the motion-force goal layout, goal_reached, ruckig result)"""
+        gp = np.ascontiguousarray(goal_pos, float)
+        gR = np.ascontiguousarray(np.asarray(goal_R).reshape(9), float)
+        gv = np.zeros(3) if goal_linvel is None else np.ascontiguousarray(goal_linvel, float)
+        gw = np.zeros(3) if goal_angvel is None else np.ascontiguousarray(goal_angvel, float)
+        out = np.zeros(24)
+        gr = C.c_int(0)
+        res = lib().otgref_cart_step(self._h, _p(gp), _p(gR), _p(gv), _p(gw), _p(out), C.byref(gr))
+        return out, bool(gr.value), res
+
+    @property
+    def finished_with_velocity(self):
+        return lib().otgref_cart_finished_with_velocity(self._h)
 
 
 def calculate(p0, v0, pf, vf, vmax, amax, sync=2, times=()):

@@ -4,9 +4,9 @@ Same class and method names as the reference (camelCase kept on purpose so that 
 /root/reference/examples/05-using_robot_controller/05-using_robot_controller.cpp:103-196), with every
 per-robot Eigen vector replaced by a (B, size) NumPy array.  Differences from the reference, all loud:
   * one SaiModel object = B robot instances of the same robot (state arrays are (B, dof));
-  * the internal OTG is ENABLED by default like in the reference.  JointTask: the acceleration-limited OTG (the reference
-    default mode) runs on the device; the jerk-limited mode raises SaipUnsupported.  MotionForceTask: the Cartesian OTG is
-    not on the device yet, computeControlTorques raises until disableInternalOtg() is called on those tasks;
+  * the internal OTG is ENABLED by default like in the reference: the acceleration-limited mode (the reference default) of both
+    the joint OTG (OTG_joints) and the Cartesian OTG (OTG_6dof_cartesian) runs on the device; the jerk-limited mode raises
+    SaipUnsupported;
   * singular / blended SingularityHandler branches and closed-loop force control are "next" rows: requesting them raises
     SaipUnsupported; instances that leave the non-singular branch get status 1 and NaN torques.
 """
@@ -191,10 +191,6 @@ class _Task:
         self._otg_enabled = False
         self._cfg("saip_batch_set_internal_otg", 0)
 
-    def enableInternalOtgAccelerationLimited(self, *a):
-        """MotionForceTask (max_lin_vel, max_lin_acc, max_ang_vel, max_ang_acc): not on the device yet -> raises at the next cycle"""
-        self._cfg("saip_batch_set_internal_otg", 1)
-
     def enableInternalOtgJerkLimited(self, *a):
         """third-order (jerk-limited) Ruckig profiles are not implemented on the device"""
         z = np.zeros(1)
@@ -203,6 +199,22 @@ class _Task:
 
     def getInternalOtgEnabled(self):
         return self._otg_enabled
+
+    def _desired_block(self):
+        """(B, goal_components): what the control law tracks -- the internal OTG's output when enabled, else the goal"""
+        ctrl = self._need_ctrl()
+        gs = capi.lib().saip_batch_goal_components(ctrl._h, self._id)
+        out = np.empty((gs, ctrl._robot.batch_size))
+        ctrl._call("saip_batch_get_desired_host", self._id, _dptr(out))
+        return out.T
+
+    def getInternalOtgStatus(self):
+        """(goal_reached (B,) bool = OTG::isGoalReached, flags (B,) int, result (B,) int = ruckig::Result of the last cycle)"""
+        ctrl = self._need_ctrl()
+        fl, res = np.zeros(ctrl._robot.batch_size, np.int32), np.zeros(ctrl._robot.batch_size, np.int32)
+        ip = C.POINTER(C.c_int)
+        ctrl._call("saip_batch_get_otg_status_host", self._id, fl.ctypes.data_as(ip), res.ctypes.data_as(ip))
+        return (fl & 1).astype(bool), fl, res
 
     def enableVelocitySaturation(self, *values):
         """MotionForceTask: (linear_vel_sat, angular_vel_sat); JointTask: (value) or (vector of task dof); () keeps the defaults"""
@@ -332,6 +344,34 @@ class MotionForceTask(_Task):
     def getGoalOrientation(self):
         return self._get_goal()[:, 3:12].reshape(-1, 3, 3)
 
+    # internal Cartesian OTG (OTG_6dof_cartesian), acceleration-limited mode on the device.  MotionForceTask.h:387-423
+    def enableInternalOtgAccelerationLimited(self, max_linear_velocity=0.3, max_linear_acceleration=2.0,
+                                             max_angular_velocity=np.pi / 3, max_angular_acceleration=2 * np.pi):
+        v = np.ascontiguousarray([float(max_linear_velocity), float(max_angular_velocity)])
+        a = np.ascontiguousarray([float(max_linear_acceleration), float(max_angular_acceleration)])
+        self._keepalive.append((v, a))
+        self._otg_enabled = True
+        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), 2)
+
+    # desired state = OTG output when enabled, else the goal (MotionForceTask.h getDesired*)
+    def getDesiredPosition(self):
+        return self._desired_block()[:, 0:3]
+
+    def getDesiredOrientation(self):
+        return self._desired_block()[:, 3:12].reshape(-1, 3, 3)
+
+    def getDesiredLinearVelocity(self):
+        return self._desired_block()[:, 12:15]
+
+    def getDesiredAngularVelocity(self):
+        return self._desired_block()[:, 15:18]
+
+    def getDesiredLinearAcceleration(self):
+        return self._desired_block()[:, 18:21]
+
+    def getDesiredAngularAcceleration(self):
+        return self._desired_block()[:, 21:24]
+
     # gains, MotionForceTask.h:272-300
     def setPosControlGains(self, kp, kv, ki=0.0):
         self._gains("saip_batch_set_pos_control_gains", kp, kv, ki)
@@ -405,30 +445,16 @@ class JointTask(_Task):
         self._otg_enabled = True
         self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), int(v.shape[0]))
 
-    def _desired(self):
-        ctrl = self._need_ctrl()
-        out = np.empty((3 * self.getTaskDof(), ctrl._robot.batch_size))
-        ctrl._call("saip_batch_get_desired_host", self._id, _dptr(out))
-        return out.T
-
     def getDesiredPosition(self):  # JointTask.h:185-200: the OTG output when enabled, else the goal
-        return self._desired()[:, :self.getTaskDof()]
+        return self._desired_block()[:, :self.getTaskDof()]
 
     def getDesiredVelocity(self):
         m = self.getTaskDof()
-        return self._desired()[:, m:2 * m]
+        return self._desired_block()[:, m:2 * m]
 
     def getDesiredAcceleration(self):
         m = self.getTaskDof()
-        return self._desired()[:, 2 * m:]
-
-    def getInternalOtgStatus(self):
-        """(goal_reached (B,) bool, flags (B,) int, result (B,) int = ruckig::Result of the last cycle)"""
-        ctrl = self._need_ctrl()
-        fl, res = np.zeros(ctrl._robot.batch_size, np.int32), np.zeros(ctrl._robot.batch_size, np.int32)
-        ip = C.POINTER(C.c_int)
-        ctrl._call("saip_batch_get_otg_status_host", self._id, fl.ctypes.data_as(ip), res.ctypes.data_as(ip))
-        return (fl & 1).astype(bool), fl, res
+        return self._desired_block()[:, 2 * m:]
 
 
 class RobotController:

@@ -98,13 +98,14 @@ struct CycleParams {
 };
 
 // Internal OTG of one joint task (saip_otg.hip).  Passed to the kernel by value.
-enum { OTG_FLAG_GOAL_REACHED = 1, OTG_FLAG_RUCKIG_INIT = 2, OTG_FLAG_STATE_VALID = 4, OTG_FLAG_ERROR = 8, OTG_FLAG_FINISHED_MOVING = 16 };
+enum { OTG_FLAG_GOAL_REACHED = 1, OTG_FLAG_RUCKIG_INIT = 2, OTG_FLAG_STATE_VALID = 4, OTG_FLAG_ERROR = 8, OTG_FLAG_FINISHED_MOVING = 16,
+	   OTG_FLAG_GOAL_ORI_VALID = 32, OTG_FLAG_INVALID_GOAL = 64 };
 struct OtgDev {
 	int m, gs;             // task dof; lanes per robot (8 or 32)
 	int epoch, pad_;       // bumped when the limits change: forces a new trajectory like InputParameter::operator!= does
 	long long lanes;       // B * gs = stride of one state field
 	double dt;             // control period (Ruckig delta_time)
-	double vmax[SAIP_MAXN], amax[SAIP_MAXN];
+	const double* limits;  // [2][SAIP_MAXN] device copy of the limits below: max velocity, max acceleration per task dof
 	double* state;         // [fields][lanes], lane-major
 	double* time;          // [ld] OutputParameter::time
 	double* duration;      // [ld] Trajectory::duration
@@ -114,8 +115,12 @@ struct OtgDev {
 	const double* goal;    // [3m][ld] user goal (position, velocity, acceleration rows)
 	double* desired;       // [3m][ld] desired state fed to the control law
 	const double* q;       // [n][ld] (re-initialisation only)
-	const TaskDev* task;   // selection matrix S (re-initialisation only)
-	int n, pad2_;
+	const TaskDev* task;   // selection matrix S / control frame (re-initialisation only)
+	int n, goal_comps;
+	// Cartesian OTG of a motion-force task (OTG_6dof_cartesian): per-instance frames [21][ld] = _reference_frame (9),
+	// _goal_orientation_in_base_frame (9), _goal_angular_velocity_in_base_frame (3)
+	double* frame;
+	const ModelDev* model;
 };
 
 }  // namespace saip

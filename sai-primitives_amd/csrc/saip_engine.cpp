@@ -18,6 +18,7 @@ hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
+hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 int otg_state_fields();
 }  // namespace saip
 
@@ -309,8 +310,10 @@ struct TaskHost {
 	double P[36];
 	bool otg_enabled = true;  // reference default (MotionForceTask.h:67, JointTask.h:38)
 	// internal OTG of a joint task (saip_otg.hip): acceleration-limited, defaults JointTask.h:39-41
-	bool otg_alloc = false, otg_inited = false;
+	bool otg_alloc = false, otg_inited = false, otg_limits_dirty = true;
 	OtgDev otg;
+	double otg_limits[2 * SAIP_MAXN];  // max velocity, max acceleration per task dof
+	double* otg_limits_dev = nullptr;
 	double* desired_dev = nullptr;
 	bool vel_sat = false;
 	bool full_joint = false;
@@ -464,6 +467,16 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
 	T.integ_rows = 6;
 	refresh_has_ki(T.dev);
+	memset(&T.otg, 0, sizeof(T.otg));
+	T.otg.m = 6;
+	T.otg.gs = 8;
+	for (int i = 0; i < SAIP_MAXN; i++) T.otg_limits[i] = T.otg_limits[SAIP_MAXN + i] = 1.0;
+	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:68-71
+		T.otg_limits[i] = 0.3;
+		T.otg_limits[SAIP_MAXN + i] = 2.0;
+		T.otg_limits[3 + i] = M_PI / 3.0;
+		T.otg_limits[SAIP_MAXN + 3 + i] = 2.0 * M_PI;
+	}
 	b->tasks.push_back(T);
 	b->config_dirty = true;
 	if (task_id) *task_id = (int)b->tasks.size() - 1;
@@ -536,8 +549,8 @@ extern "C" saip_status saip_batch_add_joint_task(saip_batch* b, const char* task
 	T.otg.m = T.dev.m;
 	T.otg.gs = T.dev.m <= 8 ? 8 : 32;
 	for (int i = 0; i < SAIP_MAXN; i++) {
-		T.otg.vmax[i] = M_PI / 3.0;   // DefaultParameters::otg_max_velocity, JointTask.h:40
-		T.otg.amax[i] = 2.0 * M_PI;   // DefaultParameters::otg_max_acceleration, JointTask.h:41
+		T.otg_limits[i] = M_PI / 3.0;              // DefaultParameters::otg_max_velocity, JointTask.h:40
+		T.otg_limits[SAIP_MAXN + i] = 2.0 * M_PI;  // DefaultParameters::otg_max_acceleration, JointTask.h:41
 	}
 	b->tasks.push_back(T);
 	b->config_dirty = true;
@@ -731,9 +744,29 @@ extern "C" saip_status saip_batch_set_internal_otg(saip_batch* b, int t, int ena
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_set_otg_acceleration_limited(saip_batch* b, int t, const double* max_velocity, const double* max_acceleration, int count) {
-	saip_status st = need_type(b, t, saip::TASK_JOINT, "saip_batch_set_otg_acceleration_limited");
+	saip_status st = check_batch(b, t, "saip_batch_set_otg_acceleration_limited");
 	if (st) return st;
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
 	TaskHost& T = b->tasks[t];
+	if (T.dev.type == saip::TASK_MOTION_FORCE) {
+		// MotionForceTask::enableInternalOtgAccelerationLimited(max_lin_vel, max_lin_acc, max_ang_vel, max_ang_acc), MotionForceTask.cpp:510-523
+		if (!max_velocity || !max_acceleration || count != 2)
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "motion-force task: pass {linear, angular} max velocities and max accelerations (count = 2)");
+		for (int i = 0; i < 2; i++) {
+			if (!(max_velocity[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMax%sVelocity", i ? "Angular" : "Linear");
+			if (!(max_acceleration[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMax%sAcceleration", i ? "Angular" : "Linear");
+		}
+		for (int i = 0; i < 6; i++) {
+			T.otg_limits[i] = max_velocity[i / 3];
+			T.otg_limits[SAIP_MAXN + i] = max_acceleration[i / 3];
+		}
+		T.otg_limits_dirty = true;
+		T.otg.epoch++;
+		if (!T.otg_enabled) T.otg_inited = false;
+		T.otg_enabled = true;
+		b->config_dirty = true;
+		return SAIP_OK;
+	}
 	const int m = T.dev.m;
 	if (!max_velocity || !max_acceleration || (count != 1 && count != m))
 		return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity or max acceleration vector size not consistent with task dof in JointTask::enableInternalOtgAccelerationLimited");
@@ -742,9 +775,10 @@ extern "C" saip_status saip_batch_set_otg_acceleration_limited(saip_batch* b, in
 		if (!(max_acceleration[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration");
 	}
 	for (int i = 0; i < m; i++) {
-		T.otg.vmax[i] = max_velocity[count == 1 ? 0 : i];
-		T.otg.amax[i] = max_acceleration[count == 1 ? 0 : i];
+		T.otg_limits[i] = max_velocity[count == 1 ? 0 : i];
+		T.otg_limits[SAIP_MAXN + i] = max_acceleration[count == 1 ? 0 : i];
 	}
+	T.otg_limits_dirty = true;
 	T.otg.epoch++;
 	if (!T.otg_enabled) T.otg_inited = false;
 	T.otg_enabled = true;
@@ -947,8 +981,14 @@ static saip_status ensure_otg(saip_batch* b, TaskHost& T) {
 	O.n = b->model->n;
 	if ((st = dev_alloc(b, &O.state, (size_t)saip::otg_state_fields() * (size_t)O.lanes)) || (st = dev_alloc(b, &O.time, (size_t)b->ld)) ||
 		(st = dev_alloc(b, &O.duration, (size_t)b->ld)) || (st = dev_alloc(b, &O.flags, (size_t)b->ld)) || (st = dev_alloc(b, &O.seen_epoch, (size_t)b->ld)) ||
-		(st = dev_alloc(b, &O.result, (size_t)b->ld)) || (st = dev_alloc(b, &T.desired_dev, (size_t)T.dev.goal_comps * b->ld)))
+		(st = dev_alloc(b, &O.result, (size_t)b->ld)) || (st = dev_alloc(b, &T.desired_dev, (size_t)T.dev.goal_comps * b->ld)) ||
+		(st = dev_alloc(b, &T.otg_limits_dev, (size_t)2 * SAIP_MAXN)))
 		return st;
+	if (T.dev.type == saip::TASK_MOTION_FORCE && (st = dev_alloc(b, &O.frame, (size_t)21 * b->ld))) return st;
+	O.model = b->model_dev;
+	O.goal_comps = T.dev.goal_comps;
+	O.limits = T.otg_limits_dev;
+	T.otg_limits_dirty = true;
 	O.desired = T.desired_dev;
 	O.goal = T.goal_dev;
 	O.q = b->q;
@@ -957,20 +997,25 @@ static saip_status ensure_otg(saip_batch* b, TaskHost& T) {
 	return SAIP_OK;
 }
 // mode 1: OTG_joints::reInitialize(S q) for every instance; mode 0: one cycle of setGoal + update
-static saip_status run_otg(saip_batch* b, int t, int mode) {
+static saip_status run_otg(saip_batch* b, int t, int mode, int mask = 3) {
 	TaskHost& T = b->tasks[t];
+	T.otg.goal_comps = T.dev.goal_comps;
 	T.otg.task = b->tasks_dev + t;
 	T.otg.dt = T.dev.dt;
-	hipError_t e = saip::launch_otg_joints(T.otg, b->B, b->ld, mode, b->stream);
+	if (T.otg_limits_dirty) {
+		HIP_TRY(hipMemcpyAsync(T.otg_limits_dev, T.otg_limits, sizeof(T.otg_limits), hipMemcpyHostToDevice, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));  // limits change rarely; keeps the host array free to change again
+		T.otg_limits_dirty = false;
+	}
+	hipError_t e = T.dev.type == saip::TASK_JOINT ? saip::launch_otg_joints(T.otg, b->B, b->ld, mode, b->stream)
+												  : saip::launch_otg_cartesian(T.otg, b->B, b->ld, mode | (mask << 4), b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "OTG kernel launch failed: %s", hipGetErrorString(e));
-	if (mode == 1) T.otg_inited = true;
+	if (mode == 1 && mask == 3) T.otg_inited = true;
 	return SAIP_OK;
 }
 
 static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	for (auto& T : b->tasks) {
-		if (T.otg_enabled && T.dev.type != saip::TASK_JOINT)  // reference default; the Cartesian OTG (OTG_6dof_cartesian) is not on the device yet
-			return fail(SAIP_ERR_UNSUPPORTED, "task [%s]: internal OTG is enabled (reference default) but the Cartesian OTG is not implemented on the device; call saip_batch_set_internal_otg(batch, task, 0) (disableInternalOtg)", T.name.c_str());
 		if (T.otg_enabled) {
 			saip_status st = ensure_otg(b, T);
 			if (st) return st;
@@ -981,7 +1026,7 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 		for (auto& T : b->tasks) {
 			TaskDev d = T.dev;
 			d.diag_N = diag ? T.diag_dev : nullptr;
-			if (T.otg_enabled && T.dev.type == saip::TASK_JOINT) d.goal = T.desired_dev;  // the law tracks the OTG output (JointTask.cpp:317-319)
+			if (T.otg_enabled) d.goal = T.desired_dev;  // the law tracks the OTG output (JointTask.cpp:317-319, MotionForceTask.cpp:394-406)
 			tmp.push_back(d);
 		}
 		HIP_TRY(hipMemcpyAsync(b->tasks_dev, tmp.data(), tmp.size() * sizeof(TaskDev), hipMemcpyHostToDevice, b->stream));
@@ -1062,7 +1107,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	if (st) return st;
 	for (size_t t = 0; t < b->tasks.size(); t++) {
 		TaskHost& T = b->tasks[t];
-		if (!T.otg_enabled || T.dev.type != saip::TASK_JOINT) continue;
+		if (!T.otg_enabled) continue;
 		if (!T.otg_inited && (st = run_otg(b, (int)t, 1))) return st;
 		if (!diag && (st = run_otg(b, (int)t, 0))) return st;  // a diagnostic re-launch must not advance the trajectory
 	}
@@ -1095,8 +1140,12 @@ static saip_status launch_reinit_masked(saip_batch* b, int task, int mask) {
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "reinit launch failed: %s", hipGetErrorString(e));
 	for (size_t t = 0; t < b->tasks.size(); t++) {  // JointTask::reInitializeTask -> _otg->reInitialize (JointTask.cpp:106)
 		TaskHost& T = b->tasks[t];
-		if ((task >= 0 && (int)t != task) || T.dev.type != saip::TASK_JOINT || !T.otg_enabled || !(mask & 1)) continue;
-		if ((st = ensure_otg(b, T)) || (st = run_otg(b, (int)t, 1))) return st;
+		if ((task >= 0 && (int)t != task) || !T.otg_enabled) continue;
+		const int m3 = T.dev.type == saip::TASK_JOINT ? ((mask & 1) ? 3 : 0) : (mask & 3);  // linear / angular parts (reInitializeLinear / Angular)
+		if (m3 == 0) continue;
+		if ((st = ensure_otg(b, T))) return st;
+		if (m3 != 3 && !T.otg_inited && (st = run_otg(b, (int)t, 1, 3))) return st;
+		if ((st = run_otg(b, (int)t, 1, m3))) return st;
 	}
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	return SAIP_OK;
@@ -1179,12 +1228,13 @@ extern "C" saip_status saip_batch_get_desired_host(saip_batch* b, int t, double*
 	if ((st = check_batch(b, t, "saip_batch_get_desired_host"))) return st;
 	if (t < 0 || !desired) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_get_desired_host: bad argument");
 	TaskHost& T = b->tasks[t];
-	const bool otg = T.otg_enabled && T.dev.type == saip::TASK_JOINT && T.otg_alloc && T.otg_inited;
+	const bool otg = T.otg_enabled && T.otg_alloc && T.otg_inited;
 	return copy_d2h(b, desired, otg ? T.desired_dev : T.goal_dev, T.dev.goal_comps);
 }
 extern "C" saip_status saip_batch_get_otg_status_host(saip_batch* b, int t, int* flags, int* result) {
-	saip_status st = need_type(b, t, saip::TASK_JOINT, "saip_batch_get_otg_status_host");
+	saip_status st = check_batch(b, t, "saip_batch_get_otg_status_host");
 	if (st) return st;
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
 	if ((st = need_ready(b, "saip_batch_get_otg_status_host"))) return st;
 	TaskHost& T = b->tasks[t];
 	if (!T.otg_alloc) return fail(SAIP_ERR_ORDER, "saip_batch_get_otg_status_host: the internal OTG of task [%s] has not run", T.name.c_str());

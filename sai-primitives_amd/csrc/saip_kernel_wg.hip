@@ -27,6 +27,7 @@
 #include "saip_device.h"
 #include "saip_law.h"
 #include "saip_wg_linalg.h"
+#include "saip_fk.h"
 
 #if defined(SAIP_STAMP_WG)
 // diagnostic build only (never shipped): s_memtime stamp of block 0 / thread 0 after every barrier of the kernel body
@@ -752,46 +753,18 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 		if (P.reinit_task >= 0 && t != P.reinit_task) continue;
 		const TaskDev& tk = P.tasks[t];
 		if (tk.type == TASK_MOTION_FORCE) {
-			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
-			for (int j = 0; j <= tk.body; j++) {
-				double t3[3], Rn[9], Rt[9];
-				mat3_mul_vec(R, md.p0[j], t3);
-				for (int e = 0; e < 3; e++) o[e] += t3[e];
-				for (int r = 0; r < 3; r++)
-					for (int c = 0; c < 3; c++) Rt[3 * r + c] = R[3 * r] * md.R0[j][c] + R[3 * r + 1] * md.R0[j][3 + c] + R[3 * r + 2] * md.R0[j][6 + c];
-				double qj = P.q[(size_t)j * P.ld + b];
-				const double ax = md.axis[j][0], ay = md.axis[j][1], az = md.axis[j][2];
-				if (md.jtype[j] == 1) {
-					double s, c;
-					sincos(qj, &s, &c);
-					double v = 1.0 - c;
-					double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
-									ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
-									az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
-					for (int r = 0; r < 3; r++)
-						for (int c2 = 0; c2 < 3; c2++) Rn[3 * r + c2] = Rt[3 * r] * Rq[c2] + Rt[3 * r + 1] * Rq[3 + c2] + Rt[3 * r + 2] * Rq[6 + c2];
-				} else {
-					double a[3] = {ax, ay, az}, d[3];
-					mat3_mul_vec(Rt, a, d);
-					for (int e = 0; e < 3; e++) o[e] += d[e] * qj;
-					for (int e = 0; e < 9; e++) Rn[e] = Rt[e];
-				}
-				for (int e = 0; e < 9; e++) R[e] = Rn[e];
-			}
-			double p[3];
-			mat3_mul_vec(R, tk.pos, p);
+			double pw[3], Rc[9];
+			fk_control_frame(md, tk, P.q, P.ld, b, pw, Rc);
 			if (mask & 1) {  // linear part: goal position := current, velocity/acceleration := 0, integrator := 0
 				for (int e = 0; e < 3; e++) {
-					tk.goal[(size_t)e * P.ld + b] = o[e] + p[e];
+					tk.goal[(size_t)e * P.ld + b] = pw[e];
 					tk.goal[(size_t)(12 + e) * P.ld + b] = 0.0;
 					tk.goal[(size_t)(18 + e) * P.ld + b] = 0.0;
 					tk.integ[(size_t)e * P.ld + b] = 0.0;
 				}
 			}
 			if (mask & 2) {  // angular part
-				for (int r = 0; r < 3; r++)
-					for (int c = 0; c < 3; c++)
-						tk.goal[(size_t)(3 + 3 * r + c) * P.ld + b] = R[3 * r] * tk.rot[c] + R[3 * r + 1] * tk.rot[3 + c] + R[3 * r + 2] * tk.rot[6 + c];
+				for (int e = 0; e < 9; e++) tk.goal[(size_t)(3 + e) * P.ld + b] = Rc[e];
 				for (int e = 0; e < 3; e++) {
 					tk.goal[(size_t)(15 + e) * P.ld + b] = 0.0;
 					tk.goal[(size_t)(21 + e) * P.ld + b] = 0.0;

@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_fk.h"
 
 #pragma clang fp contract(off)
 
@@ -358,11 +359,262 @@ __device__ __forceinline__ Sample sample_profile(double time, double duration, c
 	return s;
 }
 
+
+// ---------------------------------------------------------------- per-lane state and the shared Ruckig::update
+struct Lane {
+	double in_p, in_v, in_a, tg_p, tg_v, out_p, out_v, out_a;  // wrapper _input.current/target, _output.new
+	double ci_p, ci_v, ci_a, ci_tp, ci_tv;                      // ruckig current_input
+	double t[7], a[7], P0, V0, br_t, br_a, br_p, br_v;          // stored trajectory of this dof
+};
+
+#define ST(f) S[(size_t)(f) * stride + li]
+__device__ __forceinline__ void lane_load(Lane& L, const double* S, size_t stride, size_t li, bool act) {
+	L.in_p = L.in_v = L.in_a = L.tg_p = L.tg_v = L.out_p = L.out_v = L.out_a = 0.0;
+	L.ci_p = L.ci_v = L.ci_a = L.ci_tp = L.ci_tv = 0.0;
+#pragma unroll
+	for (int i = 0; i < 7; i++) L.t[i] = L.a[i] = 0.0;
+	L.P0 = L.V0 = L.br_t = L.br_a = L.br_p = L.br_v = 0.0;
+	if (!act) return;
+	L.in_p = ST(F_IN_P);
+	L.in_v = ST(F_IN_V);
+	L.in_a = ST(F_IN_A);
+	L.tg_p = ST(F_TG_P);
+	L.tg_v = ST(F_TG_V);
+	L.out_p = ST(F_OUT_P);
+	L.out_v = ST(F_OUT_V);
+	L.out_a = ST(F_OUT_A);
+	L.ci_p = ST(F_CI_P);
+	L.ci_v = ST(F_CI_V);
+	L.ci_a = ST(F_CI_A);
+	L.ci_tp = ST(F_CI_TP);
+	L.ci_tv = ST(F_CI_TV);
+	L.t[0] = ST(F_T0);
+	L.t[1] = ST(F_T1);
+	L.t[2] = ST(F_T2);
+	L.t[6] = ST(F_T6);
+	L.a[0] = ST(F_A0);
+	L.a[2] = ST(F_A2);
+	L.a[6] = ST(F_A6);
+	L.P0 = ST(F_P0);
+	L.V0 = ST(F_V0);
+	L.br_t = ST(F_BR_T);
+	L.br_a = ST(F_BR_A);
+	L.br_p = ST(F_BR_P);
+	L.br_v = ST(F_BR_V);
+}
+// new_traj: a trajectory was (re)calculated this cycle; plain sampling cycles leave the profile fields alone
+__device__ __forceinline__ void lane_store(const Lane& L, double* S, size_t stride, size_t li, bool new_traj) {
+	ST(F_IN_P) = L.in_p;
+	ST(F_IN_V) = L.in_v;
+	ST(F_IN_A) = L.in_a;
+	ST(F_TG_P) = L.tg_p;
+	ST(F_TG_V) = L.tg_v;
+	ST(F_OUT_P) = L.out_p;
+	ST(F_OUT_V) = L.out_v;
+	ST(F_OUT_A) = L.out_a;
+	ST(F_CI_P) = L.ci_p;
+	ST(F_CI_V) = L.ci_v;
+	ST(F_CI_A) = L.ci_a;
+	if (new_traj) {
+		ST(F_CI_TP) = L.ci_tp;
+		ST(F_CI_TV) = L.ci_tv;
+		ST(F_T0) = L.t[0];
+		ST(F_T1) = L.t[1];
+		ST(F_T2) = L.t[2];
+		ST(F_T6) = L.t[6];
+		ST(F_A0) = L.a[0];
+		ST(F_A2) = L.a[2];
+		ST(F_A6) = L.a[6];
+		ST(F_P0) = L.P0;
+		ST(F_V0) = L.V0;
+		ST(F_BR_T) = L.br_t;
+		ST(F_BR_A) = L.br_a;
+		ST(F_BR_P) = L.br_p;
+		ST(F_BR_V) = L.br_v;
+	}
+}
+#undef ST
+
+// ruckig::Ruckig::update (ruckig.hpp:184-221) for the robots of this wavefront whose `run` is set (group-uniform).
+// Returns the ruckig::Result (0 Working, 1 Finished, < 0 error); *new_traj tells whether a trajectory was calculated and stored.
+template <int GS>
+__device__ __forceinline__ int ruckig_update(const Grp<GS>& g, bool act, bool run, int m, double vMax, double aMax, bool new_limits, double dt, Lane& L,
+											 int& flags, double& time, double& duration, bool* new_traj) {
+	const int dof = g.dof;
+	const double vMin = -vMax, aMin = -aMax;
+	int result = 0;
+	*new_traj = false;
+	const bool differs = act && !(L.in_p == L.ci_p && L.in_v == L.ci_v && L.in_a == L.ci_a && L.tg_p == L.ci_tp && L.tg_v == L.ci_tv);
+	const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
+
+	if (g.any(need_calc)) {
+		// validate_input (input_parameter.hpp:155-330, check_target_state_within_limits only): NaNs and |vf| beyond the limits
+		bool bad = act && need_calc && (isnan(L.in_p) || isnan(L.in_v) || isnan(L.in_a) || isnan(L.tg_p) || isnan(L.tg_v) || L.tg_v > vMax || L.tg_v < vMin);
+		int err = g.any(bad) ? -100 : 0;
+
+		// ---------------------------------------------------- per-dof: brake pre-trajectory + step 1 (calculator_target.hpp:235-318)
+		Block blk;
+		blk.t_min = 0.0;
+		blk.has_a = false;
+		blk.a_left = blk.a_right = OTG_INF;
+		double nb_t = 0.0, nb_a = 0.0, np0 = L.in_p, nv0 = L.in_v;
+		{
+			if (L.in_v > vMax) {  // brake.cpp:82-102
+				nb_a = aMin;
+				nb_t = (vMax - L.in_v) / aMin + 2.2e-14;
+			} else if (L.in_v < vMin) {
+				nb_a = aMax;
+				nb_t = (vMin - L.in_v) / aMax + 2.2e-14;
+			}
+			if (nb_t > 0.0) {  // finalize_second_order, brake.hpp:65-75
+				np0 = L.in_p + nb_t * (L.in_v + nb_t * (nb_a / 2 + nb_t * 0.0 / 6));
+				nv0 = L.in_v + nb_t * (nb_a + nb_t * 0.0 / 2);
+			} else {
+				nb_t = 0.0;
+			}
+			Step1 s1;
+			s1.p0 = np0;
+			s1.v0 = nv0;
+			s1.pf = L.tg_p;
+			s1.vf = L.tg_v;
+			s1.brake_dur = nb_t;
+			const bool found = s1.run(vMax, vMin, aMax, aMin, blk);
+			if (err == 0 && g.any(act && need_calc && !found)) err = -110;  // ErrorExecutionTimeCalculation
+		}
+
+		// ---------------------------------------------------- synchronize (calculator_target.hpp:128-207): the smallest candidate
+		// duration {t_min, a.right} of any dof that no dof blocks; ties resolved towards the lower candidate index
+		double t_sync = OTG_INF;
+		int lim_idx = -1;  // candidate index = quot * m + dof
+		for (int c = 0; c < 2; c++) {
+			const double mine = (c == 0) ? blk.t_min : (blk.has_a ? blk.a_right : OTG_INF);
+			for (int s = 0; s < m; s++) {
+				const double cand = g.bcast(mine, s);
+				const bool blocked = act && ((cand < blk.t_min) || (blk.has_a && blk.a_left < cand && cand < blk.a_right));
+				const bool is_blocked = g.any(blocked);
+				if (!is_blocked && !isinf(cand) && !(cand < 0.0) && cand < t_sync) {
+					t_sync = cand;
+					lim_idx = c * m + s;
+				}
+			}
+		}
+		if (err == 0 && lim_idx < 0) err = -111;  // ErrorSynchronizationCalculation
+		const int lim_dof = lim_idx < 0 ? 0 : lim_idx % m;
+		const int lim_quot = lim_idx < 0 ? 0 : lim_idx / m;
+		if (err == 0 && t_sync > 7.6e3) err = -101;  // ErrorTrajectoryDuration, :354-358
+
+		Prof mine = blk.pmin;  // profile of this dof
+		if (dof == lim_dof && lim_quot == 1) mine = blk.aprof;
+		bool done = (t_sync == 0.0);  // :360-366: every dof keeps its p_min
+
+		// ---------------------------------------------------- phase synchronisation (calculator_target.hpp:44-126, 373-455)
+		if (err == 0 && !done) {
+			const double pdv = L.tg_p - L.in_p;
+			// the scale dof: the first dof with a non-zero pd, else v0, else a0, else vf (af = 0)
+			int which = 0;  // 1 pd, 2 v0, 3 a0, 4 vf
+			if (dabs(pdv) > OTG_DBL_EPS) which = 1;
+			else if (dabs(L.in_v) > OTG_DBL_EPS) which = 2;
+			else if (dabs(L.in_a) > OTG_DBL_EPS) which = 3;
+			else if (dabs(L.tg_v) > OTG_DBL_EPS) which = 4;
+			const unsigned long long cand_bits = g.bits(act && which != 0);
+			bool collinear = cand_bits != 0ull;
+			const int sdof = collinear ? __builtin_ctzll(cand_bits) : 0;
+			const int swhich = g.bcast(which, sdof);
+			const double sv = swhich == 1 ? pdv : (swhich == 2 ? L.in_v : (swhich == 3 ? L.in_a : L.tg_v));  // scale_vector[dof]
+			const double scale = g.bcast(sv, sdof);
+			const double pd_scale = g.bcast(pdv, sdof) / scale, v0_scale = g.bcast(L.in_v, sdof) / scale, vf_scale = g.bcast(L.tg_v, sdof) / scale;
+			const double a0_scale = g.bcast(L.in_a, sdof) / scale, af_scale = 0.0 / scale;
+			const double scale_limiting = g.bcast(sv, lim_dof);
+			const int lim_dir = g.bcast(mine.dir, lim_dof);
+			const double control_limiting = (lim_dir == 0) ? g.bcast(aMax, lim_dof) : g.bcast(aMin, lim_dof);
+			const bool off = act && (dabs(pdv - pd_scale * sv) > OTG_DBL_EPS || dabs(L.in_v - v0_scale * sv) > OTG_DBL_EPS ||
+									 dabs(L.in_a - a0_scale * sv) > OTG_DBL_EPS || dabs(L.tg_v - vf_scale * sv) > OTG_DBL_EPS ||
+									 dabs(0.0 - af_scale * sv) > OTG_DBL_EPS);
+			if (g.any(off)) collinear = false;
+			const double phase_control = control_limiting * sv / scale_limiting;
+			if (collinear) {
+				Prof ph;
+#pragma unroll
+				for (int i = 0; i < 7; i++) ph.t[i] = g.bcast(mine.t[i], lim_dof);  // p.t = p_limiting.t
+				bool okp = true;
+				if (dof != lim_dof) {
+					const double aUp = phase_control, aDown = -phase_control;
+					okp = (aMin - 1e-12 < aUp) && (aUp < aMax + 1e-12) && (aMin - 1e-12 < aDown) && (aDown < aMax + 1e-12) &&
+						  prof_check(ph, np0, nv0, L.tg_p, L.tg_v, aUp, aDown, vMax, vMin);
+				}
+				if (!g.any(act && !okp)) {
+					if (dof != lim_dof) mine = ph;
+					done = true;
+				}
+			}
+		}
+		// ---------------------------------------------------- time synchronisation (calculator_target.hpp:457-521)
+		if (err == 0 && !done) {
+			bool ok2 = true;
+			if (dof != lim_dof) {
+				const double t_profile = t_sync - nb_t - 0.0;
+				if (dabs(t_profile - blk.t_min) < 2 * OTG_DBL_EPS) mine = blk.pmin;
+				else if (blk.has_a && dabs(t_profile - blk.a_right) < 2 * OTG_DBL_EPS) mine = blk.aprof;
+				else {
+					Step2 s2;
+					s2.tf = t_profile;
+					s2.p0 = np0;
+					s2.v0 = nv0;
+					s2.pf = L.tg_p;
+					s2.vf = L.tg_v;
+					ok2 = s2.run(mine, vMax, vMin, aMax, aMin);
+				}
+			}
+			if (g.any(act && !ok2)) err = -111;
+		}
+
+		if (need_calc) {
+			if (err != 0) {
+				result = err;  // ruckig.hpp:199-201: returns before touching current_input / output
+			} else {
+#pragma unroll
+				for (int i = 0; i < 7; i++) {
+					L.t[i] = mine.t[i];
+					L.a[i] = mine.a[i];
+				}
+				L.P0 = np0;
+				L.V0 = nv0;
+				L.br_t = nb_t;
+				L.br_a = nb_a;
+				L.br_p = L.in_p;
+				L.br_v = L.in_v;
+				duration = t_sync;
+				time = 0.0;
+				L.ci_p = L.in_p;  // current_input = input, ruckig.hpp:203
+				L.ci_v = L.in_v;
+				L.ci_a = L.in_a;
+				L.ci_tp = L.tg_p;
+				L.ci_tv = L.tg_v;
+				flags |= OTG_FLAG_RUCKIG_INIT;
+				*new_traj = true;
+			}
+		}
+	}
+
+	if (run && result == 0) {
+		// ruckig.hpp:209-220: advance one control period along the stored trajectory
+		time = time + dt;
+		const Sample s = sample_profile(time, duration, L.t, L.a, L.P0, L.V0, L.br_t, L.br_a, L.br_p, L.br_v);
+		L.out_p = s.p;
+		L.out_v = s.v;
+		L.out_a = s.a;
+		L.ci_p = L.out_p;  // output.pass_to_input(current_input)
+		L.ci_v = L.out_v;
+		L.ci_a = L.out_a;
+		if (time > duration) result = 1;  // Finished
+	}
+	return result;
+}
+
 }  // namespace
 
 // One control cycle of the internal OTG of one joint task for the whole batch.  mode 0: cycle (JointTask.cpp:313-319);
-// mode 1: OTG_joints::reInitialize from the task's current position, which the task re-initialisation has just written to the
-// goal rows (JointTask.cpp:95-106, OTG_joints.cpp:28-42).
+// mode 1: OTG_joints::reInitialize(S q) (JointTask.cpp:95-106, OTG_joints.cpp:28-42).
 template <int GS>
 __global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, int ld, int mode) {
 	const Grp<GS> g;
@@ -372,14 +624,11 @@ __global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, in
 	const int m = O.m;
 	const bool inst_ok = inst < B;
 	const bool act = inst_ok && dof < m;
-	const size_t stride = (size_t)O.lanes;  // ngroups * GS
-	const size_t li = (size_t)gtid;         // lane-major slot (gtid < lanes by construction of the grid)
+	const size_t stride = (size_t)O.lanes;  // B * GS
+	const size_t li = (size_t)gtid;         // lane-major slot (only touched when act)
 	double* S = O.state;
 #define ST(f) S[(size_t)(f) * stride + li]
-
 	const size_t gi = (size_t)(act ? dof : 0) * ld + (inst_ok ? inst : 0);  // row `dof` of the task's goal / desired arrays
-	const double goal_p = (act && mode == 0) ? O.goal[gi] : 0.0;
-	const double goal_v = (act && mode == 0) ? O.goal[gi + (size_t)m * ld] : 0.0;
 
 	if (mode == 1) {
 		// current task position S q (JointTask.cpp:98), then setGoalPosition(initial): OTG_joints.cpp:36, 98-114
@@ -417,309 +666,413 @@ __global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, in
 		}
 		return;
 	}
+#undef ST
 
-	// ------------------------------------------------------------ wrapper + ruckig state of this lane
-	double in_p = 0, in_v = 0, in_a = 0, tg_p = 0, tg_v = 0, out_p = 0, out_v = 0, out_a = 0;
-	int flags = 0;
-	if (inst_ok) flags = O.flags[inst];
-	if (act) {
-		in_p = ST(F_IN_P);
-		in_v = ST(F_IN_V);
-		in_a = ST(F_IN_A);
-		tg_p = ST(F_TG_P);
-		tg_v = ST(F_TG_V);
-		out_p = ST(F_OUT_P);
-		out_v = ST(F_OUT_V);
-		out_a = ST(F_OUT_A);
-	}
-	const double vMax = act ? O.vmax[dof] : 1.0, aMax = act ? O.amax[dof] : 1.0;
-	const double vMin = -vMax, aMin = -aMax;
+	const double goal_p = act ? O.goal[gi] : 0.0;
+	const double goal_v = act ? O.goal[gi + (size_t)m * ld] : 0.0;
+	Lane L;
+	lane_load(L, S, stride, li, act);
+	int flags = inst_ok ? O.flags[inst] : 0;
+	const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0;
 	// new limits since the last cycle: enableInternalOtgAccelerationLimited -> disableJerkLimits() zeroes the current acceleration
 	// of the wrapper's input (OTG_joints.cpp:90-93); the changed limits themselves force a new trajectory (ruckig.hpp:197)
 	const bool new_limits = inst_ok && (O.epoch != O.seen_epoch[inst]);
-	if (new_limits) in_a = 0.0;
+	if (new_limits) L.in_a = 0.0;
 
 	// setGoalPositionAndVelocity, OTG_joints.cpp:98-114 (Eigen isApprox: ||a-b||^2 <= 1e-24 min(||a||^2, ||b||^2))
 	{
-		const double dp2 = g.sum((goal_p - tg_p) * (goal_p - tg_p)), gp2 = g.sum(goal_p * goal_p), tp2 = g.sum(tg_p * tg_p);
-		const double dv2 = g.sum((goal_v - tg_v) * (goal_v - tg_v)), gv2 = g.sum(goal_v * goal_v), tv2 = g.sum(tg_v * tg_v);
+		const double dp2 = g.sum((goal_p - L.tg_p) * (goal_p - L.tg_p)), gp2 = g.sum(goal_p * goal_p), tp2 = g.sum(L.tg_p * L.tg_p);
+		const double dv2 = g.sum((goal_v - L.tg_v) * (goal_v - L.tg_v)), gv2 = g.sum(goal_v * goal_v), tv2 = g.sum(L.tg_v * L.tg_v);
 		const bool same = (dp2 <= 1e-24 * fmin(gp2, tp2)) && (dv2 <= 1e-24 * fmin(gv2, tv2));
 		if (!same) {
 			flags &= ~OTG_FLAG_GOAL_REACHED;
-			tg_p = goal_p;
-			tg_v = goal_v;
+			L.tg_p = goal_p;
+			L.tg_v = goal_v;
 		}
 	}
 
-	int result = 0;  // ruckig::Result of this cycle: 0 Working, 1 Finished, < 0 error
+	int result = 0;
+	bool new_traj = false;
 	const bool run = inst_ok && !(flags & OTG_FLAG_GOAL_REACHED);  // OTG_joints.cpp:117-119
-	if (g.any(run)) {  // wave-level skip when every robot of the wavefront has reached its goal
-		// ---------------------------------------------------- Ruckig::update, ruckig.hpp:184-221
-		double ci_p = 0, ci_v = 0, ci_a = 0, ci_tp = 0, ci_tv = 0;
-		double t[7] = {0, 0, 0, 0, 0, 0, 0}, a[7] = {0, 0, 0, 0, 0, 0, 0};
-		double P0 = 0, V0 = 0, br_t = 0, br_a = 0, br_p = 0, br_v = 0;
-		double time = 0, duration = 0;
-		if (act) {
-			ci_p = ST(F_CI_P);
-			ci_v = ST(F_CI_V);
-			ci_a = ST(F_CI_A);
-			ci_tp = ST(F_CI_TP);
-			ci_tv = ST(F_CI_TV);
-			t[0] = ST(F_T0);
-			t[1] = ST(F_T1);
-			t[2] = ST(F_T2);
-			t[6] = ST(F_T6);
-			a[0] = ST(F_A0);
-			a[2] = ST(F_A2);
-			a[6] = ST(F_A6);
-			P0 = ST(F_P0);
-			V0 = ST(F_V0);
-			br_t = ST(F_BR_T);
-			br_a = ST(F_BR_A);
-			br_p = ST(F_BR_P);
-			br_v = ST(F_BR_V);
-		}
-		if (inst_ok) {
-			time = O.time[inst];
-			duration = O.duration[inst];
-		}
-		const bool differs = act && !(in_p == ci_p && in_v == ci_v && in_a == ci_a && tg_p == ci_tp && tg_v == ci_tv);
-		const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
-
-		if (g.any(need_calc)) {
-			// validate_input (input_parameter.hpp:155-330, check_target_state_within_limits only): NaNs and |vf| beyond the limits
-			bool bad = act && need_calc && (isnan(in_p) || isnan(in_v) || isnan(in_a) || isnan(tg_p) || isnan(tg_v) || tg_v > vMax || tg_v < vMin);
-			int err = g.any(bad) ? -100 : 0;
-
-			// ------------------------------------------------ per-dof: brake pre-trajectory + step 1 (calculator_target.hpp:235-318)
-			Block blk;
-			blk.t_min = 0.0;
-			blk.has_a = false;
-			blk.a_left = blk.a_right = OTG_INF;
-			double nb_t = 0.0, nb_a = 0.0, np0 = in_p, nv0 = in_v;
-			{
-				if (in_v > vMax) {  // brake.cpp:82-102
-					nb_a = aMin;
-					nb_t = (vMax - in_v) / aMin + 2.2e-14;
-				} else if (in_v < vMin) {
-					nb_a = aMax;
-					nb_t = (vMin - in_v) / aMax + 2.2e-14;
-				}
-				if (nb_t > 0.0) {  // finalize_second_order, brake.hpp:65-75
-					np0 = in_p + nb_t * (in_v + nb_t * (nb_a / 2 + nb_t * 0.0 / 6));
-					nv0 = in_v + nb_t * (nb_a + nb_t * 0.0 / 2);
-				} else {
-					nb_t = 0.0;
-				}
-				Step1 s1;
-				s1.p0 = np0;
-				s1.v0 = nv0;
-				s1.pf = tg_p;
-				s1.vf = tg_v;
-				s1.brake_dur = nb_t;
-				const bool found = s1.run(vMax, vMin, aMax, aMin, blk);
-				if (err == 0 && g.any(act && need_calc && !found)) err = -110;  // ErrorExecutionTimeCalculation
-			}
-
-			// ------------------------------------------------ synchronize (calculator_target.hpp:128-207): the smallest candidate
-			// duration {t_min, a.right} of any dof that no dof blocks; ties resolved towards the lower candidate index
-			double t_sync = OTG_INF;
-			int lim_idx = -1;  // candidate index = quot * m + dof
-			for (int c = 0; c < 2; c++) {
-				const double mine = (c == 0) ? blk.t_min : (blk.has_a ? blk.a_right : OTG_INF);
-				for (int s = 0; s < m; s++) {
-					const double cand = g.bcast(mine, s);
-					const bool blocked = act && ((cand < blk.t_min) || (blk.has_a && blk.a_left < cand && cand < blk.a_right));
-					const bool is_blocked = g.any(blocked);
-					if (!is_blocked && !isinf(cand) && !(cand < 0.0) && cand < t_sync) {
-						t_sync = cand;
-						lim_idx = c * m + s;
-					}
-				}
-			}
-			if (err == 0 && lim_idx < 0) err = -111;  // ErrorSynchronizationCalculation
-			const int lim_dof = lim_idx < 0 ? 0 : lim_idx % m;
-			const int lim_quot = lim_idx < 0 ? 0 : lim_idx / m;
-			if (err == 0 && t_sync > 7.6e3) err = -101;  // ErrorTrajectoryDuration, :354-358
-
-			Prof mine = blk.pmin;  // profile of this dof
-			if (dof == lim_dof && lim_quot == 1) mine = blk.aprof;
-			bool done = (t_sync == 0.0);  // :360-366: every dof keeps its p_min
-
-			// ------------------------------------------------ phase synchronisation (calculator_target.hpp:44-126, 373-455)
-			if (err == 0 && !done) {
-				const double pdv = tg_p - in_p;
-				// the scale dof: the first dof with a non-zero pd, else v0, else a0, else vf (af = 0)
-				int which = 0;  // 1 pd, 2 v0, 3 a0, 4 vf
-				if (dabs(pdv) > OTG_DBL_EPS) which = 1;
-				else if (dabs(in_v) > OTG_DBL_EPS) which = 2;
-				else if (dabs(in_a) > OTG_DBL_EPS) which = 3;
-				else if (dabs(tg_v) > OTG_DBL_EPS) which = 4;
-				const unsigned long long cand_bits = g.bits(act && which != 0);
-				bool collinear = cand_bits != 0ull;
-				const int sdof = collinear ? __builtin_ctzll(cand_bits) : 0;
-				const int swhich = g.bcast(which, sdof);
-				const double sv = swhich == 1 ? pdv : (swhich == 2 ? in_v : (swhich == 3 ? in_a : tg_v));  // scale_vector[dof]
-				const double scale = g.bcast(sv, sdof);
-				const double pd_scale = g.bcast(pdv, sdof) / scale, v0_scale = g.bcast(in_v, sdof) / scale, vf_scale = g.bcast(tg_v, sdof) / scale;
-				const double a0_scale = g.bcast(in_a, sdof) / scale, af_scale = 0.0 / scale;
-				const double scale_limiting = g.bcast(sv, lim_dof);
-				const int lim_dir = g.bcast(mine.dir, lim_dof);
-				const double control_limiting = (lim_dir == 0) ? g.bcast(aMax, lim_dof) : g.bcast(aMin, lim_dof);
-				const bool off = act && (dabs(pdv - pd_scale * sv) > OTG_DBL_EPS || dabs(in_v - v0_scale * sv) > OTG_DBL_EPS ||
-										 dabs(in_a - a0_scale * sv) > OTG_DBL_EPS || dabs(tg_v - vf_scale * sv) > OTG_DBL_EPS ||
-										 dabs(0.0 - af_scale * sv) > OTG_DBL_EPS);
-				if (g.any(off)) collinear = false;
-				const double phase_control = control_limiting * sv / scale_limiting;
-				if (collinear) {
-					Prof ph;
-#pragma unroll
-					for (int i = 0; i < 7; i++) ph.t[i] = g.bcast(mine.t[i], lim_dof);  // p.t = p_limiting.t
-					bool okp = true;
-					if (dof != lim_dof) {
-						const double aUp = phase_control, aDown = -phase_control;
-						okp = (aMin - 1e-12 < aUp) && (aUp < aMax + 1e-12) && (aMin - 1e-12 < aDown) && (aDown < aMax + 1e-12) &&
-							  prof_check(ph, np0, nv0, tg_p, tg_v, aUp, aDown, vMax, vMin);
-					}
-					if (!g.any(act && !okp)) {
-						if (dof != lim_dof) mine = ph;
-						done = true;
-					}
-				}
-			}
-			// ------------------------------------------------ time synchronisation (calculator_target.hpp:457-521)
-			if (err == 0 && !done) {
-				bool ok2 = true;
-				if (dof != lim_dof) {
-					const double t_profile = t_sync - nb_t - 0.0;
-					if (dabs(t_profile - blk.t_min) < 2 * OTG_DBL_EPS) mine = blk.pmin;
-					else if (blk.has_a && dabs(t_profile - blk.a_right) < 2 * OTG_DBL_EPS) mine = blk.aprof;
-					else {
-						Step2 s2;
-						s2.tf = t_profile;
-						s2.p0 = np0;
-						s2.v0 = nv0;
-						s2.pf = tg_p;
-						s2.vf = tg_v;
-						ok2 = s2.run(mine, vMax, vMin, aMax, aMin);
-					}
-				}
-				if (g.any(act && !ok2)) err = -111;
-			}
-
-			if (need_calc) {
-				if (err != 0) {
-					result = err;  // ruckig.hpp:199-201: returns before touching current_input / output
-				} else {
-#pragma unroll
-					for (int i = 0; i < 7; i++) {
-						t[i] = mine.t[i];
-						a[i] = mine.a[i];
-					}
-					P0 = np0;
-					V0 = nv0;
-					br_t = nb_t;
-					br_a = nb_a;
-					br_p = in_p;
-					br_v = in_v;
-					duration = t_sync;
-					time = 0.0;
-					ci_p = in_p;  // current_input = input, ruckig.hpp:203
-					ci_v = in_v;
-					ci_a = in_a;
-					ci_tp = tg_p;
-					ci_tv = tg_v;
-					flags |= OTG_FLAG_RUCKIG_INIT;
-				}
-			}
-		}
-
-		if (run && result == 0) {
-			// ruckig.hpp:209-220: advance one control period along the stored trajectory
-			time = time + O.dt;
-			const Sample s = sample_profile(time, duration, t, a, P0, V0, br_t, br_a, br_p, br_v);
-			const double pv_p = out_p, pv_v = out_v, pv_a = out_a;
-			(void)pv_p; (void)pv_v; (void)pv_a;
-			out_p = s.p;
-			out_v = s.v;
-			out_a = s.a;
-			ci_p = out_p;  // output.pass_to_input(current_input)
-			ci_v = out_v;
-			ci_a = out_a;
-			if (time > duration) result = 1;  // Finished
-		}
-		// ---------------------------------------------------- OTG_joints::update after the ruckig call, OTG_joints.cpp:125-149
+	if (g.any(run)) {
+		double time = inst_ok ? O.time[inst] : 0.0, duration = inst_ok ? O.duration[inst] : 0.0;
+		result = ruckig_update<GS>(g, act, run, m, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+		// OTG_joints::update after the ruckig call, OTG_joints.cpp:125-149
 		if (run) {
 			if (result == 1) {
-				const double vn2 = g.sum(act ? out_v * out_v : 0.0);
+				const double vn2 = g.sum(act ? L.out_v * L.out_v : 0.0);
 				if (sqrt(vn2) < 1e-3) {
 					flags |= OTG_FLAG_GOAL_REACHED;
 				} else {
 					// :131-133 would throw in the reference (a never-assigned member is passed on); the documented intent and the 6-dof
-					// wrapper (OTG_6dof_cartesian.cpp:209-210) are "same target position, zero target velocity".  Counted in the status.
+					// wrapper (OTG_6dof_cartesian.cpp:209-210) are "same target position, zero target velocity".  Counted in the flags.
 					flags |= OTG_FLAG_FINISHED_MOVING;
-					const double tv2 = g.sum(act ? tg_v * tg_v : 0.0);
+					const double tv2 = g.sum(act ? L.tg_v * L.tg_v : 0.0);
 					if (!(tv2 <= 0.0)) {
 						flags &= ~OTG_FLAG_GOAL_REACHED;
-						tg_v = 0.0;
+						L.tg_v = 0.0;
 					}
 				}
 			} else if (result == 0) {
-				in_p = out_p;  // _output.pass_to_input(_input)
-				in_v = out_v;
-				in_a = out_a;
+				L.in_p = L.out_p;  // _output.pass_to_input(_input)
+				L.in_v = L.out_v;
+				L.in_a = L.out_a;
 			} else {
-				// error: keep the previous output (never overwritten above), zero the input velocity and acceleration
-				in_v = 0.0;
-				in_a = 0.0;
+				L.in_v = 0.0;  // error: keep the previous output (never overwritten), zero the input velocity and acceleration
+				L.in_a = 0.0;
 				flags |= OTG_FLAG_ERROR;
 			}
-		}
-		if (act && run) {
-			ST(F_CI_P) = ci_p;
-			ST(F_CI_V) = ci_v;
-			ST(F_CI_A) = ci_a;
-			ST(F_CI_TP) = ci_tp;
-			ST(F_CI_TV) = ci_tv;
-			ST(F_T0) = t[0];
-			ST(F_T1) = t[1];
-			ST(F_T2) = t[2];
-			ST(F_T6) = t[6];
-			ST(F_A0) = a[0];
-			ST(F_A2) = a[2];
-			ST(F_A6) = a[6];
-			ST(F_P0) = P0;
-			ST(F_V0) = V0;
-			ST(F_BR_T) = br_t;
-			ST(F_BR_A) = br_a;
-			ST(F_BR_P) = br_p;
-			ST(F_BR_V) = br_v;
-			if (dof == 0) {
+			if (act && dof == 0) {
 				O.time[inst] = time;
 				O.duration[inst] = duration;
 			}
 		}
 	}
 	if (act) {
-		ST(F_IN_P) = in_p;
-		ST(F_IN_V) = in_v;
-		ST(F_IN_A) = in_a;
-		ST(F_TG_P) = tg_p;
-		ST(F_TG_V) = tg_v;
-		ST(F_OUT_P) = out_p;
-		ST(F_OUT_V) = out_v;
-		ST(F_OUT_A) = out_a;
+		lane_store(L, S, stride, li, new_traj);
 		// JointTask.cpp:317-319: the desired state the control law tracks
-		O.desired[gi] = out_p;
-		O.desired[gi + (size_t)m * ld] = out_v;
-		O.desired[gi + (size_t)2 * m * ld] = out_a;
+		O.desired[gi] = L.out_p;
+		O.desired[gi + (size_t)m * ld] = L.out_v;
+		O.desired[gi + (size_t)2 * m * ld] = L.out_a;
 		if (dof == 0) {
 			O.flags[inst] = flags;
 			O.result[inst] = run ? result : 1;
 			if (new_limits && (run ? result == 0 || result == 1 : true)) O.seen_epoch[inst] = O.epoch;
 		}
 	}
-#undef ST
+}
+
+
+// ================================================================ Cartesian OTG of a motion-force task
+// /root/reference/src/helper_modules/OTG_6dof_cartesian.cpp: six Ruckig dofs = position (3) + the rotation vector of the
+// orientation relative to a reference frame that is re-based on every new orientation goal (:155-191).  Lane group of 8, dofs
+// 0-2 linear, 3-5 angular; the 3x3 frame algebra is evaluated redundantly by every lane of the group (it is tiny next to the
+// state traffic) and each lane keeps its own component.
+namespace {
+
+struct M3 {
+	double m[9];
+};
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+	M3 C;
+#pragma unroll
+	for (int r = 0; r < 3; r++)
+#pragma unroll
+		for (int c = 0; c < 3; c++) C.m[3 * r + c] = A.m[3 * r] * B.m[c] + A.m[3 * r + 1] * B.m[3 + c] + A.m[3 * r + 2] * B.m[6 + c];
+	return C;
+}
+__device__ __forceinline__ M3 m3_tmul(const M3& A, const M3& B) {  // A^T B
+	M3 C;
+#pragma unroll
+	for (int r = 0; r < 3; r++)
+#pragma unroll
+		for (int c = 0; c < 3; c++) C.m[3 * r + c] = A.m[r] * B.m[c] + A.m[3 + r] * B.m[3 + c] + A.m[6 + r] * B.m[6 + c];
+	return C;
+}
+__device__ __forceinline__ void m3_vec(const M3& A, const double v[3], double o[3]) {
+#pragma unroll
+	for (int r = 0; r < 3; r++) o[r] = A.m[3 * r] * v[0] + A.m[3 * r + 1] * v[1] + A.m[3 * r + 2] * v[2];
+}
+__device__ __forceinline__ void m3_tvec(const M3& A, const double v[3], double o[3]) {  // A^T v
+#pragma unroll
+	for (int r = 0; r < 3; r++) o[r] = A.m[r] * v[0] + A.m[3 + r] * v[1] + A.m[6 + r] * v[2];
+}
+__device__ __forceinline__ double m3_sqnorm(const M3& A) {
+	double s = 0.0;
+#pragma unroll
+	for (int e = 0; e < 9; e++) s += A.m[e] * A.m[e];
+	return s;
+}
+__device__ __forceinline__ bool m3_approx(const M3& A, const M3& B, double prec) {  // Eigen isApprox on matrices (Frobenius)
+	double d2 = 0.0;
+#pragma unroll
+	for (int e = 0; e < 9; e++) d2 += (A.m[e] - B.m[e]) * (A.m[e] - B.m[e]);
+	return d2 <= prec * prec * fmin(m3_sqnorm(A), m3_sqnorm(B));
+}
+__device__ __forceinline__ bool v3_approx(const double a[3], const double b[3], double prec) {
+	const double d2 = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+	const double a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], b2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+	return d2 <= prec * prec * fmin(a2, b2);
+}
+__device__ __forceinline__ bool m3_valid_rotation(const M3& R) {  // isValidRotation, OTG_6dof_cartesian.cpp:19-27
+	M3 G = m3_tmul(R, R);
+	G.m[0] -= 1.0;
+	G.m[4] -= 1.0;
+	G.m[8] -= 1.0;
+	if (sqrt(m3_sqnorm(G)) > 1e-3) return false;
+	const double det = R.m[0] * (R.m[4] * R.m[8] - R.m[5] * R.m[7]) - R.m[1] * (R.m[3] * R.m[8] - R.m[5] * R.m[6]) + R.m[2] * (R.m[3] * R.m[7] - R.m[4] * R.m[6]);
+	return !(dabs(det - 1.0) > 1e-3);
+}
+// Eigen::AngleAxisd(angle, axis).toRotationMatrix() for v = angle * axis, identity below 1e-3 (getNextOrientation, :228-239)
+__device__ __forceinline__ M3 m3_from_rotvec(const double v[3]) {
+	M3 R;
+	const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+	if (n < 1e-3) {
+#pragma unroll
+		for (int e = 0; e < 9; e++) R.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+		return R;
+	}
+	const double ax[3] = {v[0] / n, v[1] / n, v[2] / n};
+	double sn, c;
+	sincos(n, &sn, &c);
+	const double sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+	const double ca[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+	double tmp = ca[0] * ax[1];
+	R.m[1] = tmp - sa[2];
+	R.m[3] = tmp + sa[2];
+	tmp = ca[0] * ax[2];
+	R.m[2] = tmp + sa[1];
+	R.m[6] = tmp - sa[1];
+	tmp = ca[1] * ax[2];
+	R.m[5] = tmp - sa[0];
+	R.m[7] = tmp + sa[0];
+	R.m[0] = ca[0] * ax[0] + c;
+	R.m[4] = ca[1] * ax[1] + c;
+	R.m[8] = ca[2] * ax[2] + c;
+	return R;
+}
+// angle * axis of Eigen::AngleAxisd(R): rotation matrix -> quaternion (trace / largest-diagonal branches) -> angle-axis
+__device__ __forceinline__ void rotvec_from_m3(const M3& R, double out[3]) {
+	double qw, qv[3];
+	double t = R.m[0] + R.m[4] + R.m[8];
+	if (t > 0.0) {
+		t = sqrt(t + 1.0);
+		qw = 0.5 * t;
+		t = 0.5 / t;
+		qv[0] = (R.m[7] - R.m[5]) * t;
+		qv[1] = (R.m[2] - R.m[6]) * t;
+		qv[2] = (R.m[3] - R.m[1]) * t;
+	} else {
+		int i = 0;
+		if (R.m[4] > R.m[0]) i = 1;
+		if (R.m[8] > R.m[4 * i]) i = 2;
+		const int j = (i + 1) % 3, k = (j + 1) % 3;
+		t = sqrt(R.m[4 * i] - R.m[4 * j] - R.m[4 * k] + 1.0);
+		double q[3];
+		q[i] = 0.5 * t;
+		t = 0.5 / t;
+		qw = (R.m[3 * k + j] - R.m[3 * j + k]) * t;
+		q[j] = (R.m[3 * j + i] + R.m[3 * i + j]) * t;
+		q[k] = (R.m[3 * k + i] + R.m[3 * i + k]) * t;
+		qv[0] = q[0];
+		qv[1] = q[1];
+		qv[2] = q[2];
+	}
+	double n = sqrt(qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2]);
+	if (n != 0.0) {
+		const double angle = 2.0 * atan2(n, dabs(qw));
+		if (qw < 0.0) n = -n;
+		out[0] = angle * (qv[0] / n);
+		out[1] = angle * (qv[1] / n);
+		out[2] = angle * (qv[2] / n);
+	} else {
+		out[0] = out[1] = out[2] = 0.0;  // angle 0 (axis (1,0,0))
+	}
+}
+
+struct CartFrames {
+	M3 ref, gob;    // _reference_frame, _goal_orientation_in_base_frame
+	double gab[3];  // _goal_angular_velocity_in_base_frame
+};
+
+// setGoalOrientationAndAngularVelocity, OTG_6dof_cartesian.cpp:155-191 (group-uniform; each lane keeps its own component)
+template <int GS>
+__device__ __forceinline__ void cart_set_goal_orientation(const Grp<GS>& g, bool act, Lane& L, CartFrames& F, int& flags, const M3& Rg, const double wg[3]) {
+	if (!m3_valid_rotation(Rg)) {  // the reference throws std::invalid_argument (:158-162): flagged, goal ignored
+		flags |= OTG_FLAG_INVALID_GOAL;
+		return;
+	}
+	if ((flags & OTG_FLAG_GOAL_ORI_VALID) && m3_approx(F.gob, Rg, 1e-3) && v3_approx(F.gab, wg, 1e-3)) return;
+	flags &= ~OTG_FLAG_GOAL_REACHED;
+	const int dof = g.dof;
+	const double op[3] = {g.bcast(L.out_p, 3), g.bcast(L.out_p, 4), g.bcast(L.out_p, 5)};
+	const double ov[3] = {g.bcast(L.out_v, 3), g.bcast(L.out_v, 4), g.bcast(L.out_v, 5)};
+	const double oa[3] = {g.bcast(L.out_a, 3), g.bcast(L.out_a, 4), g.bcast(L.out_a, 5)};
+	const M3 new_ref = m3_mul(F.ref, m3_from_rotvec(op));  // getNextOrientation()
+	const M3 Rntp = m3_tmul(new_ref, F.ref);               // R_new_to_previous_reference
+	F.ref = new_ref;
+	F.gob = Rg;
+	F.gab[0] = wg[0];
+	F.gab[1] = wg[1];
+	F.gab[2] = wg[2];
+	flags |= OTG_FLAG_GOAL_ORI_VALID;
+	double rv[3], ra[3];
+	m3_vec(Rntp, ov, rv);
+	m3_vec(Rntp, oa, ra);
+	if (dof >= 3 && dof < 6) {
+		L.out_p = 0.0;
+		L.out_v = rv[dof - 3];
+		L.out_a = ra[dof - 3];
+	}
+	if (act) {  // _output.pass_to_input(_input): all six dofs
+		L.in_p = L.out_p;
+		L.in_v = L.out_v;
+		L.in_a = L.out_a;
+	}
+	double aa[3], tw[3];
+	rotvec_from_m3(m3_tmul(F.ref, F.gob), aa);
+	m3_tvec(F.ref, wg, tw);
+	if (dof >= 3 && dof < 6) {
+		L.tg_p = aa[dof - 3];
+		L.tg_v = tw[dof - 3];
+	}
+}
+// setGoalPositionAndLinearVelocity, :138-148
+template <int GS>
+__device__ __forceinline__ void cart_set_goal_position(const Grp<GS>& g, Lane& L, int& flags, const double gp[3], const double gv[3]) {
+	const double tp[3] = {g.bcast(L.tg_p, 0), g.bcast(L.tg_p, 1), g.bcast(L.tg_p, 2)};
+	const double tv[3] = {g.bcast(L.tg_v, 0), g.bcast(L.tg_v, 1), g.bcast(L.tg_v, 2)};
+	if (v3_approx(gp, tp, 1e-3) && v3_approx(gv, tv, 1e-3)) return;
+	flags &= ~OTG_FLAG_GOAL_REACHED;
+	if (g.dof < 3) {
+		L.tg_p = gp[g.dof];
+		L.tg_v = gv[g.dof];
+	}
+}
+
+}  // namespace
+
+// mode 0: one control cycle (MotionForceTask.cpp:394-406).  mode 1 | (mask << 4): reInitialize (mask 3), reInitializeLinear
+// (mask 1), reInitializeAngular (mask 2) at the current pose of the control frame (OTG_6dof_cartesian.cpp:46-84).
+__global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B, int ld, int mode) {
+	constexpr int GS = 8;
+	const Grp<GS> g;
+	const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int inst = gtid / GS;
+	const int dof = g.dof;
+	const bool inst_ok = inst < B;
+	const bool act = inst_ok && dof < 6;
+	const size_t stride = (size_t)O.lanes;
+	const size_t li = (size_t)gtid;
+	double* S = O.state;
+	const size_t ib = inst_ok ? (size_t)inst : 0;
+
+	Lane L;
+	lane_load(L, S, stride, li, act);
+	int flags = inst_ok ? O.flags[inst] : 0;
+	CartFrames F;
+#pragma unroll
+	for (int e = 0; e < 9; e++) {
+		F.ref.m[e] = O.frame[(size_t)e * ld + ib];
+		F.gob.m[e] = O.frame[(size_t)(9 + e) * ld + ib];
+	}
+#pragma unroll
+	for (int e = 0; e < 3; e++) F.gab[e] = O.frame[(size_t)(18 + e) * ld + ib];
+	const double zero3[3] = {0.0, 0.0, 0.0};
+	bool new_traj = false;
+	int result = 1;
+	bool run = false;
+
+	if ((mode & 15) == 1) {
+		const int mask = mode >> 4;
+		double pw[3];
+		M3 Rc;
+		fk_control_frame(*O.model, *O.task, O.q, ld, (int)ib, pw, Rc.m);
+		if (!(flags & OTG_FLAG_STATE_VALID)) F.ref = Rc;  // constructor: _reference_frame = initial_orientation (:41), _output zero (:39)
+		if (mask & 1) cart_set_goal_position<GS>(g, L, flags, pw, zero3);
+		if (mask & 2) cart_set_goal_orientation<GS>(g, act, L, F, flags, Rc, zero3);
+		const bool mine = (dof < 3) ? (mask & 1) : (mask & 2);
+		if (act && mine) {
+			L.in_p = L.tg_p;  // :50-56
+			L.in_v = 0.0;
+			L.in_a = 0.0;
+			L.out_p = L.tg_p;
+			L.out_v = 0.0;
+			L.out_a = 0.0;
+		}
+		flags = (flags & ~(OTG_FLAG_ERROR | OTG_FLAG_FINISHED_MOVING | OTG_FLAG_INVALID_GOAL)) | OTG_FLAG_STATE_VALID;
+	} else {
+		double gp[3], gv[3], gw[3];
+		M3 Rg;
+#pragma unroll
+		for (int e = 0; e < 3; e++) {
+			gp[e] = O.goal[(size_t)e * ld + ib];
+			gv[e] = O.goal[(size_t)(12 + e) * ld + ib];
+			gw[e] = O.goal[(size_t)(15 + e) * ld + ib];
+		}
+#pragma unroll
+		for (int e = 0; e < 9; e++) Rg.m[e] = O.goal[(size_t)(3 + e) * ld + ib];
+		const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0;
+		const bool new_limits = inst_ok && (O.epoch != O.seen_epoch[inst]);
+		if (new_limits) L.in_a = 0.0;  // disableJerkLimits, OTG_6dof_cartesian.h:86-89
+		flags &= ~OTG_FLAG_INVALID_GOAL;
+		cart_set_goal_position<GS>(g, L, flags, gp, gv);                     // MotionForceTask.cpp:395-396
+		cart_set_goal_orientation<GS>(g, act, L, F, flags, Rg, gw);          // :397-398
+		run = inst_ok && !(flags & OTG_FLAG_GOAL_REACHED);                   // OTG_6dof_cartesian.cpp:194-196
+		if (g.any(run)) {
+			double time = O.time[ib], duration = O.duration[ib];
+			result = ruckig_update<GS>(g, act, run, 6, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+			if (run) {  // :201-225
+				if (result == 1) {
+					const double vn2 = g.sum(act ? L.out_v * L.out_v : 0.0);
+					if (sqrt(vn2) < 1e-3) {
+						flags |= OTG_FLAG_GOAL_REACHED;
+					} else {  // :206-211: same goal pose, zero goal velocities
+						flags |= OTG_FLAG_FINISHED_MOVING;
+						const double tp[3] = {g.bcast(L.tg_p, 0), g.bcast(L.tg_p, 1), g.bcast(L.tg_p, 2)};
+						cart_set_goal_position<GS>(g, L, flags, tp, zero3);
+						const M3 gob = F.gob;
+						cart_set_goal_orientation<GS>(g, act, L, F, flags, gob, zero3);
+					}
+				} else if (result == 0) {
+					L.in_p = L.out_p;
+					L.in_v = L.out_v;
+					L.in_a = L.out_a;
+				} else {
+					L.in_v = 0.0;
+					L.in_a = 0.0;
+					flags |= OTG_FLAG_ERROR;
+				}
+				if (act && dof == 0) {
+					O.time[inst] = time;
+					O.duration[inst] = duration;
+				}
+			}
+		}
+		if (act && dof == 0 && new_limits && (run ? result == 0 || result == 1 : true)) O.seen_epoch[inst] = O.epoch;
+	}
+
+	// ------------------------------------------------------------ stores: lane state, frames, desired state (goal layout)
+	if (act) lane_store(L, S, stride, li, new_traj);
+	if (inst_ok) {
+		const double op[3] = {g.bcast(L.out_p, 3), g.bcast(L.out_p, 4), g.bcast(L.out_p, 5)};
+		const double ov[3] = {g.bcast(L.out_v, 3), g.bcast(L.out_v, 4), g.bcast(L.out_v, 5)};
+		const double oa[3] = {g.bcast(L.out_a, 3), g.bcast(L.out_a, 4), g.bcast(L.out_a, 5)};
+		const M3 Rd = m3_mul(F.ref, m3_from_rotvec(op));  // getNextOrientation
+		double wd[3], ad[3];
+		m3_vec(F.ref, ov, wd);  // getNextAngularVelocity / Acceleration, OTG_6dof_cartesian.h:258-264
+		m3_vec(F.ref, oa, ad);
+		double* D = O.desired;
+		if (dof < 3) {
+			D[(size_t)dof * ld + inst] = L.out_p;
+			D[(size_t)(12 + dof) * ld + inst] = L.out_v;
+			D[(size_t)(18 + dof) * ld + inst] = L.out_a;
+		} else if (dof < 6) {
+			D[(size_t)(15 + dof - 3) * ld + inst] = wd[dof - 3];
+			D[(size_t)(21 + dof - 3) * ld + inst] = ad[dof - 3];
+		}
+		D[(size_t)(3 + dof) * ld + inst] = Rd.m[dof];  // eight lanes, entries 0..7
+		if (dof == 0) D[(size_t)11 * ld + inst] = Rd.m[8];
+		if (O.goal_comps == 30 && dof < 6) D[(size_t)(24 + dof) * ld + inst] = O.goal[(size_t)(24 + dof) * ld + inst];  // goal force / moment pass through
+		if (dof == 0) {
+#pragma unroll
+			for (int e = 0; e < 9; e++) {
+				O.frame[(size_t)e * ld + inst] = F.ref.m[e];
+				O.frame[(size_t)(9 + e) * ld + inst] = F.gob.m[e];
+			}
+#pragma unroll
+			for (int e = 0; e < 3; e++) O.frame[(size_t)(18 + e) * ld + inst] = F.gab[e];
+			O.flags[inst] = flags;
+			O.result[inst] = run ? result : 1;
+		}
+	}
+}
+
+hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream) {
+	const int block = 256;
+	const int grid = (int)(((long long)O.lanes + block - 1) / block);
+	hipLaunchKernelGGL(saip_otg_cartesian, dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	return hipGetLastError();
 }
 
 int otg_state_fields() { return F_COUNT; }

@@ -79,6 +79,127 @@ def scenarios():
     return out
 
 
+CART_LINK, CART_POINT = "end-effector", (0.0, 0.0, 0.07)  # the control frame of BASELINE config 2 (examples/05-...cpp:111-113)
+
+
+def cart_pose(q):
+    """(B,3) control-point positions and (B,3,3) control-frame rotations from the NumPy restatement's kinematics"""
+    import workloads as W
+    model = W.load_robot("panda_arm")
+    fr = W.fk(model, q)
+    li = model.link_index(CART_LINK)
+    return fr[li][1] + fr[li][0] @ np.array(CART_POINT), fr[li][0]
+
+
+def cart_scenarios():
+    """Cartesian OTG (OTG_6dof_cartesian) scenarios for a full motion-force task on the Panda; goal events carry
+    (position (B,3), orientation (B,3,3), linear velocity (B,3), angular velocity (B,3))"""
+    import workloads as W
+    out = {}
+    rng = np.random.default_rng(0x0C47)
+    q_nom = np.array([0.0, -0.436, 0.0, -2.356, 0.0, 1.833, 0.0])
+    B = 10
+    z3 = np.zeros((B, 3))
+
+    def rot(R, scale):
+        return W._expm_so3(rng.uniform(-scale, scale, (R.shape[0], 3))) @ R
+
+    # 1: from rest to a new pose, then a new pose in flight (the reference frame is re-based), then back to the first one
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    p0, R0 = cart_pose(q0)
+    g1 = (p0 + rng.uniform(-0.15, 0.15, (B, 3)), rot(R0, 0.6), z3, z3)
+    g1[0][0], g1[1][1] = p0[0], R0[1]          # a pure rotation and a pure translation
+    g2 = (g1[0] + rng.uniform(-0.1, 0.1, (B, 3)), rot(g1[1], 0.5), z3, z3)
+    out["otg_cart_pose_goals"] = dict(kind="cartesian", robot="panda_arm", q0=q0, K=2300, limits=(0.3, 2.0, np.pi / 3, 2 * np.pi),
+                                      events=[(0, "goal", g1), (350, "goal", g2), (900, "goal", g1)])
+
+    # 2: tighter limits from the start, limits changed in flight, re-initialisation of the linear part only and of the whole
+    #    task at a new configuration, a goal with linear and angular goal velocities
+    q0 = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    p0, R0 = cart_pose(q0)
+    g1 = (p0 + rng.uniform(-0.2, 0.2, (B, 3)), rot(R0, 0.9), z3, z3)
+    q_re = q_nom + rng.uniform(-0.2, 0.2, (B, 7))
+    p1, R1 = cart_pose(q_re)
+    g2 = (p1 + rng.uniform(-0.1, 0.1, (B, 3)), rot(R1, 0.4), rng.uniform(-0.05, 0.05, (B, 3)), rng.uniform(-0.2, 0.2, (B, 3)))
+    g2[2][:4], g2[3][:4] = 0.0, 0.0
+    g3 = (g2[0], g2[1], z3, z3)
+    out["otg_cart_limits_reinit"] = dict(kind="cartesian", robot="panda_arm", q0=q0, K=2400, limits=(0.2, 1.0, 0.8, 3.0),
+                                         events=[(0, "goal", g1), (200, "limits", (0.08, 0.6, 0.3, 1.5)), (600, "reinit", (q0, 1)),
+                                                 (1000, "reinit", (q_re, 3)), (1000, "goal", g2), (1700, "goal", g3)])
+    return out
+
+
+def run_reference_cart(sc):
+    import otg_ref as R
+    q0 = sc["q0"]
+    B = q0.shape[0]
+    p0, R0 = cart_pose(q0)
+    otg = [R.CartesianOtgRef(p0[i], R0[i], DT, sc["limits"]) for i in range(B)]
+    goal = [p0.copy(), R0.copy(), np.zeros((B, 3)), np.zeros((B, 3))]   # MotionForceTask::reInitializeTask: goal = current pose
+    steps = sample_steps(sc["K"], sc["events"])
+    want = set(steps.tolist())
+    out = np.zeros((len(steps), B, 24))
+    reached = np.zeros((len(steps), B), bool)
+    row = 0
+    for k in range(sc["K"]):
+        for st, kind, payload in sc["events"]:
+            if st != k:
+                continue
+            if kind == "goal":
+                goal = [np.array(x, float) for x in payload]
+            elif kind == "limits":
+                for o in otg:
+                    o.set_limits(payload)
+            elif kind == "reinit":
+                q, mask = payload
+                pr, Rr = cart_pose(q)
+                for i, o in enumerate(otg):
+                    o.reinitialize(pr[i], Rr[i], mask)
+                if mask & 1:
+                    goal[0], goal[2] = pr.copy(), np.zeros((B, 3))
+                if mask & 2:
+                    goal[1], goal[3] = Rr.copy(), np.zeros((B, 3))
+        for i, o in enumerate(otg):
+            d, g, res = o.step(goal[0][i], goal[1][i], goal[2][i], goal[3][i])
+            if k in want:
+                out[row, i] = d
+                reached[row, i] = g
+        if k in want:
+            row += 1
+    return steps, out, reached, sum(o.finished_with_velocity for o in otg)
+
+
+def pack_cart(sc, steps, out, reached, moving):
+    d = dict(kind="cartesian", robot=sc["robot"], q0=sc["q0"], K=sc["K"], dt=DT, limits=np.asarray(sc["limits"], float), steps=steps, desired=out,
+             goal_reached=reached, finished_with_velocity=moving, n_events=len(sc["events"]))
+    for i, (st, kind, payload) in enumerate(sc["events"]):
+        d[f"ev{i}_step"], d[f"ev{i}_kind"] = st, kind
+        if kind == "goal":
+            for j, x in enumerate(payload):
+                d[f"ev{i}_{j}"] = np.asarray(x, float)
+        elif kind == "limits":
+            d[f"ev{i}_0"] = np.asarray(payload, float)
+        else:
+            d[f"ev{i}_0"], d[f"ev{i}_1"] = np.asarray(payload[0], float), int(payload[1])
+    return d
+
+
+def load_cart(path):
+    z = np.load(path)
+    ev = []
+    for i in range(int(z["n_events"])):
+        kind = str(z[f"ev{i}_kind"])
+        if kind == "goal":
+            pl = tuple(z[f"ev{i}_{j}"] for j in range(4))
+        elif kind == "limits":
+            pl = tuple(z[f"ev{i}_0"])
+        else:
+            pl = (z[f"ev{i}_0"], int(z[f"ev{i}_1"]))
+        ev.append((int(z[f"ev{i}_step"]), kind, pl))
+    sc = dict(kind="cartesian", robot=str(z["robot"]), q0=z["q0"], K=int(z["K"]), limits=tuple(z["limits"]), events=ev)
+    return sc, z["steps"], z["desired"], z["goal_reached"], dict(finished_with_velocity=int(z["finished_with_velocity"]), dt=float(z["dt"]))
+
+
 def sample_steps(K, events):
     """cycles whose outputs are stored: every 7th, the last one, and 12 cycles after every event"""
     s = set(range(0, K, 7)) | {K - 1}
@@ -162,4 +283,8 @@ if __name__ == "__main__":
     for name, sc in scenarios().items():
         steps, out, reached, moving = run_reference(sc)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack(sc, steps, out, reached, moving))
+        print(f"{name}: B={sc['q0'].shape[0]} K={sc['K']} samples={len(steps)} reached_at_end={int(reached[-1].sum())} finished_with_velocity={moving}")
+    for name, sc in cart_scenarios().items():
+        steps, out, reached, moving = run_reference_cart(sc)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **pack_cart(sc, steps, out, reached, moving))
         print(f"{name}: B={sc['q0'].shape[0]} K={sc['K']} samples={len(steps)} reached_at_end={int(reached[-1].sum())} finished_with_velocity={moving}")

@@ -20,7 +20,9 @@ import make_otg_golden as G  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
-FIX = sorted(glob.glob(os.path.join(HERE, "golden", "otg_*.npz")))
+ALL = sorted(glob.glob(os.path.join(HERE, "golden", "otg_*.npz")))
+FIX = [p for p in ALL if "otg_cart_" not in p]
+CART = [p for p in ALL if "otg_cart_" in p]
 
 
 def _controller(robot_name, S, q0):
@@ -161,3 +163,99 @@ def test_otg_default_enabled_and_disable():
         jt.enableInternalOtgAccelerationLimited(0.0, 1.0)   # OTG_joints.cpp:51-55
     with pytest.raises(ValueError):
         jt.enableInternalOtgAccelerationLimited([1.0, 2.0], [1.0, 2.0])  # JointTask.cpp:367-373
+
+
+# ------------------------------------------------------------------ Cartesian OTG of a motion-force task (OTG_6dof_cartesian)
+def _cart_controller(q0):
+    from sai_primitives_amd.controller import MotionForceTask, RobotController, SaiModel
+    B = q0.shape[0]
+    robot = SaiModel("panda_arm", B, device=0)
+    robot.setQ(q0)
+    robot.setDq(np.zeros_like(q0))
+    robot.updateModel()
+    mf = MotionForceTask(robot, G.CART_LINK, G.CART_POINT)
+    ctrl = RobotController(robot, [mf])   # OTG enabled by default, like the reference
+    return robot, ctrl, mf
+
+
+def _set_cart_goal(mf, goal):
+    mf.setGoalPosition(goal[0])
+    mf.setGoalOrientation(goal[1])
+    mf.setGoalLinearVelocity(goal[2])
+    mf.setGoalAngularVelocity(goal[3])
+
+
+# Tolerance of the Cartesian wrapper: its frame algebra (rotation vector <-> matrix, sin/cos/atan2 of the device math library vs
+# glibc) is evaluated once per goal change and differs by a few ulp, which the trajectory then carries: 1e-9 absolute.
+@pytest.mark.parametrize("path", CART, ids=[os.path.basename(p)[:-4] for p in CART])
+def test_cartesian_otg_matches_reference_fixture(path):
+    sc, steps, desired, reached, meta = G.load_cart(path)
+    robot, ctrl, mf = _cart_controller(sc["q0"])
+    mf.enableInternalOtgAccelerationLimited(*sc["limits"])
+    B = sc["q0"].shape[0]
+    p0, R0 = G.cart_pose(sc["q0"])
+    goal = [p0, R0, np.zeros((B, 3)), np.zeros((B, 3))]
+    want = {int(s): r for r, s in enumerate(steps)}
+    worst = 0.0
+    for k in range(sc["K"]):
+        for st, kind, payload in sc["events"]:
+            if st != k:
+                continue
+            if kind == "goal":
+                goal = [np.array(x, float) for x in payload]
+            elif kind == "limits":
+                mf.enableInternalOtgAccelerationLimited(*payload)
+            elif kind == "reinit":
+                q, mask = payload
+                robot.setQ(q)
+                robot.updateModel()
+                pr, Rr = G.cart_pose(q)
+                if mask == 3:
+                    ctrl.reinitializeTasks()
+                    goal = [pr, Rr, np.zeros((B, 3)), np.zeros((B, 3))]
+                else:  # reInitializeLinear: what parametrizeForceMotionSpaces triggers when the force space changes (MotionForceTask.cpp:828-856)
+                    assert mask == 1
+                    dim = 1 if not getattr(mf, "_toggle", False) else 0
+                    mf._toggle = not getattr(mf, "_toggle", False)
+                    assert mf.parametrizeForceMotionSpaces(dim, [0, 0, 1]) is True
+                    mf.parametrizeForceMotionSpaces(0)      # back to pure motion control (second linear re-initialisation, same pose)
+                    goal[0], goal[2] = pr, np.zeros((B, 3))
+        _set_cart_goal(mf, goal)
+        ctrl.updateControllerTaskModels()
+        if k in want:
+            ctrl.computeControlTorques()
+            r = want[k]
+            got = mf._desired_block()[:, :24]
+            err = np.abs(got - desired[r]).max()
+            gr, fl, res = mf.getInternalOtgStatus()
+            assert err < TOL, (k, err, np.unravel_index(np.abs(got - desired[r]).argmax(), got.shape))
+            assert np.array_equal(gr, reached[r]), k
+            assert (res >= 0).all() and ((fl & 64) == 0).all()
+            worst = max(worst, err)
+        else:
+            ctrl.stepAsync()
+    ctrl.synchronize()
+    print(os.path.basename(path), "max |desired - reference|", worst)
+
+
+def test_cartesian_otg_default_on_and_invalid_goal():
+    d = W.make_inputs(2, 8)
+    robot, ctrl, mf = _cart_controller(d["q"])
+    p0, R0 = G.cart_pose(d["q"])
+    mf.setGoalPosition(p0 + 0.05)
+    ctrl.updateControllerTaskModels()
+    ctrl.computeControlTorques()
+    first = mf.getDesiredPosition()
+    assert 0 < np.abs(first - p0).max() < 1e-5 and np.abs(first - (p0 + 0.05)).max() > 0.04   # moving towards, not at, the goal
+    bad = R0.copy()
+    bad[:, 0, 0] += 0.1                                   # not a rotation: the reference throws, the engine flags and ignores
+    mf.setGoalOrientation(bad)
+    ctrl.computeControlTorques()
+    gr, fl, res = mf.getInternalOtgStatus()
+    assert ((fl & 64) != 0).all()
+    mf.setGoalOrientation(R0)
+    ctrl.computeControlTorques()
+    gr, fl, res = mf.getInternalOtgStatus()
+    assert ((fl & 64) == 0).all()
+    with pytest.raises(ValueError):
+        mf.enableInternalOtgAccelerationLimited(0.3, 2.0, -1.0, 1.0)   # OTG_6dof_cartesian.cpp:107-113

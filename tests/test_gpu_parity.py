@@ -167,12 +167,10 @@ def test_call_order_and_otg_are_loud():
     with pytest.raises(sp.SaipError):  # compute before update
         ctrl.computeControlTorques()
     ctrl.updateControllerTaskModels()
-    tasks[0].enableInternalOtgAccelerationLimited()   # Cartesian OTG of the motion-force task: not on the device
-    with pytest.raises(sp.SaipUnsupported):
-        ctrl.computeControlTorques()
-    tasks[0].disableInternalOtg()
-    with pytest.raises(sp.SaipUnsupported):           # jerk-limited joint OTG: not on the device
+    with pytest.raises(sp.SaipUnsupported):           # jerk-limited OTG (third-order Ruckig profiles): not on the device
         tasks[1].enableInternalOtgJerkLimited(1.0, 2.0, 10.0)
+    with pytest.raises(sp.SaipUnsupported):
+        tasks[0].enableInternalOtgJerkLimited(0.3, 2.0, 10.0, 1.0, 6.0, 30.0)
     ctrl.setGoals(d["goals"])
     assert np.isfinite(ctrl.computeControlTorques()).all()
 

@@ -14,12 +14,45 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
 import make_otg_golden as G  # noqa: E402
 import otg_ref  # noqa: E402
 
-FIX = sorted(glob.glob(os.path.join(HERE, "golden", "otg_*.npz")))
+ALL = sorted(glob.glob(os.path.join(HERE, "golden", "otg_*.npz")))
+FIX = [p for p in ALL if "otg_cart_" not in p]          # joint OTG (OTG_joints)
+CART = [p for p in ALL if "otg_cart_" in p]             # Cartesian OTG (OTG_6dof_cartesian)
 IDS = [os.path.basename(p)[:-4] for p in FIX]
+CIDS = [os.path.basename(p)[:-4] for p in CART]
 
 
 def test_fixture_set_is_complete():
-    assert sorted(IDS) == sorted(G.scenarios())
+    assert sorted(IDS) == sorted(G.scenarios()) and sorted(CIDS) == sorted(G.cart_scenarios())
+
+
+@pytest.mark.parametrize("path", CART, ids=CIDS)
+def test_cartesian_fixtures_are_reference_outputs(path):
+    if otg_ref.build() is None:
+        pytest.skip("oracle/_ref/libsaip_otg_ref.so not present (built only where /root/reference exists)")
+    sc, steps, desired, reached, meta = G.load_cart(path)
+    s2, d2, r2, moving = G.run_reference_cart(sc)
+    assert np.array_equal(s2, steps) and np.array_equal(r2, reached) and moving == meta["finished_with_velocity"]
+    assert np.array_equal(d2, desired)
+
+
+@pytest.mark.parametrize("path", CART, ids=CIDS)
+def test_cartesian_trajectory_invariants(path):
+    sc, steps, desired, reached, meta = G.load_cart(path)
+    R = desired[:, :, 3:12].reshape(desired.shape[0], -1, 3, 3)
+    assert np.abs(R @ R.transpose(0, 1, 3, 2) - np.eye(3)).max() < 1e-12        # desired orientations are rotations
+    lim = np.array(sc["limits"])
+    changed = [p for s, k, p in sc["events"] if k == "limits"]
+    amax_lin = max([lim[1]] + [p[1] for p in changed])
+    amax_ang = max([lim[3]] + [p[3] for p in changed])
+    # per-axis limits: each Cartesian / rotation-vector axis is its own Ruckig dof
+    assert np.abs(desired[:, :, 18:21]).max() <= amax_lin + 1e-9
+    ang_acc_ref = np.abs(desired[:, :, 21:24]).max()
+    assert ang_acc_ref <= np.sqrt(3) * amax_ang + 1e-9                           # reported in the base frame: rotated per-axis values
+    last = [p for s, k, p in sc["events"] if k == "goal"][-1]
+    done = reached[-1]
+    assert done.sum() >= done.size - 2
+    assert np.abs(desired[-1][done, 0:3] - last[0][done]).max() < 1e-9
+    assert np.abs(R[-1][done] - last[1][done]).max() < 1e-7
 
 
 @pytest.mark.parametrize("path", FIX, ids=IDS)
