@@ -95,8 +95,27 @@ public:
 
 	void setDynamicDecouplingType(DynamicDecouplingType t) { cfg([=](saip_batch* b, int id) { return saip_batch_set_dynamic_decoupling_type(b, id, (int)t); }); }
 	void setBoundedInertiaEstimateThreshold(double thr) { cfg([=](saip_batch* b, int id) { return saip_batch_set_bie_threshold(b, id, thr); }); }
-	void disableInternalOtg() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 0); }); }
-	void enableInternalOtgAccelerationLimited() { cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 1); }); }
+	void disableInternalOtg() {
+		_otg_enabled = false;
+		cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 0); });
+	}
+	bool getInternalOtgEnabled() const { return _otg_enabled; }
+	// [goal_components][B]: what the control law tracks -- the internal OTG's output when enabled, else the goal (getDesired*)
+	std::vector<double> getDesiredState() {
+		need();
+		std::vector<double> d((size_t)saip_batch_goal_components(_batch, _id) * _robot->batchSize());
+		check(saip_batch_get_desired_host(_batch, _id, d.data()));
+		return d;
+	}
+	// OTG::isGoalReached per instance
+	std::vector<bool> isInternalOtgGoalReached() {
+		need();
+		std::vector<int> fl(_robot->batchSize());
+		check(saip_batch_get_otg_status_host(_batch, _id, fl.data(), nullptr));
+		std::vector<bool> r(fl.size());
+		for (size_t i = 0; i < fl.size(); i++) r[i] = (fl[i] & 1) != 0;
+		return r;
+	}
 	void disableVelocitySaturation() { cfg([](saip_batch* b, int id) { return saip_batch_set_velocity_saturation(b, id, 0); }); }
 	// (B x dof x dof as [dof*dof][B]) nullspace projector of this task for the current state, TemplateTask.h:71-77
 	std::vector<double> getTaskNullspace() {
@@ -128,6 +147,7 @@ protected:
 	std::string _task_name;
 	TaskType _task_type;
 	double _loop_timestep;
+	bool _otg_enabled = true;  // reference default (JointTask.h:38, MotionForceTask.h:67)
 	saip_batch* _batch = nullptr;
 	int _id = -1;
 	std::vector<std::function<saip_status(saip_batch*, int)>> _pending;
@@ -160,6 +180,18 @@ public:
 	void setPosControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_pos_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void setSingularityHandlingBounds(double s_min, double s_max) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_bounds(b, id, s_min, s_max); }); }
+	// MotionForceTask.cpp:510-523 (defaults MotionForceTask.h:68-71); the jerk-limited variant throws (not on the device)
+	void enableInternalOtgAccelerationLimited(double max_linear_velocity = 0.3, double max_linear_acceleration = 2.0,
+											  double max_angular_velocity = M_PI / 3, double max_angular_acceleration = 2 * M_PI) {
+		_otg_enabled = true;
+		cfg([=](saip_batch* b, int id) {
+			const double v[2] = {max_linear_velocity, max_angular_velocity}, a[2] = {max_linear_acceleration, max_angular_acceleration};
+			return saip_batch_set_otg_acceleration_limited(b, id, v, a, 2);
+		});
+	}
+	void enableInternalOtgJerkLimited(double, double, double, double, double, double) {
+		cfg([](saip_batch* b, int id) { return saip_batch_set_otg_jerk_limited(b, id, nullptr, nullptr, nullptr, 0); });
+	}
 	// MotionForceTask::enableVelocitySaturation(linear, angular), MotionForceTask.cpp:771-792
 	void enableVelocitySaturation(double linear_vel_sat = 0.3, double angular_vel_sat = M_PI / 3) {
 		cfg([=](saip_batch* b, int id) {
@@ -217,6 +249,14 @@ public:
 	void setGoalVelocity(const std::vector<double>& dq) { setField(getTaskDof(), getTaskDof(), dq, "goal velocity vector size not consistent with task dof in JointTask::setGoalVelocity\n"); }
 	void setGoalAcceleration(const std::vector<double>& ddq) { setField(2 * getTaskDof(), getTaskDof(), ddq, "goal acceleration vector size not consistent with task dof in JointTask::setGoalAcceleration\n"); }
 	void setGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_joint_gains(b, id, &kp, &kv, &ki, 1); }); }
+	// JointTask.cpp:358-381 (defaults JointTask.h:40-41); the jerk-limited variant throws (not on the device)
+	void enableInternalOtgAccelerationLimited(double max_velocity = M_PI / 3.0, double max_acceleration = 2.0 * M_PI) {
+		_otg_enabled = true;
+		cfg([=](saip_batch* b, int id) { return saip_batch_set_otg_acceleration_limited(b, id, &max_velocity, &max_acceleration, 1); });
+	}
+	void enableInternalOtgJerkLimited(double, double, double) {
+		cfg([](saip_batch* b, int id) { return saip_batch_set_otg_jerk_limited(b, id, nullptr, nullptr, nullptr, 0); });
+	}
 	void enableVelocitySaturation(double saturation_velocity = M_PI / 3.0) {  // JointTask.cpp:410-421
 		cfg([=](saip_batch* b, int id) {
 			saip_status st = saip_batch_set_saturation_velocities(b, id, &saturation_velocity, 1);
