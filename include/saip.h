@@ -137,6 +137,22 @@ saip_status saip_batch_set_internal_otg(saip_batch*, int task, int enabled);
 saip_status saip_batch_set_otg_acceleration_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, int count);
 /* JointTask::enableInternalOtgJerkLimited (JointTask.cpp:383-406): third-order Ruckig profiles are not implemented -> SAIP_ERR_UNSUPPORTED */
 saip_status saip_batch_set_otg_jerk_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, const double* max_jerk, int count);
+/* ---- the step after the path: what the reference's examples do with the external simulator,
+ * sim->setJointTorques(tau); sim->integrate() (examples/05-using_robot_controller/05-using_robot_controller.cpp:225-231).
+ * Forward dynamics M(q) qdd + b(q,dq) + g(q) = tau - damping*dq on the resident state with the torques of the last cycle held,
+ * then `substeps` semi-implicit Euler steps of size dt (dq += dt*qdd; q += dt*dq).  gravity = NULL uses the model's gravity
+ * (0, 0, -9.81); pass {0,0,0} for the gravity-free worlds of the reference's examples.  Instances whose torque is NaN (flagged
+ * as outside the non-singular branch) coast.  The state changed: saip_batch_update_task_models is due before the next
+ * saip_batch_compute_control_torques, exactly like after robot->setQ(). */
+saip_status saip_batch_integrate(saip_batch*, double dt, int substeps, const double gravity[3], double damping);
+/* `steps` closed-loop control periods { internal OTGs -> control cycle -> integrate(sim_dt, substeps) } enqueued back to back on the
+ * engine stream without host synchronisation (follow with saip_batch_synchronize); goals stay as they are on the device. */
+saip_status saip_batch_rollout_async(saip_batch*, int steps, double sim_dt, int substeps, const double gravity[3], double damping);
+/* overwrite the resident torque array ([dof][B]) that saip_batch_integrate applies -- sim->setJointTorques(name, control_torques +
+ * ui_torques) in the examples (05-...cpp:226-228) when the applied torque is not just the last cycle's output */
+saip_status saip_batch_set_torques_host(saip_batch*, const double* tau);
+/* read the resident state back: q, dq [dof][B] (either may be NULL) */
+saip_status saip_batch_get_state_host(saip_batch*, double* q, double* dq);
 /* getDesiredPosition/Velocity/Acceleration (JointTask.h:185-200; MotionForceTask desired* likewise): [goal_components][B] in the
  * goal layout -- the internal OTG's output of the last cycle when it is enabled, otherwise the goal itself. */
 saip_status saip_batch_get_desired_host(saip_batch*, int task, double* desired);

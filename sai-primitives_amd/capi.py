@@ -7,8 +7,8 @@ import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libsaip.so")
-SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip", "csrc/saip_otg.hip"]
-HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "../include/saip.h"]
+SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip", "csrc/saip_otg.hip", "csrc/saip_dynamics.hip"]
+HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "csrc/saip_fk.h", "../include/saip.h"]
 
 SAIP_OK, SAIP_ERR_INVALID_ARGUMENT, SAIP_ERR_UNSUPPORTED, SAIP_ERR_NO_DEVICE, SAIP_ERR_DEVICE, SAIP_ERR_ORDER = range(6)
 NAME_LEN = 48
@@ -90,6 +90,10 @@ def lib():
         "saip_batch_set_otg_acceleration_limited": (C.c_int, [vp, C.c_int, dp, dp, C.c_int]),
         "saip_batch_set_otg_jerk_limited": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int]),
         "saip_batch_get_desired_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_integrate": (C.c_int, [vp, C.c_double, C.c_int, dp, C.c_double]),
+        "saip_batch_rollout_async": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, dp, C.c_double]),
+        "saip_batch_get_state_host": (C.c_int, [vp, dp, dp]),
+        "saip_batch_set_torques_host": (C.c_int, [vp, dp]),
         "saip_batch_get_otg_status_host": (C.c_int, [vp, C.c_int, ip, ip]),
         "saip_batch_set_velocity_saturation": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_saturation_velocities": (C.c_int, [vp, C.c_int, dp, C.c_int]),

@@ -572,6 +572,42 @@ class RobotController:
     def stepAsync(self):
         self._call("saip_batch_step_async")
 
+    # -- the step after the path: resident forward dynamics (what the examples do with sim->integrate(), examples/05-...cpp:225-231)
+    @staticmethod
+    def _grav(gravity):
+        if gravity is None:
+            return None, None
+        g = np.ascontiguousarray(np.asarray(gravity, float).reshape(3))
+        return g, _dptr(g)
+
+    def integrate(self, dt: float, substeps: int = 1, gravity=None, damping: float = 0.0):
+        """semi-implicit Euler steps of the resident state under the torques of the last cycle; gravity None = model gravity"""
+        self._push_state()
+        g, gp = self._grav(gravity)
+        self._call("saip_batch_integrate", float(dt), int(substeps), gp, float(damping))
+
+    def rolloutAsync(self, steps: int, sim_dt: float, substeps: int = 1, gravity=None, damping: float = 0.0):
+        """`steps` closed-loop periods {internal OTGs, control cycle, integrate} enqueued without host synchronisation"""
+        self._push_state()
+        g, gp = self._grav(gravity)
+        self._call("saip_batch_rollout_async", int(steps), float(sim_dt), int(substeps), gp, float(damping))
+
+    def setTorques(self, tau):
+        """overwrite the resident torques the next integrate() applies: (B, dof)"""
+        a = _soa(np.asarray(tau, float), self.batch_size, self._robot.dof(), "torques")
+        self._call("saip_batch_set_torques_host", _dptr(a))
+
+    def pullState(self):
+        """read the resident state back into the SaiModel mirror (after integrate / rolloutAsync); returns (q, dq) (B, dof)"""
+        r = self._robot
+        n, B = r.dof(), self.batch_size
+        q, dq = np.empty((n, B)), np.empty((n, B))
+        self._call("saip_batch_get_state_host", _dptr(q), _dptr(dq))
+        r._q, r._dq = q.T.copy(), dq.T.copy()
+        r._state_version += 1
+        self._pushed_version = r._state_version  # the device already holds this state
+        return r._q, r._dq
+
     def synchronize(self):
         self._call("saip_batch_synchronize")
 

@@ -97,6 +97,18 @@ struct CycleParams {
 	double bie_thr;
 };
 
+// forward dynamics + semi-implicit Euler step (saip_dynamics.hip)
+struct SimParams {
+	int B, ld, n, substeps;
+	double dt, damping;    // viscous joint damping coefficient (0 = none)
+	double gravity[3];
+	const ModelDev* model;
+	double* q;             // [n][ld] in/out
+	double* dq;            // [n][ld] in/out
+	const double* tau;     // [n][ld] joint torques held over the call (NaN = coast)
+	double* ddq;           // optional [n][ld] joint accelerations of the last substep
+};
+
 // Internal OTG of one joint task (saip_otg.hip).  Passed to the kernel by value.
 enum { OTG_FLAG_GOAL_REACHED = 1, OTG_FLAG_RUCKIG_INIT = 2, OTG_FLAG_STATE_VALID = 4, OTG_FLAG_ERROR = 8, OTG_FLAG_FINISHED_MOVING = 16,
 	   OTG_FLAG_GOAL_ORI_VALID = 32, OTG_FLAG_INVALID_GOAL = 64 };

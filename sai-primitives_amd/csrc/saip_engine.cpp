@@ -20,11 +20,13 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 int otg_state_fields();
+hipError_t launch_integrate(const SimParams& S, hipStream_t stream);
 }  // namespace saip
 
 using saip::CycleParams;
 using saip::ModelDev;
 using saip::OtgDev;
+using saip::SimParams;
 using saip::TaskDev;
 
 static thread_local std::string g_err;
@@ -1220,6 +1222,57 @@ extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
 	return SAIP_OK;
 }
 extern "C" const char* saip_batch_kernel_name(saip_batch* b) { return b ? b->kernel_name.c_str() : ""; }
+
+// ---- the step after the path: forward dynamics + semi-implicit Euler on the resident state (saip_dynamics.hip)
+static saip_status enqueue_integrate(saip_batch* b, double dt, int substeps, const double* gravity, double damping) {
+	SimParams S;
+	S.B = b->B;
+	S.ld = b->ld;
+	S.n = b->model->n;
+	S.substeps = substeps;
+	S.dt = dt;
+	S.damping = damping;
+	for (int i = 0; i < 3; i++) S.gravity[i] = gravity ? gravity[i] : b->model->dev.gravity[i];
+	S.model = b->model_dev;
+	S.q = b->q;
+	S.dq = b->dq;
+	S.tau = b->tau_bound ? b->tau_bound : b->tau;
+	S.ddq = nullptr;
+	hipError_t e = saip::launch_integrate(S, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "integrate launch failed: %s", hipGetErrorString(e));
+	b->models_valid = false;  // the state moved: like after robot->setQ(), updateControllerTaskModels() is due
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_integrate(saip_batch* b, double dt, int substeps, const double* gravity, double damping) {
+	saip_status st = need_ready(b, "saip_batch_integrate");
+	if (st) return st;
+	if (!(dt > 0) || substeps < 1 || damping < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_integrate: dt > 0, substeps >= 1, damping >= 0 required");
+	return enqueue_integrate(b, dt, substeps, gravity, damping);
+}
+// steps x { internal OTGs, control cycle, integrate } enqueued back to back on the engine stream, no host synchronisation
+extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double sim_dt, int substeps, const double* gravity, double damping) {
+	saip_status st = need_ready(b, "saip_batch_rollout_async");
+	if (st) return st;
+	if (steps < 1 || !(sim_dt > 0) || substeps < 1 || damping < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_rollout_async: bad arguments");
+	for (int i = 0; i < steps; i++) {
+		if ((st = launch_cycle(b, false))) return st;
+		if ((st = enqueue_integrate(b, sim_dt, substeps, gravity, damping))) return st;
+	}
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_torques_host(saip_batch* b, const double* tau) {
+	saip_status st = need_ready(b, "saip_batch_set_torques_host");
+	if (st) return st;
+	if (!tau) return fail(SAIP_ERR_INVALID_ARGUMENT, "null torque pointer");
+	return copy_h2d(b, b->tau_bound ? b->tau_bound : b->tau, tau, b->model->n);
+}
+extern "C" saip_status saip_batch_get_state_host(saip_batch* b, double* q, double* dq) {
+	saip_status st = need_ready(b, "saip_batch_get_state_host");
+	if (st) return st;
+	if (q && (st = copy_d2h(b, q, b->q, b->model->n))) return st;
+	if (dq && (st = copy_d2h(b, dq, b->dq, b->model->n))) return st;
+	return SAIP_OK;
+}
 
 // desired state of a task = what its control law tracks: the internal OTG's output when enabled, else the goal (JointTask.h:185-200)
 extern "C" saip_status saip_batch_get_desired_host(saip_batch* b, int t, double* desired) {

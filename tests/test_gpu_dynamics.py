@@ -1,0 +1,97 @@
+"""Resident forward dynamics + semi-implicit Euler (the step after the path; csrc/saip_dynamics.hip).
+The reference delegates this step to the external sai-simulation (examples/05-...cpp:225-231), so there is no reference arithmetic:
+the oracle is the Lagrangian restatement workloads.forward_dynamics (finite-difference Christoffel terms, no recursion in common
+with the kernel's Newton-Euler pass), plus energy conservation and the closed-loop behaviour of the reference's example 05."""
+import numpy as np
+import pytest
+
+import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(robot_name, tasks, B, **kw):
+    from sai_primitives_amd.controller import controller_from_specs
+    return controller_from_specs(robot_name, tasks, B, device=0, **kw)
+
+
+@pytest.mark.parametrize("robot_name,cfg", [("panda_arm", 2), ("panda_sliding_base", 6), ("chain30", 5)])
+def test_one_step_matches_lagrangian_oracle(robot_name, cfg):
+    B = 48
+    d = W.make_inputs(cfg, B)
+    model = d["model"]
+    n = model.dof
+    rng = np.random.default_rng(4)
+    robot, ctrl, tasks = _engine(model.name, d["tasks"], B)
+    tau = rng.uniform(-5, 5, (B, n))
+    ctrl.setTorques(tau)
+    dq = rng.uniform(-1.0, 1.0, (B, n))
+    robot.setQ(d["q"])
+    robot.setDq(dq)
+    robot.updateModel()
+    dt = 1e-4
+    for grav, damping in [((0.0, 0.0, -9.81), 0.0), ((0.0, 0.0, 0.0), 0.3)]:
+        robot.setQ(d["q"])
+        robot.setDq(dq)
+        robot.updateModel()
+        ctrl.integrate(dt, 1, gravity=grav, damping=damping)
+        ctrl.synchronize()
+        q1, dq1 = ctrl.pullState()
+        qdd = (dq1 - dq) / dt
+        ref = W.forward_dynamics(model, d["q"], dq, tau, g=grav, damping=damping)
+        err = np.abs(qdd - ref).max() / max(1.0, np.abs(ref).max())
+        print(robot_name, "gravity", grav, "max rel qdd error", err)
+        assert err < 1e-6
+        assert np.abs(q1 - (d["q"] + dt * dq1)).max() < 1e-15   # semi-implicit: positions advance with the NEW velocities
+
+
+def test_energy_is_conserved_without_torques():
+    B = 32
+    d = W.make_inputs(2, B)
+    model = d["model"]
+    robot, ctrl, _ = _engine(model.name, d["tasks"], B)
+    ctrl.setTorques(np.zeros((B, 7)))
+    dq = np.random.default_rng(1).uniform(-0.5, 0.5, (B, 7))
+    robot.setQ(d["q"])
+    robot.setDq(dq)
+    robot.updateModel()
+    E0 = W.total_energy(model, d["q"], dq)
+    ctrl.integrate(2e-5, 5000)      # 0.1 s of free motion under gravity
+    ctrl.synchronize()
+    q1, dq1 = ctrl.pullState()
+    E1 = W.total_energy(model, q1, dq1)
+    drift = np.abs(E1 - E0).max()
+    moved = np.abs(q1 - d["q"]).max()
+    print("energy drift", drift, "J over 0.1 s; max joint motion", moved, "rad; E0 range", E0.min(), E0.max())
+    assert moved > 0.02 and drift < 2e-3    # first-order symplectic scheme: bounded O(dt) energy error
+
+
+def test_on_device_closed_loop_rollout_tracks_otg_trajectory():
+    """examples/05 scenario, entirely on the device: internal OTGs -> control cycle -> dynamics, 1 kHz control / 2 kHz simulation
+    (examples/05-...cpp:216-231), gravity-free world (world.urdf:3).  The end effector must follow the Cartesian OTG to its goal."""
+    B = 64
+    d = W.make_inputs(2, B)
+    model = d["model"]
+    robot, ctrl, tasks = _engine(model.name, d["tasks"], B, disable_otg=False)
+    robot.setQ(d["q"])
+    robot.setDq(np.zeros((B, 7)))
+    robot.updateModel()
+    ctrl.reinitializeTasks()
+    mf, jt = tasks
+    x0 = mf.getGoalPosition()
+    goal = x0 + np.array([0.05, -0.04, 0.03])
+    mf.setGoalPosition(goal)
+    ctrl.updateControllerTaskModels()
+    ctrl.rolloutAsync(1500, 5e-4, 2, gravity=(0.0, 0.0, 0.0))
+    ctrl.synchronize()
+    q1, dq1 = ctrl.pullState()
+    fr = W.fk(model, q1)
+    li = model.link_index("end-effector")
+    x1 = fr[li][1] + fr[li][0] @ np.array([0.0, 0.0, 0.07])
+    gr, fl, res = mf.getInternalOtgStatus()
+    err = np.linalg.norm(x1 - goal, axis=1)
+    print("rollout: OTG goal reached", int(gr.sum()), "of", B, "| max end-effector error", err.max(), "| max |dq|", np.abs(dq1).max())
+    assert ctrl.getTorques() is not None and ctrl.status.sum() == 0
+    assert gr.all()
+    assert err.max() < 2e-3 and np.abs(dq1).max() < 0.05
+    assert np.linalg.norm(x0 - goal, axis=1).min() > 0.06

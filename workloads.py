@@ -195,6 +195,39 @@ def gravity_vector(model: RobotModel, frames, g=(0.0, 0.0, -9.81)) -> np.ndarray
     return tau
 
 
+def forward_dynamics(model: RobotModel, q, dq, tau, g=(0.0, 0.0, -9.81), damping=0.0, eps=1e-5):
+    """qdd (B,n) from the Lagrange equations, independent of any recursive Newton-Euler code:
+    M qdd + Mdot dq - 1/2 grad_q(dq^T M dq) + dU/dq = tau - damping dq,  with dM/dq_k by central differences of mass_matrix.
+    (test oracle for the resident integrator, csrc/saip_dynamics.hip; accuracy ~1e-9 relative)"""
+    q, dq, tau = (np.asarray(x, float) for x in (q, dq, tau))
+    B, n = q.shape
+    M = mass_matrix(model, fk(model, q))
+    dM = np.zeros((n, B, n, n))
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = eps
+        dM[k] = (mass_matrix(model, fk(model, q + e)) - mass_matrix(model, fk(model, q - e))) / (2 * eps)
+    Mdot_dq = np.einsum("kbij,bk,bj->bi", dM, dq, dq)
+    grad = 0.5 * np.einsum("kbij,bi,bj->bk", dM, dq, dq)
+    grav = gravity_vector(model, fk(model, q), g)   # dU/dq
+    rhs = tau - damping * dq - (Mdot_dq - grad) - grav
+    return np.linalg.solve(M, rhs[..., None])[..., 0]
+
+
+def total_energy(model: RobotModel, q, dq, g=(0.0, 0.0, -9.81)):
+    """kinetic + potential energy (B,)"""
+    fr = fk(model, q)
+    M = mass_matrix(model, fr)
+    T = 0.5 * np.einsum("bi,bij,bj->b", dq, M, dq)
+    U = np.zeros(q.shape[0])
+    gv = np.asarray(g, float)
+    for li, l in enumerate(model.links):
+        R, o = fr[li]
+        c = o + R @ np.asarray(l["com"], float)
+        U -= l["mass"] * (c @ gv)
+    return T + U
+
+
 # ----------------------------------------------------------- sai-model style helpers
 def matrix_range_basis(A: np.ndarray, tol: float = 1e-3) -> np.ndarray:
     """SaiModel::matrixRangeBasis [RECALLED]: zeros(rows,1) if ~0, identity if full row
