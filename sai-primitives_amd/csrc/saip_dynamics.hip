@@ -7,8 +7,8 @@
 //   M(q) qdd + b(q, dq) + g(q) = tau        b: Coriolis / centrifugal, g: gravity
 //   dq <- dq + dt qdd ;  q <- q + dt dq     (semi-implicit Euler, `substeps` times per call with the torque held)
 //
-// One lane per instance.  Bias forces by the recursive Newton-Euler pass in world coordinates, M column by column from the same
-// backward pass with unit joint accelerations (O(n^2) per instance, n <= 32), Cholesky solve.  Per-body arrays are lane-private
+// One lane per instance.  Bias forces by one recursive Newton-Euler pass in world coordinates, M(q) from composite rigid bodies
+// (spatial inertias about the world origin, suffix sums along the chain), Cholesky solve; fully unrolled for 7-dof arms.  Per-body arrays are lane-private
 // (scratch for NMAX = 32, mostly registers for NMAX = 8); the kernel is FP64-latency bound like the cycle kernels and is not on the
 // benchmarked path.
 #include <hip/hip_runtime.h>
@@ -46,6 +46,7 @@ template <int NMAX>
 __device__ void chain_fk(const ModelDev& md, int n, const double* q, Chain<NMAX>& K) {
 	double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	V3 o = v3(0, 0, 0);
+#pragma unroll
 	for (int j = 0; j < n; j++) {
 		o = o + mulR(R, v3(md.p0[j][0], md.p0[j][1], md.p0[j][2]));
 		double Rt[9];
@@ -85,6 +86,7 @@ template <int NMAX>
 __device__ void rnea(const ModelDev& md, int n, const Chain<NMAX>& K, const double* dq, const double* ddq, V3 a0, bool with_velocity, double* tau) {
 	V3 f[NMAX], nn[NMAX];  // net force on body j, net moment about its centre of mass
 	V3 w = v3(0, 0, 0), al = v3(0, 0, 0), a = a0, op = v3(0, 0, 0);
+#pragma unroll
 	for (int j = 0; j < n; j++) {
 		const V3 r = K.o[j] - op;  // from the previous joint origin (rigidly attached to body j-1) to this one
 		a = a + cross(al, r);
@@ -107,7 +109,9 @@ __device__ void rnea(const ModelDev& md, int n, const Chain<NMAX>& K, const doub
 		op = K.o[j];
 	}
 	V3 F = v3(0, 0, 0), N = v3(0, 0, 0);  // force / moment (about o_j) transmitted through joint j
-	for (int j = n - 1; j >= 0; j--) {
+#pragma unroll
+	for (int jj = 0; jj < n; jj++) {
+		const int j = n - 1 - jj;
 		if (j < n - 1) N = N + cross(K.o[j + 1] - K.o[j], F);  // shift the child's wrench from o_{j+1} to o_j
 		F = F + f[j];
 		N = N + nn[j] + cross(K.c[j] - K.o[j], f[j]);
@@ -117,59 +121,128 @@ __device__ void rnea(const ModelDev& md, int n, const Chain<NMAX>& K, const doub
 
 }  // namespace
 
-template <int NMAX>
+// Joint-space inertia from composite rigid bodies in world coordinates (serial chain: every later body is a descendant).
+// Spatial inertia about the world origin O: mass m, first moment hm = m c, rotational inertia Io = R I R^T + m (c.c 1 - c c^T).
+// Column j: momentum of the composite body j.. under the unit motion of joint j, (p, L_O) = Ic_j s_j with s_j = (z_j, o_j x z_j) for a
+// revolute and (0, z_j) for a prismatic joint; M_ij = s_i . (L_O, p) for i <= j.
+template <int NMAX, bool EXACT>
+__device__ __forceinline__ void mass_matrix_crb(const ModelDev& md, int n_rt, const Chain<NMAX>& K, double (&M)[NMAX][NMAX]) {
+	const int n = EXACT ? NMAX : n_rt;
+	double cm = 0.0;
+	V3 ch = v3(0, 0, 0);
+	double cI[6] = {0, 0, 0, 0, 0, 0};  // xx yy zz xy xz yz
+#pragma unroll
+	for (int jj = 0; jj < n; jj++) {
+		const int j = n - 1 - jj;
+		// add body j to the composite
+		const double m = md.mass[j];
+		const V3 c = K.c[j];
+		const double* R = K.R[j];
+		const double* I6 = md.inertia[j];
+		// R I R^T
+		double RI[9];
+#pragma unroll
+		for (int r = 0; r < 3; r++) {
+			RI[3 * r + 0] = R[3 * r] * I6[0] + R[3 * r + 1] * I6[3] + R[3 * r + 2] * I6[4];
+			RI[3 * r + 1] = R[3 * r] * I6[3] + R[3 * r + 1] * I6[1] + R[3 * r + 2] * I6[5];
+			RI[3 * r + 2] = R[3 * r] * I6[4] + R[3 * r + 1] * I6[5] + R[3 * r + 2] * I6[2];
+		}
+		const double cc = dot(c, c);
+		cI[0] += RI[0] * R[0] + RI[1] * R[1] + RI[2] * R[2] + m * (cc - c.x * c.x);
+		cI[1] += RI[3] * R[3] + RI[4] * R[4] + RI[5] * R[5] + m * (cc - c.y * c.y);
+		cI[2] += RI[6] * R[6] + RI[7] * R[7] + RI[8] * R[8] + m * (cc - c.z * c.z);
+		cI[3] += RI[0] * R[3] + RI[1] * R[4] + RI[2] * R[5] - m * c.x * c.y;
+		cI[4] += RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8] - m * c.x * c.z;
+		cI[5] += RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8] - m * c.y * c.z;
+		cm += m;
+		ch = ch + m * c;
+		// unit motion of joint j
+		const bool rev = md.jtype[j] == 1;
+		const V3 wj = rev ? K.z[j] : v3(0, 0, 0);
+		const V3 vj = rev ? cross(K.o[j], K.z[j]) : K.z[j];
+		const V3 p = cm * vj + cross(wj, ch);
+		const V3 L = v3(cI[0] * wj.x + cI[3] * wj.y + cI[4] * wj.z, cI[3] * wj.x + cI[1] * wj.y + cI[5] * wj.z, cI[4] * wj.x + cI[5] * wj.y + cI[2] * wj.z) +
+					 cross(ch, vj);
+#pragma unroll
+		for (int i = 0; i < n; i++) {
+			if (i > j) continue;
+			const bool ri = md.jtype[i] == 1;
+			const V3 wi = ri ? K.z[i] : v3(0, 0, 0);
+			const V3 vi = ri ? cross(K.o[i], K.z[i]) : K.z[i];
+			const double v = dot(wi, L) + dot(vi, p);
+			M[i][j] = v;
+			M[j][i] = v;
+		}
+	}
+}
+
+template <int NMAX, bool EXACT>
 __global__ void __launch_bounds__(64) saip_integrate_kernel(const SimParams S) {
 	const int b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= S.B) return;
 	const ModelDev& md = *S.model;
-	const int n = S.n;
-	double q[NMAX], dq[NMAX], tau[NMAX], h[NMAX], ddq[NMAX], e[NMAX], col[NMAX];
+	const int n = EXACT ? NMAX : S.n;
+	double q[NMAX], dq[NMAX], tau[NMAX], h[NMAX], ddq[NMAX], e[NMAX];
 	double M[NMAX][NMAX];
+#pragma unroll
 	for (int j = 0; j < n; j++) {
 		q[j] = S.q[(size_t)j * S.ld + b];
 		dq[j] = S.dq[(size_t)j * S.ld + b];
 		tau[j] = S.tau[(size_t)j * S.ld + b];
 		if (!(tau[j] == tau[j])) tau[j] = 0.0;  // flagged instances (NaN torques) coast
+		e[j] = 0.0;
+		ddq[j] = 0.0;
 	}
 	const V3 a0 = v3(-S.gravity[0], -S.gravity[1], -S.gravity[2]);
 	Chain<NMAX> K;
 	for (int step = 0; step < S.substeps; step++) {
 		chain_fk<NMAX>(md, n, q, K);
-		for (int j = 0; j < n; j++) e[j] = 0.0;
 		rnea<NMAX>(md, n, K, dq, e, a0, true, h);  // b(q, dq) + g(q)
-		for (int i = 0; i < n; i++) {              // M[:, i] = RNEA(ddq = e_i) without velocity and gravity terms
-			e[i] = 1.0;
-			rnea<NMAX>(md, n, K, dq, e, v3(0, 0, 0), false, col);
-			e[i] = 0.0;
-			for (int j = 0; j < n; j++) M[j][i] = col[j];
-		}
+		mass_matrix_crb<NMAX, EXACT>(md, n, K, M);
 		// Cholesky M = L L^T (lower, in place), then two triangular solves
+#pragma unroll
 		for (int k = 0; k < n; k++) {
 			double d = M[k][k];
-			for (int l = 0; l < k; l++) d -= M[k][l] * M[k][l];
+#pragma unroll
+			for (int l = 0; l < n; l++)
+				if (l < k) d -= M[k][l] * M[k][l];
 			d = sqrt(d);
 			M[k][k] = d;
-			for (int i = k + 1; i < n; i++) {
+			const double rd = 1.0 / d;
+#pragma unroll
+			for (int i = 0; i < n; i++) {
+				if (i <= k) continue;
 				double s = M[i][k];
-				for (int l = 0; l < k; l++) s -= M[i][l] * M[k][l];
-				M[i][k] = s / d;
+#pragma unroll
+				for (int l = 0; l < n; l++)
+					if (l < k) s -= M[i][l] * M[k][l];
+				M[i][k] = s * rd;
 			}
 		}
+#pragma unroll
 		for (int i = 0; i < n; i++) {
 			double s = tau[i] - h[i] - S.damping * dq[i];
-			for (int l = 0; l < i; l++) s -= M[i][l] * ddq[l];
+#pragma unroll
+			for (int l = 0; l < n; l++)
+				if (l < i) s -= M[i][l] * ddq[l];
 			ddq[i] = s / M[i][i];
 		}
-		for (int i = n - 1; i >= 0; i--) {
+#pragma unroll
+		for (int ii = 0; ii < n; ii++) {
+			const int i = n - 1 - ii;
 			double s = ddq[i];
-			for (int l = i + 1; l < n; l++) s -= M[l][i] * ddq[l];
+#pragma unroll
+			for (int l = 0; l < n; l++)
+				if (l > i) s -= M[l][i] * ddq[l];
 			ddq[i] = s / M[i][i];
 		}
+#pragma unroll
 		for (int j = 0; j < n; j++) {
 			dq[j] += S.dt * ddq[j];
 			q[j] += S.dt * dq[j];
 		}
 	}
+#pragma unroll
 	for (int j = 0; j < n; j++) {
 		S.q[(size_t)j * S.ld + b] = q[j];
 		S.dq[(size_t)j * S.ld + b] = dq[j];
@@ -179,8 +252,9 @@ __global__ void __launch_bounds__(64) saip_integrate_kernel(const SimParams S) {
 
 hipError_t launch_integrate(const SimParams& S, hipStream_t stream) {
 	const int grid = (S.B + 63) / 64;
-	if (S.n <= 8) hipLaunchKernelGGL((saip_integrate_kernel<8>), dim3(grid), dim3(64), 0, stream, S);
-	else hipLaunchKernelGGL((saip_integrate_kernel<32>), dim3(grid), dim3(64), 0, stream, S);
+	if (S.n == 7) hipLaunchKernelGGL((saip_integrate_kernel<7, true>), dim3(grid), dim3(64), 0, stream, S);   // Panda-class arms: unrolled
+	else if (S.n <= 8) hipLaunchKernelGGL((saip_integrate_kernel<8, false>), dim3(grid), dim3(64), 0, stream, S);
+	else hipLaunchKernelGGL((saip_integrate_kernel<32, false>), dim3(grid), dim3(64), 0, stream, S);
 	return hipGetLastError();
 }
 
