@@ -67,6 +67,41 @@ def test_engine_matches_oracle_full_size(cfg, B):
     assert err < TOL
 
 
+@pytest.mark.parametrize("B", [1, 63, 65, 4097])
+@pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "general"])
+def test_ragged_batches(B, kernel):
+    """batch sizes that do not fill a wavefront / the 32-instance padding of the device arrays: every instance still matches the
+    oracle and nothing is read or written past B (B = 1 is the reference's own single-robot case)"""
+    from oracle import Oracle
+    d = W.make_inputs(2, B)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(kernel)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert tau.shape == (B, 7) and ctrl.status.shape == (B,) and ctrl.status.sum() == 0
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=4)
+    assert W.torque_error(tau, ref) < TOL
+
+
+def test_config4_shard_size_and_lean_variant():
+    """BASELINE config 4 = 8 x 8192 instances of the config-2 stack: one per-GPU shard (rank 3 of the seeded stream) against the
+    oracle, and the large-batch (> 16384) instantiation of the lane kernel against the default one on the same inputs"""
+    from oracle import Oracle
+    d = W.make_inputs(4, 8192, shard=3)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 8192)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)
+    assert st.sum() == 0 and ctrl.status.sum() == 0
+    assert W.torque_error(tau, ref) < TOL
+    B = 20480
+    reps = B // 4096
+    q, dq = np.tile(d["q"][:4096], (reps, 1)), np.tile(d["dq"][:4096], (reps, 1))
+    goals = [np.tile(g[:4096], (reps, 1)) for g in d["goals"]]
+    robot2, ctrl2, _ = _engine(d["model"].name, d["tasks"], B)
+    tau2 = _run(robot2, ctrl2, q, dq, goals)
+    assert ctrl2.status.sum() == 0
+    assert W.torque_error(tau2[:4096], ref[:4096]) < TOL and W.torque_error(tau2[-4096:], ref[:4096]) < TOL
+
+
 def test_general_kernel_explicitly_selected():
     from oracle import Oracle
     d = W.make_inputs(2, 512)
