@@ -121,6 +121,15 @@ saip_status saip_batch_set_joint_gains(saip_batch*, int task, const double* kp, 
 /* setDynamicDecouplingType (.h:670 / JointTask.h:363), setBoundedInertiaEstimateThreshold (.h:679 / JointTask.h:372) */
 saip_status saip_batch_set_dynamic_decoupling_type(saip_batch*, int task, int type);
 saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold);
+/* MotionForceTask::enableSingularityHandling / disableSingularityHandling (.h:715-725 -> SingularityHandler.h:146-158).
+ * enabled (reference default): instances that leave the fully non-singular branch need the reference's blended singularity
+ * strategies, which are not on the device -> status 1, NaN torques.
+ * disabled: the reference then uses only the non-singular part of the task, _N = _N_ns and tau = tau_ns
+ * (SingularityHandler.cpp:146-148, 319-330): the task acts on the span of the leading left singular vectors of its projected
+ * Jacobian, up to the first sigma_i / sigma_0 < s_max (:100-121); a fully singular task (sigma_0 < 1e-3) is passed through.
+ * Implemented: such instances finish with valid torques and status 2 (flagged by the lane kernel, recomputed by the general
+ * kernel launched behind it as a device-side slow path). */
+saip_status saip_batch_set_singularity_handling(saip_batch*, int task, int enabled);
 /* MotionForceTask::setSingularityHandlingBounds (.h:736) */
 saip_status saip_batch_set_singularity_bounds(saip_batch*, int task, double s_min, double s_max);
 /* disableInternalOtg / enableInternalOtg* (MotionForceTask.h:423, JointTask.h:323).  The reference default is ENABLED.

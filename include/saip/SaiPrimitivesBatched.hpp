@@ -179,6 +179,8 @@ public:
 	void setGoalAngularAcceleration(const std::vector<double>& a) { setField(21, 3, a, "setGoalAngularAcceleration: expected [3][B]"); }
 	void setPosControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_pos_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
+	void enableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 1); }); }    // MotionForceTask.h:715
+	void disableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 0); }); }  // :723
 	void setSingularityHandlingBounds(double s_min, double s_max) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_bounds(b, id, s_min, s_max); }); }
 	// MotionForceTask.cpp:510-523 (defaults MotionForceTask.h:68-71); the jerk-limited variant throws (not on the device)
 	void enableInternalOtgAccelerationLimited(double max_linear_velocity = 0.3, double max_linear_acceleration = 2.0,

@@ -42,7 +42,7 @@
 enum { JT_FIXED = 0, JT_REVOLUTE = 1, JT_PRISMATIC = 2 };
 enum { TASK_MOTION_FORCE = 1, TASK_JOINT = 2 };
 enum { FULL_DYNAMIC_DECOUPLING = 0, BOUNDED_INERTIA_ESTIMATES = 1, IMPEDANCE = 2 };
-enum { ST_OK = 0, ST_SINGULAR = 1 };
+enum { ST_OK = 0, ST_SINGULAR = 1, ST_TRUNCATED = 2 };
 
 typedef struct {
 	int type;
@@ -56,6 +56,7 @@ typedef struct {
 	int pos_range, ori_range;
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double s_min, s_max, s_abs_tol;
+	int sing_handling;     /* SingularityHandler::_enforce_handling_strategy (default true, SingularityHandler.cpp:61) */
 	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
 	double force_axis[3], moment_axis[3];
@@ -400,6 +401,7 @@ typedef struct {
 	double task_range_ns[36], projected_jacobian_ns[6 * MAXN], Lambda_ns[36], Lambda_ns_modified[36];
 	double sv[6];
 	int singular;
+	int truncated, skip;   /* handling disabled: task reduced to its non-singular part / passed through (fully singular) */
 	/* joint */
 	int r, empty;
 	double jt_projected_jacobian[MAXN * MAXN], current_task_range[MAXN * MAXN], M_partial[MAXN * MAXN],
@@ -415,24 +417,39 @@ static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	int r = n < 6 ? n : 6;
 	for (int i = 0; i < 6; i++) tm->sv[i] = i < r ? s[i] : 0;
 	tm->singular = 0;
-	if (s[0] < t->s_abs_tol) { /* :83 fully singular */
+	tm->truncated = 0;
+	tm->skip = 0;
+	if (k < 2) { /* :100 loop never runs (SURVEY App. C-4): rank-1 tasks leave stale state */
 		tm->singular = 1;
 		return;
 	}
-	if (k < 2) { /* :100 loop never runs (SURVEY App. C-4): rank-1 tasks leave stale state */
-		tm->singular = 1;
+	if (s[0] < t->s_abs_tol) { /* :83 fully singular */
+		if (t->sing_handling) {
+			tm->singular = 1;
+			return;
+		}
+		/* handling disabled: computeTorques returns zeros (:316-317); _N = _N_ns (:146-148) is a stale matrix in the reference,
+		 * restated as the identity (the task is passed through) */
+		tm->truncated = tm->skip = 1;
+		eye(tm->N, n);
 		return;
 	}
 	for (int i = 1; i < k; i++) {
 		double inv_condition_number = s[i] / s[0];
 		if (inv_condition_number < t->s_max) { /* :103 blending region */
-			tm->singular = 1;
-			return;
+			if (t->sing_handling) {
+				tm->singular = 1; /* needs the blended type-1 / type-2 strategies: not restated */
+				return;
+			}
+			/* disableSingularityHandling(): _N = _N_ns (:146-148), tau = tau_ns (:319-330) with _task_range_ns = U.leftCols(i) (:108) */
+			tm->truncated = 1;
+			tm->k = k = i;
+			break;
 		}
 	}
-	/* :123-141 fully non-singular: alpha = 1 */
+	/* :123-141 fully non-singular: alpha = 1 (or the non-singular part, :107-115) */
 	for (int i = 0; i < 6; i++)
-		for (int j = 0; j < k; j++) tm->task_range_ns[i * k + j] = U[i * r + j]; /* _svd_U.leftCols(task_rank) */
+		for (int j = 0; j < k; j++) tm->task_range_ns[i * k + j] = U[i * r + j]; /* _svd_U.leftCols(...) */
 	mTm(tm->task_range_ns, tm->projected_jacobian, tm->projected_jacobian_ns, 6, k, n);
 	double Jbar[MAXN * 6];
 	op_space_matrices(rs, n, tm->projected_jacobian_ns, k, tm->Lambda_ns, Jbar, tm->N); /* _N = _N_ns :146-148 */
@@ -567,7 +584,11 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	for (int i = 0; i < 3; i++) F_f[i] += tmp[i];
 	mat3v(sig_m, goal_moment, tmp);
 	for (int i = 0; i < 3; i++) F_f[3 + i] += tmp[i];
-	/* SingularityHandler::computeTorques, :307-309 */
+	/* SingularityHandler::computeTorques, :307-309 (and :316-330 with the handling strategy disabled) */
+	if (tm->skip) { /* fully singular task passed through: the integrators above still advanced, the torque is zero */
+		for (int i = 0; i < n; i++) tau[i] = 0;
+		return;
+	}
 	double a[6], b[6], f[6];
 	mTm(tm->task_range_ns, F_um, a, 6, k, 1);
 	mTm(tm->task_range_ns, F_f, b, 6, k, 1);
@@ -816,12 +837,13 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 	eye(N_prec, n);
 	jla_model jm;
 	jla_update_task_model(c, &rs, N_prec, N_constraints, &jm); /* :71-72, runs even when JLA is disabled */
-	int status = ST_OK;
+	int status = ST_OK, info = ST_OK;
 	for (int t = 0; t < c->nt; t++) {
 		const orc_task* tk = &c->task[t];
 		if (tk->type == TASK_MOTION_FORCE) {
 			mf_update_task_model(c, tk, &rs, N_prec, &tm[t]);
 			if (tm[t].singular) status = ST_SINGULAR;
+			if (tm[t].truncated) info = ST_TRUNCATED;
 			if (det && det->sv_out) memcpy(det->sv_out + 6 * t, tm[t].sv, sizeof(double) * 6);
 			if (status != ST_OK) break;
 			if (det && det->Lambda_out) memcpy(det->Lambda_out + t * MAXN * MAXN, tm[t].Lambda_ns, sizeof(double) * tm[t].k * tm[t].k);
@@ -869,7 +891,7 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 		joint_gravity_vector(c, &rs, g);
 		for (int i = 0; i < n; i++) tau[i] += g[i];
 	}
-	return ST_OK;
+	return info;
 }
 
 /* ------------------------------------------------------------------ exported API (ctypes) */
@@ -972,6 +994,7 @@ int orc_add_motion_force_task(orc_ctx* c, int link, const double* pos_in_link, c
 	}
 	t->s_min = 6e-3; t->s_max = 6e-2; /* MotionForceTask.cpp:197 */
 	t->s_abs_tol = 1e-3;              /* SingularityHandler.cpp:11 */
+	t->sing_handling = 1;             /* :61 */
 	t->kv_force = 10.0; t->kv_moment = 10.0; /* MotionForceTask.h:51,54 */
 	t->lin_sat = 0.3; t->ang_sat = M_PI / 3;  /* :63-64 */
 	t->force_axis[2] = 1.0; t->moment_axis[2] = 1.0;
@@ -1015,6 +1038,7 @@ void orc_set_singularity_bounds(orc_ctx* c, int task, double s_min, double s_max
 	c->task[task].s_min = s_min;
 	c->task[task].s_max = s_max;
 }
+void orc_set_singularity_handling(orc_ctx* c, int task, int enabled) { c->task[task].sing_handling = enabled != 0; }
 void orc_set_timestep(orc_ctx* c, int task, double dt) { c->task[task].dt = dt; }
 int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
 	c->jla_enabled = jla;

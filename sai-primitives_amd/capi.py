@@ -87,6 +87,7 @@ def lib():
         "saip_batch_set_bie_threshold": (C.c_int, [vp, C.c_int, C.c_double]),
         "saip_batch_set_singularity_bounds": (C.c_int, [vp, C.c_int, C.c_double, C.c_double]),
         "saip_batch_set_internal_otg": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_singularity_handling": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_otg_acceleration_limited": (C.c_int, [vp, C.c_int, dp, dp, C.c_int]),
         "saip_batch_set_otg_jerk_limited": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int]),
         "saip_batch_get_desired_host": (C.c_int, [vp, C.c_int, dp]),

@@ -379,6 +379,13 @@ class MotionForceTask(_Task):
     def setOriControlGains(self, kp, kv, ki=0.0):
         self._gains("saip_batch_set_ori_control_gains", kp, kv, ki)
 
+    def enableSingularityHandling(self):  # MotionForceTask.h:715-725
+        self._cfg("saip_batch_set_singularity_handling", 1)
+
+    def disableSingularityHandling(self):
+        """near-singular instances then use the non-singular part of the task only (status 2) instead of being flagged (status 1)"""
+        self._cfg("saip_batch_set_singularity_handling", 0)
+
     def setSingularityHandlingBounds(self, s_min, s_max):  # MotionForceTask.h:736
         self._cfg("saip_batch_set_singularity_bounds", float(s_min), float(s_max))
 
@@ -645,6 +652,8 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
             o.setPosControlGains(t["kp_pos"], t["kv_pos"], t["ki_pos"])
             o.setOriControlGains(t["kp_ori"], t["kv_ori"], t["ki_ori"])
             o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
+            if not t.get("singularity_handling", True):
+                o.disableSingularityHandling()
             o.setForceControlGains(0.7, t.get("kv_force", 10.0), 1.3)
             o.setMomentControlGains(0.7, t.get("kv_moment", 10.0), 1.3)
             if t.get("force_dim", 0):

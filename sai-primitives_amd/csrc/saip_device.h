@@ -50,7 +50,7 @@ struct TaskDev {
 	int has_ki;        // any integral gain != 0
 	int goal_comps;
 	int bm_identity;   // motion force: Bm == I6 (full task)
-	int pad0_;
+	int sing_handling; // motion force: SingularityHandler::_enforce_handling_strategy (1 = reference default)
 	double dt, bie_threshold, s_min, s_max, s_abs_tol;
 	double cert_kroot; // k^(-1/8): lower/upper bound ratio of the trace-power bound on lambda_max (singular-value certificate)
 	double pos[3];     // control point in the body frame
@@ -76,7 +76,8 @@ struct TaskDev {
 struct CycleParams {
 	int B, ld, n, nt;
 	int gravity_comp, torque_sat, integ_always, diag;
-	int jla, pad4_;    // RobotController::enableJointLimitAvoidance
+	int jla;           // RobotController::enableJointLimitAvoidance
+	int only_flagged;  // general kernel as the slow path behind the lane kernel: workgroups whose instance has status 0 exit at once
 	const double* q;   // [n][ld]
 	const double* dq;  // [n][ld]
 	double* tau;       // [n][ld]

@@ -467,6 +467,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_min = 6e-3;   // MotionForceTask.cpp:197
 	T.dev.s_max = 6e-2;
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
+	T.dev.sing_handling = 1; // _enforce_handling_strategy = true, SingularityHandler.cpp:61
 	T.integ_rows = 6;
 	refresh_has_ki(T.dev);
 	memset(&T.otg, 0, sizeof(T.otg));
@@ -732,6 +733,13 @@ extern "C" saip_status saip_batch_set_singularity_bounds(saip_batch* b, int t, d
 	if (s_min < 0 || s_max < s_min) return fail(SAIP_ERR_INVALID_ARGUMENT, "singularity bounds must satisfy 0 <= s_min <= s_max");
 	b->tasks[t].dev.s_min = s_min;
 	b->tasks[t].dev.s_max = s_max;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_singularity_handling(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_singularity_handling");
+	if (st) return st;
+	b->tasks[t].dev.sing_handling = enabled ? 1 : 0;
 	b->config_dirty = true;
 	return SAIP_OK;
 }
@@ -1043,7 +1051,7 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.torque_sat = b->torque_sat;
 	P.integ_always = b->integ_always;
 	P.jla = b->jla;
-	P.pad4_ = 0;
+	P.only_flagged = 0;
 	P.diag = diag;
 	P.q = b->q;
 	P.dq = b->dq;
@@ -1119,6 +1127,17 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
 			b->kernel_name = "saip_cycle_lane";
+			// slow path: instances the lane kernel flagged (outside the fully non-singular branch) are recomputed by the general kernel
+			// when a task can handle them there (singularity handling disabled: the task is reduced to its non-singular subspace);
+			// workgroups of unflagged instances exit at once, no host round trip
+			bool slow = false;
+			for (auto& T : b->tasks)
+				if (T.dev.type == saip::TASK_MOTION_FORCE && !T.dev.sing_handling) slow = true;
+			if (slow) {
+				P.only_flagged = 1;
+				hipError_t e2 = saip::launch_cycle_wg(P, b->stream);
+				if (e2 != hipSuccess) return fail(SAIP_ERR_DEVICE, "slow-path kernel launch failed: %s", hipGetErrorString(e2));
+			}
 			return SAIP_OK;
 		}
 	}

@@ -492,7 +492,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
 			UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
 		}
-		if (track && live) {
+		if (track && live && !singular) {  // flagged instances are recomputed from scratch by the slow path (or stay invalid)
 			UNR for (int i = 0; i < 3; i++) {
 				tk->integ[(size_t)i * ld + b] = ip[i];
 				tk->integ[(size_t)(3 + i) * ld + b] = io[i];
@@ -738,7 +738,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : tk->goal[(size_t)i * ld + b]);
 				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
 				ie += e * tk->dt;  // :323-324
-				if (track && live) tk->integ[(size_t)i * ld + b] = ie;
+				if (track && live && !singular) tk->integ[(size_t)i * ld + b] = ie;
 				double fi;
 				if (GL && tk->vel_sat) {  // JointTask.cpp:327-341
 					double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;

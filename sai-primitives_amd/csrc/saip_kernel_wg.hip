@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	const int tid = threadIdx.x;
 	const int b = blockIdx.x;
 	if (b >= P.B) return;
+	if (P.only_flagged && P.status[b] == 0) return;  // slow-path launch behind the lane kernel (workgroup-uniform)
 	const int n = P.n;
 	const ModelDev& md = *P.model;
 
@@ -248,6 +249,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	SYNC();
 
 	bool singular = false;
+	bool truncated = false;  // some motion-force task was reduced to its non-singular subspace (singularity handling disabled)
 	// ---------------------------------------------------------------- task hierarchy
 	for (int t = 0; t < P.nt; t++) {
 		const TaskDev& tk = P.tasks[t];
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		int r = 0;           // rank of the task in its range basis
 		bool empty = false;  // JointTask with no controllable dof left
 		bool u_identity = true;
+		bool mf_trunc = false;  // this motion-force task acts on the top-r left singular directions only; W[3] = their k x r coordinates
 		const int gs = tk.goal_comps;
 		for (int e = tid; e < gs; e += T) sm.goal[e] = tk.goal[(size_t)e * P.ld + b];
 
@@ -348,20 +351,67 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				SYNC();
 				const bool certified = sm.flag != 0;
 				SYNC();
+				r = k;
 				if (!certified) {  // exact path: singular values from the Gram eigenvalues (SingularityHandler.cpp:78-121)
-					jacobi_eig<T>(sm.W[1], nullptr, k, LD, sm.cs, &sm.flag, tid);
+					jacobi_eig<T>(sm.W[1], tk.sing_handling ? nullptr : sm.W[2], k, LD, sm.cs, &sm.flag, tid);
 					double lmax = 0.0;
 					for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
 					double s0 = sqrt(lmax);
-					sing = !(s0 >= tk.s_abs_tol);
-					for (int i = 0; i < k; i++) {
-						double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
-						if (si / s0 < tk.s_max) sing = true;
+					if (tk.sing_handling) {
+						// handling strategy enforced (reference default): the blended / singular strategies are not on the device -> flagged
+						sing = !(s0 >= tk.s_abs_tol);
+						for (int i = 0; i < k; i++) {
+							double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
+							if (si / s0 < tk.s_max) sing = true;
+						}
+					} else {
+						// disableSingularityHandling(): _N = _N_ns and tau = tau_ns (SingularityHandler.cpp:146-148, 319-330): the task acts on
+						// the span of the leading left singular vectors U[:, :i], i = first index with sigma_i / sigma_0 < s_max (:100-121)
+						if (tid == 0) {
+							int ord[6];
+							for (int i = 0; i < k; i++) ord[i] = i;
+							for (int i = 1; i < k; i++)  // insertion sort, descending eigenvalue
+								for (int j = i; j > 0 && sm.W[1][ord[j] * LD + ord[j]] > sm.W[1][ord[j - 1] * LD + ord[j - 1]]; j--) {
+									int t_ = ord[j];
+									ord[j] = ord[j - 1];
+									ord[j - 1] = t_;
+								}
+							int ns = k;
+							if (!(s0 >= tk.s_abs_tol)) ns = 0;  // fully singular (:83-98): the task is passed through (tau = 0, :316-317)
+							else
+								for (int i = 1; i < k; i++)
+									if (sqrt(fmax(sm.W[1][ord[i] * LD + ord[i]], 0.0)) / s0 < tk.s_max) {
+										ns = i;
+										break;
+									}
+							sm.rank = ns;
+							for (int i = 0; i < k; i++) sm.colidx[i] = ord[i];
+						}
+						SYNC();
+						r = sm.rank;
+						if (r < k) {
+							truncated = true;
+							if (r == 0) {
+								empty = true;
+							} else {
+								mf_trunc = true;
+								for (int e = tid; e < k * r; e += T) {
+									int i = e / r, c = e - i * r;
+									sm.W[3][i * LD + c] = sm.W[2][i * LD + sm.colidx[c]];  // U_ns in range(P) coordinates
+								}
+								SYNC();
+								gemm<T>(sm.W[0], LD, sm.W[3], 1, LD, Jh, LD, 1, r, k, n, tid);  // J_ns = U_ns^T Jh
+								SYNC();
+								for (int e = tid; e < r * n; e += T) {
+									int i = e / n, j = e - i * n;
+									Jh[i * LD + j] = sm.W[0][i * LD + j];
+								}
+							}
+						}
 					}
 				}
 			}
 			if (sing) singular = true;
-			r = k;
 			SYNC();
 		} else {
 			const int m = tk.m;
@@ -570,7 +620,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 						}
 				}
 				SYNC();
-				if (tid < r) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
+				if (tid < tk.k) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
 					double s = 0.0, s2 = 0.0;
 					for (int i = 0; i < 6; i++) {
 						s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
@@ -580,6 +630,20 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					sm.v1[tid] = s2;
 				}
 				SYNC();
+				if (mf_trunc) {  // U_ns^T of both (task_range_ns^T F, SingularityHandler.cpp:321-322)
+					double s = 0.0, s2 = 0.0;
+					if (tid < r)
+						for (int i = 0; i < tk.k; i++) {
+							s = fma(sm.W[3][i * LD + tid], sm.v0[i], s);
+							s2 = fma(sm.W[3][i * LD + tid], sm.v1[i], s2);
+						}
+					SYNC();
+					if (tid < r) {
+						sm.v0[tid] = s;
+						sm.v1[tid] = s2;
+					}
+					SYNC();
+				}
 				if (tid < r) {  // g = Lambda_mod fhat + ffhat   (SingularityHandler.cpp:307-309)
 					double s = sm.v1[tid];
 					for (int i = 0; i < r; i++) s = fma(Lmod[tid * LD + i], sm.v0[i], s);
@@ -739,7 +803,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		if (singular) tv = __builtin_nan("");
 		P.tau[(size_t)tid * P.ld + b] = tv;
 	}
-	if (tid == 0) P.status[b] = singular ? 1 : 0;
+	if (tid == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
 }
 
 // ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)

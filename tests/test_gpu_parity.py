@@ -35,20 +35,20 @@ def _load(path):
     tasks = W.config_tasks(cfg)
     goals = [z[f"goal{i}"] for i in range(len(tasks))]
     jla = bool(z["joint_limit_avoidance"]) if "joint_limit_avoidance" in z else False
-    return cfg, W.CONFIGS[cfg]["robot"], tasks, z["q"], z["dq"], goals, z["tau"], bool(z["gravity_comp"]), bool(z["torque_saturation"]), jla
+    return cfg, W.CONFIGS[cfg]["robot"], tasks, z["q"], z["dq"], goals, z["tau"], bool(z["gravity_comp"]), bool(z["torque_saturation"]), jla, z["status"]
 
 
 @pytest.mark.parametrize("kernel", [0, 1], ids=["auto", "general"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_engine_matches_golden(path, kernel):
-    cfg, robot_name, tasks, q, dq, goals, tau_ref, grav, sat, jla = _load(path)
+    cfg, robot_name, tasks, q, dq, goals, tau_ref, grav, sat, jla, st_ref = _load(path)
     robot, ctrl, _ = _engine(robot_name, tasks, q.shape[0])
     ctrl.setKernel(kernel)   # 0: lane kernel where it applies; 1: force the general workgroup-per-instance kernel
     ctrl.enableJointLimitAvoidance(jla)
     ctrl.enableGravityCompensation(grav)
     ctrl.enableTorqueSaturation(sat)
     tau = _run(robot, ctrl, q, dq, goals)
-    assert ctrl.status.sum() == 0
+    assert np.array_equal(ctrl.status, st_ref)   # all 0, except config 12: 2 = task reduced to its non-singular subspace
     err = W.torque_error(tau, tau_ref)
     print(os.path.basename(path), ctrl.kernelName(), "err", err)
     assert err < TOL
@@ -143,6 +143,30 @@ def test_singular_instances_are_flagged_not_wrong():
     assert np.array_equal(ctrl.status, st) and st[5] == 1
     assert np.isnan(tau[st == 1]).all()
     assert W.torque_error(tau[st == 0], ref[st == 0]) < TOL
+
+
+def test_singularity_handling_disabled_full_size():
+    """disableSingularityHandling() (MotionForceTask.h:723): near-singular instances are not flagged any more, the motion-force task
+    acts on its non-singular subspace (SingularityHandler.cpp:107-115, 146-148, 319-330).  Lane kernel + device-side slow path and
+    the general kernel alone against the oracle, 4096 instances of which a third sit inside the blending region; with the handling
+    strategy enabled (default) the same instances are flagged."""
+    from oracle import Oracle
+    B = 4096
+    d = W.make_inputs(12, B)
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)
+    assert (st == 2).sum() > B // 4 and (st == 1).sum() == 0
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+        ctrl.setKernel(kernel)
+        tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+        assert np.array_equal(ctrl.status, st)
+        err = W.torque_error(tau, ref)
+        print("handling disabled, kernel", ctrl.kernelName(), "truncated", int((st == 2).sum()), "err", err)
+        assert err < TOL
+    tasks_on = W.config_tasks(2)
+    robot, ctrl, _ = _engine(d["model"].name, tasks_on, B)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status == 1, st == 2) and np.isnan(tau[st == 2]).all() and np.isfinite(tau[st == 0]).all()
 
 
 def test_task_nullspaces_match_oracle():

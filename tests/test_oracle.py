@@ -24,20 +24,20 @@ def load_golden(path):
     goals = [z[f"goal{i}"] for i in range(len(tasks))]
     opts = dict(gravity_comp=bool(z["gravity_comp"]), torque_saturation=bool(z["torque_saturation"]),
                 joint_limit_avoidance=bool(z["joint_limit_avoidance"]) if "joint_limit_avoidance" in z else False)
-    return model, tasks, z["q"], z["dq"], goals, z["tau"], opts
+    return model, tasks, z["q"], z["dq"], goals, z["tau"], opts, z["status"]
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_matches_golden(path):
-    model, tasks, q, dq, goals, tau_ref, opts = load_golden(path)
+    model, tasks, q, dq, goals, tau_ref, opts, st_ref = load_golden(path)
     tau, status = Oracle(model, tasks, **opts).step(q, dq, goals)
-    assert status.sum() == 0
+    assert np.array_equal(status, st_ref) and (status != 1).all()   # 2 = task reduced to its non-singular subspace (config 12)
     assert W.torque_error(tau, tau_ref) < 1e-9
 
 
 def test_golden_inputs_reproducible():
     """the committed inputs are exactly what the seeded generator produces today"""
-    model, tasks, q, dq, goals, _, _ = load_golden([p for p in GOLDEN if "cfg2_mf_joint" in p][0])
+    model, tasks, q, dq, goals, _, _, _ = load_golden([p for p in GOLDEN if "cfg2_mf_joint" in p][0])
     d = W.make_inputs(2, q.shape[0])
     assert np.array_equal(d["q"], q) and np.array_equal(d["dq"], dq)
     for a, b in zip(d["goals"], goals):

@@ -285,7 +285,8 @@ def motion_force_task(name, link, pos_in_link=(0, 0, 0), rot_in_link=None, dirs_
              # MotionForceTask.h:50-66: force/moment gains (only kv acts in open loop), velocity saturation, force spaces
              kv_force=10.0, kv_moment=10.0, vel_sat=False, lin_sat=0.3, ang_sat=np.pi / 3,
              force_dim=0, force_axis=[0.0, 0.0, 1.0], moment_dim=0, moment_axis=[0.0, 0.0, 1.0],
-             param_in_compliant_frame=False)
+             param_in_compliant_frame=False,
+             singularity_handling=True)   # SingularityHandler::_enforce_handling_strategy, SingularityHandler.cpp:61
     t.update(kw)
     return t
 
@@ -457,7 +458,7 @@ class Singular(Exception):
 
 
 def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_comp=False,
-                           torque_saturation=False, joint_limit_avoidance=False, details=None):
+                           torque_saturation=False, joint_limit_avoidance=False, details=None, info=None):
     """One control cycle for ONE instance, literal reference path (SVDs, explicit inverses).
     goals[t]: flat vector (goal_size).  Returns tau (n,).  Raises Singular when an instance
     leaves the non-singular branch of SingularityHandler (alpha != 1)."""
@@ -481,14 +482,28 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             J = P @ Jw                                              # MotionForceTask.cpp:261-263
             Jp = J @ N_prec                                         # :264
             U, s, Vt = np.linalg.svd(Jp, full_matrices=False)       # SingularityHandler.cpp:78-81
-            if s[0] < 1e-3:
-                raise Singular("fully singular")
+            handling = t.get("singularity_handling", True)           # _enforce_handling_strategy, :61
             if k == 1:
                 raise Singular("rank-1 motion force task unsupported (SURVEY App. C-4)")
-            for i in range(1, k):
-                if s[i] / s[0] < t["s_max"]:
-                    raise Singular("blending region")               # :100-121
-            U_ns = U[:, :k]                                          # :128
+            ns = k
+            if s[0] < 1e-3:
+                if handling:
+                    raise Singular("fully singular")
+                ns = 0                                               # :83-98 + :316-317: the task is passed through
+            else:
+                for i in range(1, k):
+                    if s[i] / s[0] < t["s_max"]:
+                        if handling:
+                            raise Singular("blending region")       # :100-121: needs the blended strategies
+                        ns = i                                       # handling disabled: _N = _N_ns, tau = tau_ns (:146-148, 319-330)
+                        break
+            if ns < k and info is not None:
+                info["truncated"] = True                             # reported as status 2
+            if ns == 0:
+                tm.append(dict(skip=True, N=np.eye(n), N_prec=N_prec, J=J, P=P, R=R_l @ np.asarray(t["rot_in_link"]), x=p, sv=s))
+                continue
+            k = ns
+            U_ns = U[:, :k]                                          # :128 / :108
             J_ns = U_ns.T @ Jp
             Lam, Jbar, N = op_space_matrices(J_ns, Minv)             # :130-134
             if t["decoupling"] == FULL_DYNAMIC_DECOUPLING:
@@ -569,7 +584,10 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
                 st["int_pos"], st["int_ori"] = ipos, iori
             F_um = np.concatenate([F_p, F_o])                        # :475-478
             F_f = np.concatenate([F_force + sig_f @ goal_force, F_moment + sig_m @ goal_moment])   # :471-487 (open loop: no kff)
-            tt = m["J_ns"].T @ (m["Lam_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)  # SH.cpp:307-309
+            if m.get("skip"):
+                tt = np.zeros(n)
+            else:
+                tt = m["J_ns"].T @ (m["Lam_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)  # SH.cpp:307-309
             # computeTorques(tau_prec): _Lambda is never written => compensation == 0 (App. C-1)
             tau = tau + tt
             if details is not None:
@@ -620,7 +638,10 @@ def controller_step(model, tasks, q, dq, goals, **kw):
     status = np.zeros(B, np.uint8)
     for b in range(B):
         try:
-            tau[b] = controller_step_single(model, tasks, q[b], dq[b], [g[b] for g in goals], **kw)
+            info = {}
+            tau[b] = controller_step_single(model, tasks, q[b], dq[b], [g[b] for g in goals], info=info, **kw)
+            if info.get("truncated"):
+                status[b] = 2   # singularity handling disabled: a task was reduced to its non-singular subspace
         except Singular:
             status[b] = 1
     return tau, status
@@ -655,6 +676,8 @@ CONFIGS = {
     10: dict(robot="panda_arm", batch=256, desc="Panda, full force space (dim 3) + motion-only rotation, world-frame parametrisation, joint velocity saturation"),
     11: dict(robot="panda_arm", batch=256, desc="config-2 tasks with joint states pushed into the joint-limit-avoidance zones (q within 2% of the limits, "
              "|dq| up to the velocity limit): exercises RobotController's JLA wrap + torque saturation"),
+    12: dict(robot="panda_arm", batch=256, desc="config-2 tasks with disableSingularityHandling(); every third instance has the elbow nearly straight "
+             "(inside SingularityHandler's blending region): the motion-force task is reduced to its non-singular subspace"),
 }
 
 
@@ -663,6 +686,9 @@ def config_tasks(cfg: int):
         return [joint_task("joint_task", kp=100.0, kv=20.0)]          # examples/01-joint_control:133
     if cfg in (2, 4, 11):
         return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07)),  # examples/05:111-117
+                joint_task("joint_task")]
+    if cfg == 12:
+        return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07), singularity_handling=False),  # MotionForceTask.h:723
                 joint_task("joint_task")]
     if cfg == 3:
         return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07),
@@ -760,6 +786,10 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
             q = np.where(bad[:, None], qn, q)
         else:
             raise RuntimeError("rejection sampling did not converge")
+    if cfg == 12:
+        near = (np.arange(B) % 3) == 0
+        q4 = -0.07 - 0.28 * rng.uniform_range(0.0, 1.0, 1)[:, 0]     # elbow in [-0.35, -0.07] rad: sigma_5 / sigma_0 below s_max = 0.06
+        q[:, 3] = np.where(near, q4, q[:, 3])
     dq = rng.uniform_range(-0.5, 0.5, n)
     if cfg == 11:
         dq = dq * 2.0 * model.vel_limit[None]    # up to +-vel_limit: velocity zones get entered
