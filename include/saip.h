@@ -107,7 +107,7 @@ int saip_batch_task_type(const saip_batch* batch, int task_id);   /* TemplateTas
 const char* saip_batch_task_name(const saip_batch* batch, int task_id); /* TemplateTask::getTaskName / getTaskNames */
 int saip_batch_task_by_name(const saip_batch* batch, const char* name); /* get{Joint,MotionForce}TaskByName; -1 when absent */
 int saip_batch_task_dof(const saip_batch* batch, int task_id);    /* JointTask::getTaskDof (rows of S); 6-dof projector rank for motion-force */
-int saip_batch_goal_components(const saip_batch* batch, int task_id); /* 30 (x3,R9 row-major,v3,w3,a3,alpha3,goal force 3,goal moment 3) or 3*m (q,dq,ddq) */
+int saip_batch_goal_components(const saip_batch* batch, int task_id); /* 36 (x3,R9 row-major,v3,w3,a3,alpha3,goal force 3,goal moment 3,sensed force 3,sensed moment 3) or 3*m (q,dq,ddq) */
 /* MotionForceTask partial task projection P (6x6 row-major, MotionForceTask.cpp:55-87) and the orthonormal basis of
  * range(P) the engine works in (6x6 row-major, first *rank columns valid; = _current_task_range, :162-168) */
 saip_status saip_batch_get_task_projection(const saip_batch* batch, int task_id, double* P36, double* basis36, int* rank);
@@ -188,9 +188,22 @@ saip_status saip_batch_set_parametrization_in_compliant_frame(saip_batch*, int t
 /* MotionForceTask::setForceControlGains / setMomentControlGains: open-loop force control uses kv only (MotionForceTask.cpp:350-354, :379-383) */
 saip_status saip_batch_set_force_control_gains(saip_batch*, int task, double kp, double kv, double ki);
 saip_status saip_batch_set_moment_control_gains(saip_batch*, int task, double kp, double kv, double ki);
-/* setClosedLoopForceControl / setClosedLoopMomentControl: enabled -> SAIP_ERR_UNSUPPORTED (needs sensed forces + POPC, out of scope) */
+/* setClosedLoopForceControl / setClosedLoopMomentControl (MotionForceTask.cpp:973-986; law :327-349, :357-378, :484-487): PI feedback
+ * on the sensed force / moment inside the force / moment space, saturated at the maximum feedback output, goal force feed-forward
+ * scaled by kff.  The sensed force and moment of the current cycle are rows 30..32 / 33..35 of the task's goal block, in the SENSOR
+ * frame (updateSensedForceAndMoment, :805-828: the engine applies _T_control_to_sensor and the control frame's world rotation of the
+ * current state).  A change of either flag resets the linear / angular integrators like the reference.  The passivity observer /
+ * controller around the force loop (POPCExplicitForceControl) is off by default in the reference and not on the device:
+ * saip_batch_set_passivity(…, 1) returns SAIP_ERR_UNSUPPORTED. */
 saip_status saip_batch_set_closed_loop_force_control(saip_batch*, int task, int enabled);
 saip_status saip_batch_set_closed_loop_moment_control(saip_batch*, int task, int enabled);
+saip_status saip_batch_set_passivity(saip_batch*, int task, int enabled);
+/* setFeedforwardForceGain / setFeedforwardMomentGain / setMaxForceControlFeedbackOutput / setMaxMomentControlFeedbackOutput
+ * (MotionForceTask.h:330-355); defaults 0.95, 0.95, 20 N, 10 Nm (.h:56-59) */
+saip_status saip_batch_set_force_control_parameters(saip_batch*, int task, double kff_force, double kff_moment, double max_force_feedback, double max_moment_feedback);
+/* setForceSensorFrame (MotionForceTask.cpp:794-803) given as _T_control_to_sensor = compliant_frame^-1 * T_link_sensor:
+ * rotation 3x3 row-major and translation; default identity (:94) */
+saip_status saip_batch_set_control_to_sensor_transform(saip_batch*, int task, const double* R_row_major, const double* translation);
 /* RobotController::enable{GravityCompensation,JointLimitAvoidance,TorqueSaturation}, RobotController.h:64-75 */
 saip_status saip_batch_enable_gravity_compensation(saip_batch*, int enabled);
 saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* JLA wrap, RobotController.cpp:96-112 */

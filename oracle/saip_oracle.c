@@ -59,6 +59,10 @@ typedef struct {
 	int sing_handling;     /* SingularityHandler::_enforce_handling_strategy (default true, SingularityHandler.cpp:61) */
 	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
+	/* closed-loop force / moment control, MotionForceTask.h:50-60 */
+	int cl_force, cl_moment;
+	double kp_force, ki_force, kp_moment, ki_moment, kff_force, kff_moment, max_force_fb, max_moment_fb;
+	double Rcs[9], tcs[3]; /* _T_control_to_sensor */
 	double force_axis[3], moment_axis[3];
 	/* joint */
 	int m;
@@ -535,12 +539,53 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 		mat3v(rot, goal + 24, goal_force);
 		mat3v(rot, goal + 27, goal_moment);
 	}
-	/* open-loop force / moment terms :350-354, :379-383 */
 	double F_f[6];
-	for (int i = 0; i < 3; i++) tmp[i] = -t->kv_force * v[i];
-	mat3v(sig_f, tmp, F_f);
-	for (int i = 0; i < 3; i++) tmp[i] = -t->kv_moment * w[i];
-	mat3v(sig_m, tmp, F_f + 3);
+	double f_sw[3] = {0, 0, 0}, m_sw[3] = {0, 0, 0};
+	if (t->cl_force || t->cl_moment) { /* updateSensedForceAndMoment :805-828 */
+		double f_c[3], m_c[3], x[3];
+		mat3v(t->Rcs, goal + 30, f_c);
+		mat3v(t->Rcs, goal + 33, m_c);
+		cross3(t->tcs, f_c, x);
+		for (int i = 0; i < 3; i++) m_c[i] += x[i];
+		mat3v(Rc, f_c, f_sw);
+		mat3v(Rc, m_c, m_sw);
+	}
+	if (t->cl_force) { /* :327-349; POPC disabled (POPCExplicitForceControl.cpp:31-33): vcl - kv_force * vr */
+		double d[3], sd[3], fb[3], u[3], nrm = 0;
+		for (int i = 0; i < 3; i++) d[i] = f_sw[i] - goal_force[i];
+		mat3v(sig_f, d, sd);
+		for (int i = 0; i < 3; i++) integ[6 + i] += sd[i] * t->dt;
+		for (int i = 0; i < 3; i++) u[i] = -t->kp_force * d[i] - t->ki_force * integ[6 + i];
+		mat3v(sig_f, u, fb);
+		for (int i = 0; i < 3; i++) nrm += fb[i] * fb[i];
+		nrm = sqrt(nrm);
+		if (nrm > t->max_force_fb)
+			for (int i = 0; i < 3; i++) fb[i] *= t->max_force_fb / nrm;
+		double vcl[3], vr[3];
+		mat3v(sig_f, fb, vcl);
+		mat3v(sig_f, v, vr);
+		for (int i = 0; i < 3; i++) F_f[i] = vcl[i] - t->kv_force * vr[i];
+	} else { /* open loop :350-354 */
+		for (int i = 0; i < 3; i++) tmp[i] = -t->kv_force * v[i];
+		mat3v(sig_f, tmp, F_f);
+	}
+	if (t->cl_moment) { /* :357-378 */
+		double d[3], sd[3], fb[3], u[3], nrm = 0;
+		for (int i = 0; i < 3; i++) d[i] = m_sw[i] - goal_moment[i];
+		mat3v(sig_m, d, sd);
+		for (int i = 0; i < 3; i++) integ[9 + i] += sd[i] * t->dt;
+		for (int i = 0; i < 3; i++) u[i] = -t->kp_moment * d[i] - t->ki_moment * integ[9 + i];
+		mat3v(sig_m, u, fb);
+		for (int i = 0; i < 3; i++) nrm += fb[i] * fb[i];
+		nrm = sqrt(nrm);
+		if (nrm > t->max_moment_fb)
+			for (int i = 0; i < 3; i++) fb[i] *= t->max_moment_fb / nrm;
+		for (int i = 0; i < 3; i++) tmp[i] = fb[i] - t->kv_moment * w[i];
+		mat3v(sig_m, tmp, F_f + 3);
+	} else { /* open loop :379-383 */
+		for (int i = 0; i < 3; i++) tmp[i] = -t->kv_moment * w[i];
+		mat3v(sig_m, tmp, F_f + 3);
+	}
 	for (int i = 0; i < 3; i++) e[i] = p[i] - xd[i];
 	mat3v(sig_p, e, tmp);
 	for (int i = 0; i < 3; i++) integ[i] += tmp[i] * t->dt;   /* :411-413 */
@@ -579,11 +624,11 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 		for (int i = 0; i < 3; i++) tmp[i] = ald[i] - t->kp_ori[i] * dphi[i] - t->kv_ori[i] * (w[i] - wd[i]) - t->ki_ori[i] * integ[3 + i];
 	}
 	mat3v(sig_o, tmp, F_um + 3);                               /* :463-468 */
-	/* force_moment_contribution + feedforward (open loop: no kff scaling) :471-487 */
+	/* force_moment_contribution + feedforward :471-487; both parts are scaled by kff when closed-loop FORCE control is on (:484-487) */
 	mat3v(sig_f, goal_force, tmp);
-	for (int i = 0; i < 3; i++) F_f[i] += tmp[i];
+	for (int i = 0; i < 3; i++) F_f[i] += (t->cl_force ? t->kff_force : 1.0) * tmp[i];
 	mat3v(sig_m, goal_moment, tmp);
-	for (int i = 0; i < 3; i++) F_f[3 + i] += tmp[i];
+	for (int i = 0; i < 3; i++) F_f[3 + i] += (t->cl_force ? t->kff_moment : 1.0) * tmp[i];
 	/* SingularityHandler::computeTorques, :307-309 (and :316-330 with the handling strategy disabled) */
 	if (tm->skip) { /* fully singular task passed through: the integrators above still advanced, the torque is zero */
 		for (int i = 0; i < n; i++) tau[i] = 0;
@@ -1048,7 +1093,7 @@ int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
 }
 int orc_goal_size(const orc_ctx* c, int task) {
 	const orc_task* t = &c->task[task];
-	if (t->type == TASK_MOTION_FORCE) return (t->force_dim || t->moment_dim) ? 30 : 24;
+	if (t->type == TASK_MOTION_FORCE) return (t->cl_force || t->cl_moment) ? 36 : ((t->force_dim || t->moment_dim) ? 30 : 24);
 	return 3 * t->m;
 }
 void orc_set_mf_force_spaces(orc_ctx* c, int task, int force_dim, const double* force_axis, int moment_dim, const double* moment_axis,
@@ -1057,6 +1102,15 @@ void orc_set_mf_force_spaces(orc_ctx* c, int task, int force_dim, const double* 
 	t->force_dim = force_dim; t->moment_dim = moment_dim; t->param_in_compliant_frame = param_in_compliant_frame;
 	t->kv_force = kv_force; t->kv_moment = kv_moment;
 	for (int i = 0; i < 3; i++) { t->force_axis[i] = force_axis[i]; t->moment_axis[i] = moment_axis[i]; }
+}
+/* setClosedLoopForceControl / MomentControl, setForceControlGains, setFeedforward*Gain, setMax*ControlFeedbackOutput, setForceSensorFrame */
+void orc_set_closed_loop_force_control(orc_ctx* c, int task, int cl_force, int cl_moment, const double* gains8, const double* Rcs, const double* tcs) {
+	orc_task* t = &c->task[task];
+	t->cl_force = cl_force; t->cl_moment = cl_moment;
+	t->kp_force = gains8[0]; t->ki_force = gains8[1]; t->kp_moment = gains8[2]; t->ki_moment = gains8[3];
+	t->kff_force = gains8[4]; t->kff_moment = gains8[5]; t->max_force_fb = gains8[6]; t->max_moment_fb = gains8[7];
+	for (int i = 0; i < 9; i++) t->Rcs[i] = Rcs[i];
+	for (int i = 0; i < 3; i++) t->tcs[i] = tcs[i];
 }
 void orc_set_velocity_saturation(orc_ctx* c, int task, int enabled, double lin_sat, double ang_sat, const double* joint_sat) {
 	orc_task* t = &c->task[task];

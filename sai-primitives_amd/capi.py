@@ -105,6 +105,9 @@ def lib():
         "saip_batch_set_moment_control_gains": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_double]),
         "saip_batch_set_closed_loop_force_control": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_closed_loop_moment_control": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_passivity": (C.c_int, [vp, C.c_int, C.c_int]),
+        "saip_batch_set_force_control_parameters": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+        "saip_batch_set_control_to_sensor_transform": (C.c_int, [vp, C.c_int, dp, dp]),
         "saip_batch_enable_gravity_compensation": (C.c_int, [vp, C.c_int]),
         "saip_batch_enable_joint_limit_avoidance": (C.c_int, [vp, C.c_int]),
         "saip_batch_enable_torque_saturation": (C.c_int, [vp, C.c_int]),

@@ -338,6 +338,26 @@ class MotionForceTask(_Task):
     def setClosedLoopMomentControl(self, enabled: bool):
         self._cfg("saip_batch_set_closed_loop_moment_control", int(enabled))
 
+    def enablePassivity(self):  # MotionForceTask.h:630: the POPC passivity controller is not on the device
+        self._cfg("saip_batch_set_passivity", 1)
+
+    def disablePassivity(self):
+        self._cfg("saip_batch_set_passivity", 0)
+
+    def updateSensedForceAndMoment(self, sensed_force_sensor_frame, sensed_moment_sensor_frame):  # MotionForceTask.cpp:805-828
+        self._set_field(30, 3, sensed_force_sensor_frame, "updateSensedForceAndMoment (force)")
+        self._set_field(33, 3, sensed_moment_sensor_frame, "updateSensedForceAndMoment (moment)")
+
+    def setForceControlParameters(self, kff_force=0.95, kff_moment=0.95, max_force_feedback=20.0, max_moment_feedback=10.0):
+        """setFeedforwardForceGain / MomentGain, setMaxForceControlFeedbackOutput / Moment (MotionForceTask.h:330-355)"""
+        self._cfg("saip_batch_set_force_control_parameters", float(kff_force), float(kff_moment), float(max_force_feedback), float(max_moment_feedback))
+
+    def setControlToSensorTransform(self, R, p):
+        """_T_control_to_sensor of setForceSensorFrame (MotionForceTask.cpp:802): rotation (3,3) and translation (3,)"""
+        R, p = np.ascontiguousarray(np.asarray(R, float).reshape(9)), np.ascontiguousarray(np.asarray(p, float).reshape(3))
+        self._keepalive.append((R, p))
+        self._cfg("saip_batch_set_control_to_sensor_transform", _dptr(R), _dptr(p))
+
     def getGoalPosition(self):
         return self._get_goal()[:, 0:3]
 
@@ -571,8 +591,8 @@ class RobotController:
         for t, g in zip(self._tasks, goals):
             gs = capi.lib().saip_batch_goal_components(self._h, t._id)
             g = np.asarray(g, float)
-            if gs == 30 and g.ndim == 2 and g.shape[1] == 24:  # no goal force / moment given: zeros
-                g = np.concatenate([g, np.zeros((g.shape[0], 6))], axis=1)
+            if g.ndim == 2 and g.shape[1] in (24, 30) and gs > g.shape[1]:  # no goal / sensed force and moment given: zeros
+                g = np.concatenate([g, np.zeros((g.shape[0], gs - g.shape[1]))], axis=1)
             a = _soa(g, self.batch_size, gs, f"goal of task {t.getTaskName()}")
             capi.check(capi.lib().saip_batch_set_goal_host(self._h, t._id, _dptr(a)))
 
@@ -654,8 +674,13 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
             o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
             if not t.get("singularity_handling", True):
                 o.disableSingularityHandling()
-            o.setForceControlGains(0.7, t.get("kv_force", 10.0), 1.3)
-            o.setMomentControlGains(0.7, t.get("kv_moment", 10.0), 1.3)
+            if t.get("cl_force") or t.get("cl_moment"):
+                o.setForceControlParameters(t.get("kff_force", 0.95), t.get("kff_moment", 0.95), t.get("max_force_fb", 20.0), t.get("max_moment_fb", 10.0))
+                o.setControlToSensorTransform(t.get("Rcs", np.eye(3)), t.get("tcs", np.zeros(3)))
+                o.setClosedLoopForceControl(bool(t.get("cl_force")))
+                o.setClosedLoopMomentControl(bool(t.get("cl_moment")))
+            o.setForceControlGains(t.get("kp_force", 0.7), t.get("kv_force", 10.0), t.get("ki_force", 1.3))
+            o.setMomentControlGains(t.get("kp_moment", 0.7), t.get("kv_moment", 10.0), t.get("ki_moment", 1.3))
             if t.get("force_dim", 0):
                 o.parametrizeForceMotionSpaces(t["force_dim"], t.get("force_axis"))
             if t.get("moment_dim", 0):

@@ -65,6 +65,10 @@ struct TaskDev {
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame, pad1_[3];
 	double lin_sat, ang_sat, kv_force, kv_moment;
 	double force_axis[3], moment_axis[3];      // unit axes
+	// closed-loop force / moment control (MotionForceTask.cpp:327-349, 357-378, 484-487), passivity controller off (POPC default)
+	int cl_force, cl_moment, pad2_[2];
+	double kp_force, ki_force, kp_moment, ki_moment, kff_force, kff_moment, max_force_fb, max_moment_fb;
+	double Rcs[9], tcs[3];                     // _T_control_to_sensor (MotionForceTask.cpp:94, 802)
 	double kvinv_pos[3], kvinv_ori[3];         // pseudo-inverse of the diagonal kv gains (computePseudoInverse)
 	double kvinv[SAIP_MAXN], sat[SAIP_MAXN];   // joint task
 	double S[SAIP_MAXN * SAIP_MAXN]; // m x n row-major

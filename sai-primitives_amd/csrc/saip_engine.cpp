@@ -452,7 +452,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	m3_T(T.dev.Pori, PT);
 	m3_mul(T.dev.Pori, PT, T.dev.sig_o);
 	T.dev.k = pr + orr;
-	T.dev.goal_comps = 30;  // x3 R9 v3 w3 a3 alpha3 + goal force 3 + goal moment 3
+	T.dev.goal_comps = 36;  // x3 R9 v3 w3 a3 alpha3 + goal force 3 + goal moment 3 + sensed force 3 + sensed moment 3 (sensor frame)
 	T.dev.kv_force = 10.0;   // MotionForceTask.h:51,54
 	T.dev.kv_moment = 10.0;
 	T.dev.lin_sat = 0.3;     // :63-64
@@ -468,7 +468,13 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_max = 6e-2;
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
 	T.dev.sing_handling = 1; // _enforce_handling_strategy = true, SingularityHandler.cpp:61
-	T.integ_rows = 6;
+	T.integ_rows = 12;  // position 3, orientation 3, force 3, moment 3
+	T.dev.kp_force = T.dev.kp_moment = 0.7;  // MotionForceTask.h:50-59
+	T.dev.ki_force = T.dev.ki_moment = 1.3;
+	T.dev.kff_force = T.dev.kff_moment = 0.95;
+	T.dev.max_force_fb = 20.0;
+	T.dev.max_moment_fb = 10.0;
+	T.dev.Rcs[0] = T.dev.Rcs[4] = T.dev.Rcs[8] = 1.0;  // _T_control_to_sensor = identity, MotionForceTask.cpp:94
 	refresh_has_ki(T.dev);
 	memset(&T.otg, 0, sizeof(T.otg));
 	T.otg.m = 6;
@@ -658,7 +664,7 @@ static void refresh_has_ki(TaskDev& d) {
 		d.kvinv_ori[c] = fabs(d.kv_ori[c]) > 1e-6 ? 1.0 / d.kv_ori[c] : 0.0;
 	}
 	for (int c = 0; c < d.m; c++) d.kvinv[c] = fabs(d.kv[c]) > 1e-6 ? 1.0 / d.kv[c] : 0.0;
-	d.general_law = (d.vel_sat || d.force_dim || d.moment_dim) ? 1 : 0;
+	d.general_law = (d.vel_sat || d.force_dim || d.moment_dim || d.cl_force || d.cl_moment) ? 1 : 0;
 	d.has_ki = 0;
 	if (d.type == saip::TASK_MOTION_FORCE) {
 		for (int c = 0; c < 3; c++)
@@ -875,7 +881,10 @@ static saip_status set_fm_gains(saip_batch* b, int t, double kp, double kv, doub
 	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, who);
 	if (st) return st;
 	if (kp < 0 || kv < 0 || ki < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "all gains should be positive or zero in %s", who);
-	(moment ? b->tasks[t].dev.kv_moment : b->tasks[t].dev.kv_force) = kv;  // kp, ki only act in closed-loop force control
+	TaskDev& d = b->tasks[t].dev;
+	(moment ? d.kv_moment : d.kv_force) = kv;
+	(moment ? d.kp_moment : d.kp_force) = kp;  // kp, ki only act in closed-loop control
+	(moment ? d.ki_moment : d.ki_force) = ki;
 	b->config_dirty = true;
 	return SAIP_OK;
 }
@@ -885,16 +894,58 @@ extern "C" saip_status saip_batch_set_force_control_gains(saip_batch* b, int t, 
 extern "C" saip_status saip_batch_set_moment_control_gains(saip_batch* b, int t, double kp, double kv, double ki) {
 	return set_fm_gains(b, t, kp, kv, ki, true, "MotionForceTask::setMomentControlGains");
 }
-extern "C" saip_status saip_batch_set_closed_loop_force_control(saip_batch* b, int t, int enabled) {
-	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_closed_loop_force_control");
+// setClosedLoopForceControl / setClosedLoopMomentControl (MotionForceTask.cpp:973-986): a change resets the linear / angular integrators
+static saip_status set_closed_loop(saip_batch* b, int t, int enabled, bool moment, const char* who) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, who);
 	if (st) return st;
-	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "closed-loop force control (sensed forces + POPC, MotionForceTask.cpp:327-349) is out of scope");
+	TaskDev& d = b->tasks[t].dev;
+	int& flag = moment ? d.cl_moment : d.cl_force;
+	const bool changed = (flag != 0) != (enabled != 0);
+	flag = enabled ? 1 : 0;
+	refresh_has_ki(d);
+	b->config_dirty = true;
+	if (changed && b->finalized && has_device(b)) {
+		// resetIntegratorsLinear / Angular: position + force (orientation + moment) integrators := 0
+		const int rows[2] = {moment ? 3 : 0, moment ? 9 : 6};
+		for (int r : rows) HIP_TRY(hipMemsetAsync(b->tasks[t].integ_dev + (size_t)r * b->ld, 0, (size_t)3 * b->ld * sizeof(double), b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+	}
 	return SAIP_OK;
 }
+extern "C" saip_status saip_batch_set_closed_loop_force_control(saip_batch* b, int t, int enabled) {
+	return set_closed_loop(b, t, enabled, false, "saip_batch_set_closed_loop_force_control");
+}
 extern "C" saip_status saip_batch_set_closed_loop_moment_control(saip_batch* b, int t, int enabled) {
-	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_closed_loop_moment_control");
+	return set_closed_loop(b, t, enabled, true, "saip_batch_set_closed_loop_moment_control");
+}
+// enablePassivity (MotionForceTask.h:630): the windowed passivity observer / controller of POPCExplicitForceControl is not on the device
+extern "C" saip_status saip_batch_set_passivity(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_passivity");
 	if (st) return st;
-	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "closed-loop moment control (MotionForceTask.cpp:356-378) is out of scope");
+	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "the passivity observer / controller (POPCExplicitForceControl.cpp:35-96) is not implemented on the device; closed-loop force control runs with it disabled (its default)");
+	return SAIP_OK;
+}
+// setFeedforwardForceGain / MomentGain, setMaxForceControlFeedbackOutput / Moment (MotionForceTask.h:330-355)
+extern "C" saip_status saip_batch_set_force_control_parameters(saip_batch* b, int t, double kff_force, double kff_moment, double max_force_feedback, double max_moment_feedback) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_force_control_parameters");
+	if (st) return st;
+	TaskDev& d = b->tasks[t].dev;
+	d.kff_force = kff_force;
+	d.kff_moment = kff_moment;
+	d.max_force_fb = max_force_feedback;
+	d.max_moment_fb = max_moment_feedback;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+// setForceSensorFrame (MotionForceTask.cpp:794-803), given directly as _T_control_to_sensor = compliant_frame^-1 * T_link_sensor
+extern "C" saip_status saip_batch_set_control_to_sensor_transform(saip_batch* b, int t, const double* R_row_major, const double* translation) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_control_to_sensor_transform");
+	if (st) return st;
+	if (!R_row_major || !translation) return fail(SAIP_ERR_INVALID_ARGUMENT, "null transform");
+	TaskDev& d = b->tasks[t].dev;
+	for (int i = 0; i < 9; i++) d.Rcs[i] = R_row_major[i];
+	for (int i = 0; i < 3; i++) d.tcs[i] = translation[i];
+	b->config_dirty = true;
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_enable_gravity_compensation(saip_batch* b, int e) {
@@ -1104,6 +1155,7 @@ static bool lane_eligible(const saip_batch* b) {
 	double thr = -1.0;
 	for (auto& T : b->tasks) {
 		if (T.dev.type == saip::TASK_MOTION_FORCE) nmf++;
+		if (T.dev.type == saip::TASK_MOTION_FORCE && (T.dev.cl_force || T.dev.cl_moment)) return false;  // closed-loop force control: general kernel
 		if (T.dev.decoupling == SAIP_BOUNDED_INERTIA_ESTIMATES) {
 			if (thr >= 0.0 && thr != T.dev.bie_threshold) return false;
 			thr = T.dev.bie_threshold;

@@ -468,7 +468,8 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 		if (GL) {
 			// velocity saturation and/or force & moment spaces (open-loop force control); reduces to the short law for the defaults
 			UNR for (int e = 24; e < 30; e++) G24[e] = tk->goal[(size_t)e * ld + b];
-			law_motion_force_general(tk, vw, xp, Rc, G24, ip, io, Fum, Ff);
+			// closed-loop force / moment control is left to the general kernel (lane_eligible in the engine)
+			law_motion_force_general<false>(tk, vw, xp, Rc, G24, ip, io, (double*)nullptr, Fum, Ff);
 		} else {
 			double v[3], w[3], e3[3], tmp[3];
 			UNR for (int i = 0; i < 3; i++) {

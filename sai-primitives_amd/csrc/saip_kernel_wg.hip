@@ -57,7 +57,7 @@ struct WgSmem {
 	double body[NMAX * 10], comp[NMAX * 10];  // spatial inertia about the world origin: m, h(3)=m*c, Io(6: xx yy zz xy xz yz)
 	double Jw[6 * LD];
 	double q[NMAX], dq[NMAX], tau[NMAX], v0[NMAX], v1[NMAX], v2[NMAX], v3[NMAX], v4[NMAX], dv[NMAX];
-	double goal[3 * NMAX > 30 ? 3 * NMAX : 30];
+	double goal[3 * NMAX > 36 ? 3 * NMAX : 36];
 	double vw[6], Fum[6], Ff[6], xp[3], Rc[9];
 	double cs[4 * (NMAX / 2 + 1)];
 	int colidx[NMAX];
@@ -612,7 +612,13 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 							io[i] = tk.integ[(size_t)(3 + i) * P.ld + b];
 						}
 					// general law (velocity saturation, force/moment spaces) reduces to MotionForceTask.cpp:411-468 for the defaults
-					law_motion_force_general(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, sm.Fum, sm.Ff);
+					double ifm[6] = {0, 0, 0, 0, 0, 0};
+					const bool closed = tk.cl_force || tk.cl_moment;
+					if (closed)
+						for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * P.ld + b];
+					law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff);
+					if (closed)
+						for (int i = 0; i < 6; i++) tk.integ[(size_t)(6 + i) * P.ld + b] = ifm[i];
 					if (track)
 						for (int i = 0; i < 3; i++) {
 							tk.integ[(size_t)i * P.ld + b] = ip[i];
@@ -825,6 +831,7 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 					tk.goal[(size_t)(12 + e) * P.ld + b] = 0.0;
 					tk.goal[(size_t)(18 + e) * P.ld + b] = 0.0;
 					tk.integ[(size_t)e * P.ld + b] = 0.0;
+					tk.integ[(size_t)(6 + e) * P.ld + b] = 0.0;  // force integrator (resetIntegratorsLinear)
 				}
 			}
 			if (mask & 2) {  // angular part
@@ -833,10 +840,11 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 					tk.goal[(size_t)(15 + e) * P.ld + b] = 0.0;
 					tk.goal[(size_t)(21 + e) * P.ld + b] = 0.0;
 					tk.integ[(size_t)(3 + e) * P.ld + b] = 0.0;
+					tk.integ[(size_t)(9 + e) * P.ld + b] = 0.0;  // moment integrator (resetIntegratorsAngular)
 				}
 			}
 			if (mask & 4)  // goal force / moment (reInitializeTask, MotionForceTask.cpp:232-237)
-				for (int e = 24; e < 30; e++) tk.goal[(size_t)e * P.ld + b] = 0.0;
+				for (int e = 24; e < 36; e++) tk.goal[(size_t)e * P.ld + b] = 0.0;  // goal and sensed force / moment
 		} else {
 			for (int i = 0; i < tk.m; i++) {
 				double cur = 0.0;

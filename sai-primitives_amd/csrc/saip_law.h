@@ -40,11 +40,14 @@ __device__ __forceinline__ void law_sigma_space(CP Pb, const int dim, CP axis, c
 }
 
 // General motion-force law.  tk: task constants (any address space); vw = Jw dq (unprojected world twist of the control point);
-// xp, Rc: control point / control frame; G: goal block (30: x3 R9 v3 w3 a3 alpha3 f3 m3); ip, io: integrators (in/out).
+// xp, Rc: control point / control frame; G: goal block (36: x3 R9 v3 w3 a3 alpha3 f3 m3 + sensed force 3, sensed moment 3 in the
+// sensor frame); ip, io: position / orientation integrators (in/out); ifm: force (0..2) and moment (3..5) integrators (in/out).
 // Outputs F_um (unit-mass force, acts through Lambda_mod) and F_f (force-related terms, act directly).
-template <typename TK>
+// CL = false compiles the closed-loop force / moment branch out (the lane kernel leaves such task stacks to the general kernel;
+// G then only needs 30 entries and ifm may be null).
+template <bool CL, typename TK>
 __device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw, const double* xp, const double* Rc, const double* G,
-														 double* ip, double* io, double* Fum, double* Ff) {
+														 double* ip, double* io, double* ifm, double* Fum, double* Ff) {
 	const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	const double* rot = tk->param_in_compliant_frame ? Rc : I3;
 	double sig_f[9], sig_m[9], sig_p[9], sig_o[9], T[9], ImS[9];
@@ -74,11 +77,74 @@ __device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw
 	}
 	law_mat3_vec(rot, G + 24, gf);  // getGoalForce / getGoalMoment (:755-769)
 	law_mat3_vec(rot, G + 27, gm);
-	// open-loop force / moment terms + feed-forward (:350-354, :379-383, :471-487; no kff scaling in open loop)
-	LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gf[i] - tk->kv_force * v[i];
-	law_mat3_vec(sig_f, tmp, Ff);
-	LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gm[i] - tk->kv_moment * w[i];
-	law_mat3_vec(sig_m, tmp, Ff + 3);
+	if (CL && (tk->cl_force || tk->cl_moment)) {
+		// updateSensedForceAndMoment (:805-828): sensor frame -> control frame -> world
+		double fc[3], mc[3], fsw[3], msw[3], t2[3], Rl[9];
+		LAW_UNR for (int i = 0; i < 9; i++) Rl[i] = tk->Rcs[i];
+		law_mat3_vec(Rl, G + 30, fc);
+		law_mat3_vec(Rl, G + 33, mc);
+		mc[0] += tk->tcs[1] * fc[2] - tk->tcs[2] * fc[1];
+		mc[1] += tk->tcs[2] * fc[0] - tk->tcs[0] * fc[2];
+		mc[2] += tk->tcs[0] * fc[1] - tk->tcs[1] * fc[0];
+		law_mat3_vec(Rc, fc, fsw);
+		law_mat3_vec(Rc, mc, msw);
+		const double kff_f = tk->cl_force ? tk->kff_force : 1.0, kff_m = tk->cl_force ? tk->kff_moment : 1.0;  // :484-487: both scaled by the FORCE flag
+		if (tk->cl_force) {  // :327-349 with the passivity controller disabled (POPCExplicitForceControl.cpp:31-33): vcl - kv vr
+			double d[3], sd[3], fb[3], nrm = 0.0;
+			LAW_UNR for (int i = 0; i < 3; i++) d[i] = fsw[i] - gf[i];
+			law_mat3_vec(sig_f, d, sd);
+			LAW_UNR for (int i = 0; i < 3; i++) ifm[i] += sd[i] * tk->dt;
+			LAW_UNR for (int i = 0; i < 3; i++) t2[i] = -tk->kp_force * d[i] - tk->ki_force * ifm[i];
+			law_mat3_vec(sig_f, t2, fb);
+			LAW_UNR for (int i = 0; i < 3; i++) nrm += fb[i] * fb[i];
+			nrm = sqrt(nrm);
+			if (nrm > tk->max_force_fb) {
+				const double sc = tk->max_force_fb / nrm;
+				LAW_UNR for (int i = 0; i < 3; i++) fb[i] *= sc;
+			}
+			double sfb[3], sv[3], sg[3];
+			law_mat3_vec(sig_f, fb, sfb);
+			law_mat3_vec(sig_f, v, sv);
+			law_mat3_vec(sig_f, gf, sg);
+			LAW_UNR for (int i = 0; i < 3; i++) Ff[i] = sfb[i] - tk->kv_force * sv[i] + kff_f * sg[i];
+		} else {
+			double sv[3], sg[3];
+			law_mat3_vec(sig_f, v, sv);
+			law_mat3_vec(sig_f, gf, sg);
+			LAW_UNR for (int i = 0; i < 3; i++) Ff[i] = -tk->kv_force * sv[i] + kff_f * sg[i];
+		}
+		if (tk->cl_moment) {  // :357-378
+			double d[3], sd[3], fb[3], nrm = 0.0;
+			LAW_UNR for (int i = 0; i < 3; i++) d[i] = msw[i] - gm[i];
+			law_mat3_vec(sig_m, d, sd);
+			LAW_UNR for (int i = 0; i < 3; i++) ifm[3 + i] += sd[i] * tk->dt;
+			LAW_UNR for (int i = 0; i < 3; i++) t2[i] = -tk->kp_moment * d[i] - tk->ki_moment * ifm[3 + i];
+			law_mat3_vec(sig_m, t2, fb);
+			LAW_UNR for (int i = 0; i < 3; i++) nrm += fb[i] * fb[i];
+			nrm = sqrt(nrm);
+			if (nrm > tk->max_moment_fb) {
+				const double sc = tk->max_moment_fb / nrm;
+				LAW_UNR for (int i = 0; i < 3; i++) fb[i] *= sc;
+			}
+			double sg[3];
+			LAW_UNR for (int i = 0; i < 3; i++) t2[i] = fb[i] - tk->kv_moment * w[i];
+			law_mat3_vec(sig_m, t2, Ff + 3);
+			law_mat3_vec(sig_m, gm, sg);
+			LAW_UNR for (int i = 0; i < 3; i++) Ff[3 + i] += kff_m * sg[i];
+		} else {
+			double sg[3];
+			LAW_UNR for (int i = 0; i < 3; i++) t2[i] = -tk->kv_moment * w[i];
+			law_mat3_vec(sig_m, t2, Ff + 3);
+			law_mat3_vec(sig_m, gm, sg);
+			LAW_UNR for (int i = 0; i < 3; i++) Ff[3 + i] += kff_m * sg[i];
+		}
+	} else {
+		// open-loop force / moment terms + feed-forward (:350-354, :379-383, :471-487; no kff scaling in open loop)
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gf[i] - tk->kv_force * v[i];
+		law_mat3_vec(sig_f, tmp, Ff);
+		LAW_UNR for (int i = 0; i < 3; i++) tmp[i] = gm[i] - tk->kv_moment * w[i];
+		law_mat3_vec(sig_m, tmp, Ff + 3);
+	}
 	// linear motion (:411-437)
 	double se[3];
 	LAW_UNR for (int i = 0; i < 3; i++) e3[i] = xp[i] - G[i];

@@ -1053,7 +1053,8 @@ __global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B,
 		}
 		D[(size_t)(3 + dof) * ld + inst] = Rd.m[dof];  // eight lanes, entries 0..7
 		if (dof == 0) D[(size_t)11 * ld + inst] = Rd.m[8];
-		if (O.goal_comps == 30 && dof < 6) D[(size_t)(24 + dof) * ld + inst] = O.goal[(size_t)(24 + dof) * ld + inst];  // goal force / moment pass through
+		if (dof < 6)  // goal force / moment and sensed force / moment pass through
+			for (int e = 24 + dof; e < O.goal_comps; e += 6) D[(size_t)e * ld + inst] = O.goal[(size_t)e * ld + inst];
 		if (dof == 0) {
 #pragma unroll
 			for (int e = 0; e < 9; e++) {

@@ -30,6 +30,7 @@ SCENARIOS = {
     "cfg11_joint_limit_avoidance": (11, 48, dict(joint_limit_avoidance=True, torque_saturation=True)),
     "cfg11_jla_gravity": (11, 32, dict(joint_limit_avoidance=True, gravity_comp=True)),
     "cfg12_handling_disabled_truncated": (12, 48, {}),
+    "cfg13_closed_loop_force": (13, 32, {}),
 }
 
 

@@ -102,8 +102,12 @@ def test_task_constructor_validation(sp):
     with pytest.raises(ValueError, match="non singular vector"):
         t.parametrizeMomentRotMotionSpaces(1, [0, 0, 1e-3])
     assert t.parametrizeForceMotionSpaces(2, [1, 0, 0]) is True and t.parametrizeForceMotionSpaces(2, [3, 0, 0]) is False
-    with pytest.raises(sp.SaipUnsupported, match="closed-loop"):
-        t.setClosedLoopForceControl(True)
+    t.setClosedLoopForceControl(True)           # implemented (passivity controller off, its default)
+    t.setClosedLoopMomentControl(True)
+    t.setForceControlParameters(0.9, 0.8, 15.0, 5.0)
+    with pytest.raises(sp.SaipUnsupported, match="passivity"):
+        t.enablePassivity()
+    t.disablePassivity()
     r2 = _cfg_only(sp)
     j2 = sp.JointTask(r2)
     sp.RobotController(r2, [j2])

@@ -169,6 +169,47 @@ def test_singularity_handling_disabled_full_size():
     assert np.array_equal(ctrl.status == 1, st == 2) and np.isnan(tau[st == 2]).all() and np.isfinite(tau[st == 0]).all()
 
 
+def test_closed_loop_force_control_over_cycles():
+    """setClosedLoopForceControl / MomentControl (MotionForceTask.cpp:327-349, 357-378, 484-487): sensed force / moment from a rotated,
+    offset sensor, PI feedback with saturation, feed-forward gains; the force / moment integrators advance over cycles with changing
+    sensor readings.  Both kernels against the oracle; toggling the flag resets the integrators (:973-986); passivity is refused."""
+    import sai_primitives_amd as sp
+    from oracle import Oracle
+    B = 512
+    d = W.make_inputs(13, B)
+    rng = np.random.default_rng(9)
+    for kernel in (0, 1):
+        orc = Oracle(d["model"], d["tasks"])
+        robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], B)
+        ctrl.setKernel(kernel)
+        goals = [g.copy() for g in d["goals"]]
+        robot.setQ(d["q"])
+        robot.setDq(d["dq"])
+        robot.updateModel()
+        ctrl.updateControllerTaskModels()
+        ctrl.setGoals(goals)
+        for k in range(4):
+            fs, ms = rng.uniform(-8, 8, (B, 3)), rng.uniform(-1.5, 1.5, (B, 3))
+            goals[0][:, 30:33], goals[0][:, 33:36] = fs, ms
+            tasks[0].updateSensedForceAndMoment(fs, ms)
+            tau = ctrl.computeControlTorques()
+            ref, st = orc.step(d["q"], d["dq"], goals, nthreads=8)
+            assert st.sum() == 0 and ctrl.status.sum() == 0
+            err = W.torque_error(tau, ref)
+            print("closed-loop force control, kernel", ctrl.kernelName(), "cycle", k, "err", err)
+            assert err < TOL
+        # toggling closed-loop force control resets the linear integrators: the next cycle equals a fresh oracle's first cycle
+        tasks[0].setClosedLoopForceControl(False)
+        tasks[0].setClosedLoopForceControl(True)
+        tasks[0].setClosedLoopMomentControl(False)
+        tasks[0].setClosedLoopMomentControl(True)
+        tau = ctrl.computeControlTorques()
+        ref, _ = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], goals, nthreads=8)
+        assert W.torque_error(tau, ref) < TOL
+        with pytest.raises(sp.SaipUnsupported):
+            tasks[0].enablePassivity()
+
+
 def test_task_nullspaces_match_oracle():
     from oracle import Oracle
     d = W.make_inputs(3, 32)

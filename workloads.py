@@ -341,6 +341,8 @@ def joint_selection(task, n):
 def goal_size(task, n):
     if task["type"] == "motion_force":
         # x3, R9 (row-major), v3, w3, a3, alpha3 [, goal force 3, goal moment 3 when a force/moment space is active]
+        if task.get("cl_force") or task.get("cl_moment"):
+            return 36   # + sensed force 3, sensed moment 3 (sensor frame), MotionForceTask.cpp:805-828
         return 30 if (task.get("force_dim", 0) or task.get("moment_dim", 0)) else 24
     return 3 * joint_selection(task, n).shape[0]
 
@@ -557,8 +559,34 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             goal_moment = rot @ (g[27:30] if g.size >= 30 else np.zeros(3))
             kp, kv, ki = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_pos", "kv_pos", "ki_pos"))
             kpo, kvo, kio = (np.diag(np.broadcast_to(t[k_], 3)) for k_ in ("kp_ori", "kv_ori", "ki_ori"))
-            F_force = sig_f @ (-t["kv_force"] * v)                   # open loop, :350-354
-            F_moment = sig_m @ (-t["kv_moment"] * w)                 # :379-383
+            cl_f, cl_m = bool(t.get("cl_force")), bool(t.get("cl_moment"))
+            if cl_f or cl_m:                                         # updateSensedForceAndMoment, :805-828
+                Rcs, tcs = np.asarray(t.get("Rcs", np.eye(3)), float), np.asarray(t.get("tcs", np.zeros(3)), float)
+                f_c = Rcs @ g[30:33]
+                m_c = np.cross(tcs, f_c) + Rcs @ g[33:36]
+                f_sw, m_sw = Rcur @ f_c, Rcur @ m_c
+            ifo = np.zeros(3) if st is None else st.setdefault("int_force", np.zeros(3))
+            imo = np.zeros(3) if st is None else st.setdefault("int_moment", np.zeros(3))
+            if cl_f:                                                 # :327-349, passivity controller off (POPC...cpp:31-33)
+                ifo = ifo + sig_f @ (f_sw - goal_force) * t["dt"]
+                fb = sig_f @ (-t.get("kp_force", 0.7) * (f_sw - goal_force) - t.get("ki_force", 1.3) * ifo)
+                if np.linalg.norm(fb) > t.get("max_force_fb", 20.0):
+                    fb = fb * t.get("max_force_fb", 20.0) / np.linalg.norm(fb)
+                F_force = sig_f @ fb - t["kv_force"] * (sig_f @ v)
+            else:
+                F_force = sig_f @ (-t["kv_force"] * v)               # open loop, :350-354
+            if cl_m:                                                 # :357-378
+                imo = imo + sig_m @ (m_sw - goal_moment) * t["dt"]
+                fbm = sig_m @ (-t.get("kp_moment", 0.7) * (m_sw - goal_moment) - t.get("ki_moment", 1.3) * imo)
+                if np.linalg.norm(fbm) > t.get("max_moment_fb", 10.0):
+                    fbm = fbm * t.get("max_moment_fb", 10.0) / np.linalg.norm(fbm)
+                F_moment = sig_m @ (fbm - t["kv_moment"] * w)
+            else:
+                F_moment = sig_m @ (-t["kv_moment"] * w)             # :379-383
+            if st is not None:
+                st["int_force"], st["int_moment"] = ifo, imo
+            kff_f = t.get("kff_force", 0.95) if cl_f else 1.0        # :484-487: BOTH feed-forward terms are scaled by the FORCE flag
+            kff_m = t.get("kff_moment", 0.95) if cl_f else 1.0
             ipos = np.zeros(3) if st is None else st["int_pos"]
             iori = np.zeros(3) if st is None else st["int_ori"]
             ipos = ipos + sig_p @ (m["x"] - xd) * t["dt"]             # :411-413
@@ -583,7 +611,7 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             if st is not None:
                 st["int_pos"], st["int_ori"] = ipos, iori
             F_um = np.concatenate([F_p, F_o])                        # :475-478
-            F_f = np.concatenate([F_force + sig_f @ goal_force, F_moment + sig_m @ goal_moment])   # :471-487 (open loop: no kff)
+            F_f = np.concatenate([F_force + kff_f * (sig_f @ goal_force), F_moment + kff_m * (sig_m @ goal_moment)])   # :471-487
             if m.get("skip"):
                 tt = np.zeros(n)
             else:
@@ -676,6 +704,8 @@ CONFIGS = {
     10: dict(robot="panda_arm", batch=256, desc="Panda, full force space (dim 3) + motion-only rotation, world-frame parametrisation, joint velocity saturation"),
     11: dict(robot="panda_arm", batch=256, desc="config-2 tasks with joint states pushed into the joint-limit-avoidance zones (q within 2% of the limits, "
              "|dq| up to the velocity limit): exercises RobotController's JLA wrap + torque saturation"),
+    13: dict(robot="panda_arm", batch=256, desc="Panda, closed-loop force (1 axis) and moment (2 axes) control in the compliant frame with a rotated / offset "
+             "force sensor, PI feedback with saturation, feed-forward gains; full JointTask in the nullspace"),
     12: dict(robot="panda_arm", batch=256, desc="config-2 tasks with disableSingularityHandling(); every third instance has the elbow nearly straight "
              "(inside SingularityHandler's blending region): the motion-force task is reduced to its non-singular subspace"),
 }
@@ -721,6 +751,15 @@ def config_tasks(cfg: int):
     if cfg == 10:
         return [motion_force_task("force_task", "end-effector", (0, 0, 0.07), force_dim=3, moment_dim=0),
                 joint_task("joint_task", vel_sat=True, sat=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7])]
+    if cfg == 13:
+        c, s_ = np.cos(0.4), np.sin(0.4)
+        return [motion_force_task("contact_task", "end-effector", (0, 0, 0.07), force_dim=1, force_axis=[0.0, 0.0, 1.0],
+                                  moment_dim=2, moment_axis=[0.0, 0.0, 1.0], param_in_compliant_frame=True,
+                                  cl_force=True, cl_moment=True, kp_force=0.9, kv_force=12.0, ki_force=1.7,
+                                  kp_moment=0.6, kv_moment=8.0, ki_moment=1.1, kff_force=0.9, kff_moment=0.8,
+                                  max_force_fb=4.0, max_moment_fb=0.5,                      # low enough to saturate some instances
+                                  Rcs=[[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], tcs=[0.01, -0.02, 0.05]),
+                joint_task("joint_task")]
     raise ValueError(cfg)
 
 
@@ -808,8 +847,10 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
             ag = rng.uniform_range(-0.5, 0.5, 3)
             alg = rng.uniform_range(-0.5, 0.5, 3)
             blocks = [xg, Rg.reshape(B, 9), vg, wg, ag, alg]
-            if goal_size(t, n) == 30:
+            if goal_size(t, n) >= 30:
                 blocks += [rng.uniform_range(-5.0, 5.0, 3), rng.uniform_range(-1.0, 1.0, 3)]  # goal force, goal moment
+            if goal_size(t, n) == 36:
+                blocks += [rng.uniform_range(-8.0, 8.0, 3), rng.uniform_range(-1.5, 1.5, 3)]  # sensed force, sensed moment (sensor frame)
             goals.append(np.concatenate(blocks, axis=1))
         else:
             S = joint_selection(t, n)
