@@ -192,9 +192,11 @@ saip_status saip_batch_set_moment_control_gains(saip_batch*, int task, double kp
  * on the sensed force / moment inside the force / moment space, saturated at the maximum feedback output, goal force feed-forward
  * scaled by kff.  The sensed force and moment of the current cycle are rows 30..32 / 33..35 of the task's goal block, in the SENSOR
  * frame (updateSensedForceAndMoment, :805-828: the engine applies _T_control_to_sensor and the control frame's world rotation of the
- * current state).  A change of either flag resets the linear / angular integrators like the reference.  The passivity observer /
- * controller around the force loop (POPCExplicitForceControl) is off by default in the reference and not on the device:
- * saip_batch_set_passivity(…, 1) returns SAIP_ERR_UNSUPPORTED. */
+ * current state).  A change of either flag resets the linear / angular integrators like the reference.
+ * saip_batch_set_passivity = enablePassivity / disablePassivity (.h:630-631): the windowed passivity observer + passivity controller
+ * of POPCExplicitForceControl.cpp:29-96 around the force loop (off by default like in the reference; disabling re-initialises it).
+ * The reference's energy window is an unbounded std::queue; the device keeps 1024 samples per instance and sets status bit 2 (value
+ * 4) on an instance whose window would have grown beyond that (more than ~0.77 s of uninterrupted activity at 1 kHz). */
 saip_status saip_batch_set_closed_loop_force_control(saip_batch*, int task, int enabled);
 saip_status saip_batch_set_closed_loop_moment_control(saip_batch*, int task, int enabled);
 saip_status saip_batch_set_passivity(saip_batch*, int task, int enabled);

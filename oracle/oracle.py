@@ -43,6 +43,7 @@ def lib():
         L.orc_goal_size.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_mf_force_spaces.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double]
         L.orc_set_closed_loop_force_control.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, dp]
+        L.orc_set_passivity.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_set_velocity_saturation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, dp]
         L.orc_reset_state.argtypes = [C.c_void_p]
         L.orc_step_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(dp), dp, C.POINTER(C.c_ubyte), C.c_int]
@@ -108,6 +109,7 @@ class Oracle:
                 g8 = _d([t.get("kp_force", 0.7), t.get("ki_force", 1.3), t.get("kp_moment", 0.7), t.get("ki_moment", 1.3),
                          t.get("kff_force", 0.95), t.get("kff_moment", 0.95), t.get("max_force_fb", 20.0), t.get("max_moment_fb", 10.0)])
                 rcs, tcs = _d(np.asarray(t.get("Rcs", np.eye(3)), float).reshape(9)), _d(np.asarray(t.get("tcs", np.zeros(3)), float))
+                L.orc_set_passivity(self._h, tid, int(bool(t.get("passivity"))))
                 L.orc_set_closed_loop_force_control(self._h, tid, int(bool(t.get("cl_force"))), int(bool(t.get("cl_moment"))), g8[1], rcs[1], tcs[1])
             else:
                 import workloads as W

@@ -60,7 +60,7 @@ typedef struct {
 	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
 	/* closed-loop force / moment control, MotionForceTask.h:50-60 */
-	int cl_force, cl_moment;
+	int cl_force, cl_moment, passivity;
 	double kp_force, ki_force, kp_moment, ki_moment, kff_force, kff_moment, max_force_fb, max_moment_fb;
 	double Rcs[9], tcs[3]; /* _T_control_to_sensor */
 	double force_axis[3], moment_axis[3];
@@ -83,7 +83,9 @@ typedef struct {
 	double gravity[3];
 	/* per-instance integrator state (lazily sized) */
 	int state_B;
-	double* integ; /* [B][MAXT][MAXN] (motion force uses 6) */
+	double* integ; /* [B][MAXT][MAXN] (motion force: 12) */
+	void* popc;    /* [B][popc_tasks] passivity observer states (tasks with enablePassivity), lazily sized */
+	int popc_tasks, popc_slot[MAXT];
 } orc_ctx;
 
 /* ------------------------------------------------------------------ small dense helpers (row-major) */
@@ -396,6 +398,64 @@ static void orientation_error(const double Rd[9], const double Rc[9], double e[3
 	}
 }
 
+/* POPCExplicitForceControl (src/helper_modules/POPCExplicitForceControl.cpp), per instance and task.  The reference's window is an
+ * unbounded std::queue; POPC_CAP samples are kept here (ample for the test horizons; overflow aborts the step with status 4). */
+#define POPC_CAP 2048
+typedef struct {
+	int inited;
+	double PO, Ecorr, stored, Rc, vsum;
+	int counter, head, size;
+	double ring[POPC_CAP];
+} popc_state;
+static void popc_reinit(popc_state* s) { /* :10-22 */
+	s->PO = s->Ecorr = s->stored = s->vsum = 0;
+	s->counter = 50;
+	s->Rc = 1.0;
+	s->head = s->size = 0;
+	s->inited = 1;
+}
+/* computePassivitySaturatedForce with _is_enabled, :35-95; returns Rc */
+static double popc_step(popc_state* s, double dt, double kff, double kv, const double* fd, const double* fs, const double* vcl, const double* vr, int* overflow) {
+	const int PO_WINDOW = 250, PO_MAX = 50;
+	double Fcmd[3], vc2 = 0, p = 0;
+	for (int i = 0; i < 3; i++) {
+		Fcmd[i] = kff * fd[i] + s->Rc * vcl[i] - kv * vr[i];
+		vc2 += vcl[i] * vcl[i];
+		p += (fs[i] - fd[i]) * vcl[i] - Fcmd[i] * vr[i];
+	}
+	p *= dt;
+	s->PO += p;
+	if (s->size == POPC_CAP) { *overflow = 1; s->head = (s->head + 1) % POPC_CAP; s->size--; }
+	s->ring[(s->head + s->size) % POPC_CAP] = p;
+	s->size++;
+	if (s->PO + s->stored + s->Ecorr > 0) {
+		while (s->size > PO_WINDOW) {
+			double front = s->ring[s->head];
+			if (s->PO + s->Ecorr + s->stored > front) {
+				if (front > 0) s->PO -= front;
+				s->head = (s->head + 1) % POPC_CAP;
+				s->size--;
+			} else break;
+		}
+	}
+	if (s->counter <= 0) {
+		s->counter = PO_MAX;
+		double old = s->Rc;
+		if (s->PO + s->stored + s->Ecorr < 0) {
+			s->Rc = 1 + (s->PO + s->stored + s->Ecorr) / (s->vsum * dt);
+			if (s->Rc > 1) s->Rc = 1;
+			if (s->Rc < 0) s->Rc = 0;
+		} else {
+			s->Rc = (1 + (0.1 * PO_MAX - 1) * s->Rc) / (double)(0.1 * PO_MAX);
+		}
+		s->Ecorr += (1 - old) * s->vsum * dt;
+		s->vsum = 0;
+	}
+	s->counter--;
+	s->vsum += vc2;
+	return s->Rc;
+}
+
 /* ------------------------------------------------------------------ per-task cached models */
 typedef struct {
 	double N_prec[MAXN * MAXN], N[MAXN * MAXN];
@@ -501,7 +561,7 @@ static void sigma_space(const double Pb[9], int dim, const double axis[3], const
 /* MotionForceTask::computeTorques(), :278-509, with sigma_force = sigma_moment = 0 (defaults, :897-899, :937-939),
  * OTG disabled (desired = goal, :385-391), velocity saturation off, open-loop force control. */
 static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm, const double* goal,
-								double* integ, double* tau) {
+								double* integ, popc_state* popc, double* tau) {
 	int n = c->n, k = tm->k;
 	double p[3], Jw[6 * MAXN], Rc[9];
 	position_in_world(rs, t->link, t->pos_in_link, p);         /* :286-287 */
@@ -561,10 +621,18 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 		nrm = sqrt(nrm);
 		if (nrm > t->max_force_fb)
 			for (int i = 0; i < 3; i++) fb[i] *= t->max_force_fb / nrm;
-		double vcl[3], vr[3];
+		double vcl[3], vr[3], rc = 1.0;
 		mat3v(sig_f, fb, vcl);
 		mat3v(sig_f, v, vr);
-		for (int i = 0; i < 3; i++) F_f[i] = vcl[i] - t->kv_force * vr[i];
+		if (t->passivity && popc) { /* enablePassivity(): :344-348 */
+			double fd[3], fs[3];
+			int ovf = 0;
+			mat3v(sig_f, goal_force, fd);
+			mat3v(sig_f, f_sw, fs);
+			if (!popc->inited) popc_reinit(popc);
+			rc = popc_step(popc, t->dt, t->kff_force, t->kv_force, fd, fs, vcl, vr, &ovf);
+		}
+		for (int i = 0; i < 3; i++) F_f[i] = rc * vcl[i] - t->kv_force * vr[i];
 	} else { /* open loop :350-354 */
 		for (int i = 0; i < 3; i++) tmp[i] = -t->kv_force * v[i];
 		mat3v(sig_f, tmp, F_f);
@@ -868,7 +936,7 @@ typedef struct {
 } orc_details;
 
 static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* dq, const double* const* goal, double* integ,
-							  double* tau, orc_details* det) {
+							  popc_state* popc, double* tau, orc_details* det) {
 	int n = c->n;
 	robot_state rs;
 	task_model tm[MAXT];
@@ -910,7 +978,8 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 	for (int i = 0; i < n; i++) tau[i] = 0;
 	for (int t = 0; t < c->nt; t++) {
 		const orc_task* tk = &c->task[t];
-		if (tk->type == TASK_MOTION_FORCE) mf_compute_torques(c, tk, &rs, &tm[t], goal[t], integ + t * MAXN, tt);
+		if (tk->type == TASK_MOTION_FORCE)
+			mf_compute_torques(c, tk, &rs, &tm[t], goal[t], integ + t * MAXN, (popc && c->popc_slot[t] >= 0) ? popc + c->popc_slot[t] : NULL, tt);
 		else jt_compute_torques(c, tk, &rs, &tm[t], goal[t], integ + t * MAXN, tau, tt);
 		if (det && det->task_tau) memcpy(det->task_tau + t * n, tt, sizeof(double) * n);
 		for (int i = 0; i < n; i++) tau[i] += tt[i];
@@ -974,7 +1043,7 @@ orc_ctx* orc_create(int n_links, const int* joint_type, const double* xyz, const
 	return c;
 }
 void orc_destroy(orc_ctx* c) {
-	if (c) { free(c->integ); free(c); }
+	if (c) { free(c->integ); free(c->popc); free(c); }
 }
 int orc_dof(const orc_ctx* c) { return c->n; }
 
@@ -1104,6 +1173,7 @@ void orc_set_mf_force_spaces(orc_ctx* c, int task, int force_dim, const double* 
 	for (int i = 0; i < 3; i++) { t->force_axis[i] = force_axis[i]; t->moment_axis[i] = moment_axis[i]; }
 }
 /* setClosedLoopForceControl / MomentControl, setForceControlGains, setFeedforward*Gain, setMax*ControlFeedbackOutput, setForceSensorFrame */
+void orc_set_passivity(orc_ctx* c, int task, int enabled) { c->task[task].passivity = enabled != 0; c->state_B = 0; }
 void orc_set_closed_loop_force_control(orc_ctx* c, int task, int cl_force, int cl_moment, const double* gains8, const double* Rcs, const double* tcs) {
 	orc_task* t = &c->task[task];
 	t->cl_force = cl_force; t->cl_moment = cl_moment;
@@ -1120,6 +1190,8 @@ void orc_set_velocity_saturation(orc_ctx* c, int task, int enabled, double lin_s
 void orc_reset_state(orc_ctx* c) {
 	free(c->integ);
 	c->integ = NULL;
+	free(c->popc);
+	c->popc = NULL;
 	c->state_B = 0;
 }
 
@@ -1146,7 +1218,8 @@ static void* worker(void* p) {
 			for (int i = 0; i < gs; i++) gbuf[t][i] = a->goals[t][(size_t)i * B + b];
 			gp[t] = gbuf[t];
 		}
-		int st = orc_instance_cycle(c, q, dq, gp, a->integ + (size_t)b * MAXT * MAXN, tau, NULL);
+		int st = orc_instance_cycle(c, q, dq, gp, a->integ + (size_t)b * MAXT * MAXN,
+									c->popc ? (popc_state*)c->popc + (size_t)b * c->popc_tasks : NULL, tau, NULL);
 		for (int i = 0; i < n; i++) a->tau[(size_t)i * B + b] = tau[i];
 		if (a->status) a->status[b] = (unsigned char)st;
 	}
@@ -1159,6 +1232,13 @@ int orc_step_batch(orc_ctx* c, int B, const double* q, const double* dq, const d
 	if (c->state_B != B) {
 		free(c->integ);
 		c->integ = (double*)calloc((size_t)B * MAXT * MAXN, sizeof(double));
+		free(c->popc);
+		c->popc = NULL;
+		c->popc_tasks = 0;
+		for (int t = 0; t < MAXT; t++) c->popc_slot[t] = -1;
+		for (int t = 0; t < c->nt; t++)
+			if (c->task[t].type == TASK_MOTION_FORCE && c->task[t].passivity) c->popc_slot[t] = c->popc_tasks++;
+		if (c->popc_tasks) c->popc = calloc((size_t)B * c->popc_tasks, sizeof(popc_state));  /* inited = 0: re-initialised on first use */
 		c->state_B = B;
 	}
 	if (nthreads < 1) nthreads = 1;
@@ -1182,6 +1262,6 @@ int orc_step_details(const orc_ctx* c, const double* q, const double* dq, const 
 	double integ[MAXT * MAXN];
 	memset(integ, 0, sizeof(integ));
 	orc_details d = {N_out, Lambda_out, sv_out, M_out, task_tau};
-	return orc_instance_cycle(c, q, dq, goals, integ, tau, &d);
+	return orc_instance_cycle(c, q, dq, goals, integ, NULL, tau, &d);
 }
 int orc_maxn(void) { return MAXN; }

@@ -338,7 +338,7 @@ class MotionForceTask(_Task):
     def setClosedLoopMomentControl(self, enabled: bool):
         self._cfg("saip_batch_set_closed_loop_moment_control", int(enabled))
 
-    def enablePassivity(self):  # MotionForceTask.h:630: the POPC passivity controller is not on the device
+    def enablePassivity(self):  # MotionForceTask.h:630: POPC passivity observer / controller around the closed-loop force control
         self._cfg("saip_batch_set_passivity", 1)
 
     def disablePassivity(self):
@@ -679,6 +679,8 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
                 o.setControlToSensorTransform(t.get("Rcs", np.eye(3)), t.get("tcs", np.zeros(3)))
                 o.setClosedLoopForceControl(bool(t.get("cl_force")))
                 o.setClosedLoopMomentControl(bool(t.get("cl_moment")))
+                if t.get("passivity"):
+                    o.enablePassivity()
             o.setForceControlGains(t.get("kp_force", 0.7), t.get("kv_force", 10.0), t.get("ki_force", 1.3))
             o.setMomentControlGains(t.get("kp_moment", 0.7), t.get("kv_moment", 10.0), t.get("ki_moment", 1.3))
             if t.get("force_dim", 0):

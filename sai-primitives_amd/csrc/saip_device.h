@@ -66,7 +66,8 @@ struct TaskDev {
 	double lin_sat, ang_sat, kv_force, kv_moment;
 	double force_axis[3], moment_axis[3];      // unit axes
 	// closed-loop force / moment control (MotionForceTask.cpp:327-349, 357-378, 484-487), passivity controller off (POPC default)
-	int cl_force, cl_moment, pad2_[2];
+	int cl_force, cl_moment;
+	int popc_enabled, popc_cap;                // POPCExplicitForceControl around the force loop; capacity of the energy window ring
 	double kp_force, ki_force, kp_moment, ki_moment, kff_force, kff_moment, max_force_fb, max_moment_fb;
 	double Rcs[9], tcs[3];                     // _T_control_to_sensor (MotionForceTask.cpp:94, 802)
 	double kvinv_pos[3], kvinv_ori[3];         // pseudo-inverse of the diagonal kv gains (computePseudoInverse)
@@ -75,6 +76,7 @@ struct TaskDev {
 	double* goal;      // [goal_comps][ld]
 	double* integ;     // [6 or m][ld]
 	double* diag_N;    // optional [n*n][ld] task nullspace dump (diagnostic variant), else nullptr
+	double* popc;      // [7 + popc_cap][ld] passivity observer state: PO, E_correction, Rc, sum |vcl|^2, counter, ring head, ring size, ring
 };
 
 struct CycleParams {

@@ -341,6 +341,7 @@ struct saip_batch {
 };
 
 static bool has_device(const saip_batch* b) { return b->device >= 0; }
+static saip_status need_ready(saip_batch* b, const char* fn);
 
 extern "C" int saip_device_count(void) {
 	int n = 0;
@@ -918,11 +919,33 @@ extern "C" saip_status saip_batch_set_closed_loop_force_control(saip_batch* b, i
 extern "C" saip_status saip_batch_set_closed_loop_moment_control(saip_batch* b, int t, int enabled) {
 	return set_closed_loop(b, t, enabled, true, "saip_batch_set_closed_loop_moment_control");
 }
-// enablePassivity (MotionForceTask.h:630): the windowed passivity observer / controller of POPCExplicitForceControl is not on the device
+// POPCExplicitForceControl::reInitialize (POPCExplicitForceControl.cpp:10-22) for every instance; allocates the state on first use
+static saip_status popc_reinit(saip_batch* b, TaskHost& T) {
+	const int cap = T.dev.popc_cap;
+	const size_t rows = 7 + (size_t)cap, ld = b->ld;
+	if (!T.dev.popc) {
+		saip_status st = dev_alloc(b, &T.dev.popc, rows * ld);
+		if (st) return st;
+	}
+	HIP_TRY(hipMemsetAsync(T.dev.popc, 0, rows * ld * sizeof(double), b->stream));
+	std::vector<double> one(ld, 1.0), fifty(ld, 50.0);  // _Rc = 1, _PO_counter = _PO_max_counter
+	HIP_TRY(hipMemcpyAsync(T.dev.popc + 2 * ld, one.data(), ld * sizeof(double), hipMemcpyHostToDevice, b->stream));
+	HIP_TRY(hipMemcpyAsync(T.dev.popc + 4 * ld, fifty.data(), ld * sizeof(double), hipMemcpyHostToDevice, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+// enablePassivity / disablePassivity (MotionForceTask.h:630-631 -> POPCExplicitForceControl::enable / disable, .cpp:24-29)
 extern "C" saip_status saip_batch_set_passivity(saip_batch* b, int t, int enabled) {
 	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_passivity");
 	if (st) return st;
-	if (enabled) return fail(SAIP_ERR_UNSUPPORTED, "the passivity observer / controller (POPCExplicitForceControl.cpp:35-96) is not implemented on the device; closed-loop force control runs with it disabled (its default)");
+	TaskHost& T = b->tasks[t];
+	T.dev.popc_enabled = enabled ? 1 : 0;
+	if (T.dev.popc_cap == 0) T.dev.popc_cap = 1024;
+	b->config_dirty = true;
+	if (b->finalized && has_device(b)) {
+		if ((st = need_ready(b, "saip_batch_set_passivity"))) return st;
+		if (!enabled || !T.dev.popc) return popc_reinit(b, T);  // disable() re-initialises; the first enable() creates the state
+	}
 	return SAIP_OK;
 }
 // setFeedforwardForceGain / MomentGain, setMaxForceControlFeedbackOutput / Moment (MotionForceTask.h:330-355)
@@ -1080,6 +1103,11 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 		if (T.otg_enabled) {
 			saip_status st = ensure_otg(b, T);
 			if (st) return st;
+		}
+		if (T.dev.type == saip::TASK_MOTION_FORCE && T.dev.popc_enabled && !T.dev.popc) {  // enabled before finalize
+			saip_status st = popc_reinit(b, T);
+			if (st) return st;
+			b->config_dirty = true;
 		}
 	}
 	if (b->config_dirty || diag) {

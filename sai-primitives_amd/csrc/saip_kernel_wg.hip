@@ -62,6 +62,7 @@ struct WgSmem {
 	double cs[4 * (NMAX / 2 + 1)];
 	int colidx[NMAX];
 	int flag, rank;
+	int flag2;  // passivity-observer window overflow (status bit 2)
 };
 
 template <int NMAX, int T>
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	const ModelDev& md = *P.model;
 
 	// ---------------------------------------------------------------- state
+	if (tid == 0) sm.flag2 = 0;
 	if (tid < n) {
 		sm.q[tid] = P.q[(size_t)tid * P.ld + b];
 		sm.dq[tid] = P.dq[(size_t)tid * P.ld + b];
@@ -616,7 +618,9 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					const bool closed = tk.cl_force || tk.cl_moment;
 					if (closed)
 						for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * P.ld + b];
-					law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff);
+					bool ovf = false;
+					law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, P.ld, &ovf);
+					if (ovf) sm.flag2 = 1;
 					if (closed)
 						for (int i = 0; i < 6; i++) tk.integ[(size_t)(6 + i) * P.ld + b] = ifm[i];
 					if (track)
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		if (singular) tv = __builtin_nan("");
 		P.tau[(size_t)tid * P.ld + b] = tv;
 	}
-	if (tid == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
+	if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0));
 }
 
 // ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)

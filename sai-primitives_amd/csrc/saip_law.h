@@ -43,11 +43,76 @@ __device__ __forceinline__ void law_sigma_space(CP Pb, const int dim, CP axis, c
 // xp, Rc: control point / control frame; G: goal block (36: x3 R9 v3 w3 a3 alpha3 f3 m3 + sensed force 3, sensed moment 3 in the
 // sensor frame); ip, io: position / orientation integrators (in/out); ifm: force (0..2) and moment (3..5) integrators (in/out).
 // Outputs F_um (unit-mass force, acts through Lambda_mod) and F_f (force-related terms, act directly).
+// POPCExplicitForceControl::computePassivitySaturatedForce (POPCExplicitForceControl.cpp:29-96): windowed passivity observer
+// (window 250 cycles) + passivity controller updated every 50 cycles; returns the scaling Rc of the feedback term.
+// st = this instance's column of the task's POPC state ([7 + cap][ld]): PO, E_correction, Rc, sum |vcl|^2, counter, ring head, ring
+// size, then the ring of per-cycle power samples (the reference's std::queue is unbounded; *overflow is set when cap is exceeded
+// and the oldest sample is dropped).
+__device__ inline double law_popc(double* st, int ld, int cap, double dt, double kff, double kv, const double* fd, const double* fs,
+								  const double* vcl, const double* vr, bool* overflow) {
+	const int PO_WINDOW = 250, PO_MAX_COUNTER = 50;
+	double PO = st[0], Ecorr = st[(size_t)1 * ld], Rc = st[(size_t)2 * ld], vsum = st[(size_t)3 * ld];
+	int counter = (int)st[(size_t)4 * ld], head = (int)st[(size_t)5 * ld], size = (int)st[(size_t)6 * ld];
+	double* ring = st + (size_t)7 * ld;
+	const double stored = 0.0;  // _stored_energy_PO is never written after reInitialize
+	double Fcmd[3], vc2 = 0.0, p = 0.0;
+	for (int i = 0; i < 3; i++) {
+		Fcmd[i] = kff * fd[i] + Rc * vcl[i] - kv * vr[i];
+		vc2 += vcl[i] * vcl[i];
+		p += (fs[i] - fd[i]) * vcl[i] - Fcmd[i] * vr[i];
+	}
+	p *= dt;
+	PO += p;
+	if (size == cap) {  // window storage exhausted: drop the oldest sample without touching PO
+		head = (head + 1) % cap;
+		size--;
+		*overflow = true;
+	}
+	ring[(size_t)((head + size) % cap) * ld] = p;
+	size++;
+	if (PO + stored + Ecorr > 0) {
+		while (size > PO_WINDOW) {
+			const double front = ring[(size_t)head * ld];
+			if (PO + Ecorr + stored > front) {
+				if (front > 0) PO -= front;
+				head = (head + 1) % cap;
+				size--;
+			} else {
+				break;
+			}
+		}
+	}
+	if (counter <= 0) {
+		counter = PO_MAX_COUNTER;
+		const double old_Rc = Rc;
+		if (PO + stored + Ecorr < 0) {  // activity detected
+			Rc = 1 + (PO + stored + Ecorr) / (vsum * dt);
+			if (Rc > 1) Rc = 1;
+			if (Rc < 0) Rc = 0;
+		} else {
+			Rc = (1 + (0.1 * PO_MAX_COUNTER - 1) * Rc) / (double)(0.1 * PO_MAX_COUNTER);
+		}
+		Ecorr += (1 - old_Rc) * vsum * dt;
+		vsum = 0;
+	}
+	counter--;
+	vsum += vc2;
+	st[0] = PO;
+	st[(size_t)1 * ld] = Ecorr;
+	st[(size_t)2 * ld] = Rc;
+	st[(size_t)3 * ld] = vsum;
+	st[(size_t)4 * ld] = (double)counter;
+	st[(size_t)5 * ld] = (double)head;
+	st[(size_t)6 * ld] = (double)size;
+	return Rc;
+}
+
 // CL = false compiles the closed-loop force / moment branch out (the lane kernel leaves such task stacks to the general kernel;
 // G then only needs 30 entries and ifm may be null).
 template <bool CL, typename TK>
 __device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw, const double* xp, const double* Rc, const double* G,
-														 double* ip, double* io, double* ifm, double* Fum, double* Ff) {
+														 double* ip, double* io, double* ifm, double* Fum, double* Ff, double* popc_state = nullptr, int ld = 0,
+														 bool* popc_overflow = nullptr) {
 	const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	const double* rot = tk->param_in_compliant_frame ? Rc : I3;
 	double sig_f[9], sig_m[9], sig_p[9], sig_o[9], T[9], ImS[9];
@@ -102,11 +167,16 @@ __device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw
 				const double sc = tk->max_force_fb / nrm;
 				LAW_UNR for (int i = 0; i < 3; i++) fb[i] *= sc;
 			}
-			double sfb[3], sv[3], sg[3];
+			double sfb[3], sv[3], sg[3], rc = 1.0;
 			law_mat3_vec(sig_f, fb, sfb);
 			law_mat3_vec(sig_f, v, sv);
 			law_mat3_vec(sig_f, gf, sg);
-			LAW_UNR for (int i = 0; i < 3; i++) Ff[i] = sfb[i] - tk->kv_force * sv[i] + kff_f * sg[i];
+			if (tk->popc_enabled && popc_state) {  // enablePassivity(): :344-348
+				double sfs[3];
+				law_mat3_vec(sig_f, fsw, sfs);
+				rc = law_popc(popc_state, ld, tk->popc_cap, tk->dt, tk->kff_force, tk->kv_force, sg, sfs, sfb, sv, popc_overflow);
+			}
+			LAW_UNR for (int i = 0; i < 3; i++) Ff[i] = rc * sfb[i] - tk->kv_force * sv[i] + kff_f * sg[i];
 		} else {
 			double sv[3], sg[3];
 			law_mat3_vec(sig_f, v, sv);

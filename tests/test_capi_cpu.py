@@ -105,8 +105,7 @@ def test_task_constructor_validation(sp):
     t.setClosedLoopForceControl(True)           # implemented (passivity controller off, its default)
     t.setClosedLoopMomentControl(True)
     t.setForceControlParameters(0.9, 0.8, 15.0, 5.0)
-    with pytest.raises(sp.SaipUnsupported, match="passivity"):
-        t.enablePassivity()
+    t.enablePassivity()                         # POPC passivity observer / controller (MotionForceTask.h:630)
     t.disablePassivity()
     r2 = _cfg_only(sp)
     j2 = sp.JointTask(r2)

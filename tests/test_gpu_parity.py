@@ -206,8 +206,49 @@ def test_closed_loop_force_control_over_cycles():
         tau = ctrl.computeControlTorques()
         ref, _ = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], goals, nthreads=8)
         assert W.torque_error(tau, ref) < TOL
-        with pytest.raises(sp.SaipUnsupported):
-            tasks[0].enablePassivity()
+
+
+def test_closed_loop_force_control_with_passivity_controller():
+    """enablePassivity() (MotionForceTask.h:630; examples 07 / 09): windowed passivity observer + passivity controller of
+    POPCExplicitForceControl.cpp:35-95 around the force loop.  600 cycles with changing sensor readings and joint velocities:
+    the observer detects activity, the controller scales the feedback down (Rc < 1) and recovers; torques match the oracle in
+    every compared cycle.  disablePassivity() re-initialises the observer (:24-29)."""
+    from oracle import Oracle
+    B = 64
+    d = W.make_inputs(13, B)
+    tasks_spec = W.config_tasks(13)
+    tasks_spec[0]["passivity"] = True
+    rng = np.random.default_rng(21)
+    orc = Oracle(d["model"], tasks_spec)
+    robot, ctrl, tasks = _engine(d["model"].name, tasks_spec, B)
+    goals = [g.copy() for g in d["goals"]]
+    robot.setQ(d["q"])
+    ctrl.setGoals(goals)
+    worst, taus = 0.0, []
+    for k in range(600):
+        if k % 9 == 0:
+            scale = 0.05 if (k // 150) % 2 else 1.0          # alternate rough and quiet sensor phases
+            fs = goals[0][:, 24:27] + scale * rng.uniform(-8, 8, (B, 3))
+            goals[0][:, 30:33] = fs
+            tasks[0].updateSensedForceAndMoment(fs, goals[0][:, 33:36])
+        dq = d["dq"] * (1.0 + 0.5 * np.sin(0.05 * k))
+        robot.setDq(dq)
+        robot.updateModel()
+        ctrl.updateControllerTaskModels()
+        tau = ctrl.computeControlTorques()
+        ref, st = orc.step(d["q"], dq, goals, nthreads=8)
+        assert st.sum() == 0 and ctrl.status.sum() == 0
+        worst = max(worst, W.torque_error(tau, ref))
+        taus.append(tau)
+    print("passivity controller, 600 cycles, kernel", ctrl.kernelName(), "worst err", worst)
+    assert worst < TOL
+    # the controller did something: with passivity off the same final cycle gives different torques
+    orc2 = Oracle(d["model"], W.config_tasks(13))
+    for k in range(3):
+        ref_off, _ = orc2.step(d["q"], dq, goals, nthreads=8)
+    assert np.abs(ref_off - taus[-1]).max() > 1e-3
+    tasks[0].disablePassivity()
+    tasks[0].enablePassivity()
 
 
 def test_task_nullspaces_match_oracle():

@@ -195,6 +195,46 @@ def gravity_vector(model: RobotModel, frames, g=(0.0, 0.0, -9.81)) -> np.ndarray
     return tau
 
 
+def popc_new():
+    """POPCExplicitForceControl::reInitialize, POPCExplicitForceControl.cpp:10-22"""
+    return dict(PO=0.0, Ecorr=0.0, stored=0.0, window=[], counter=50, Rc=1.0, vsum=0.0)
+
+
+def popc_step(s, dt, kff, kv, fd, fs, vcl, vr, window=250, max_counter=50):
+    """computePassivitySaturatedForce (enabled), POPCExplicitForceControl.cpp:35-95; returns the new Rc"""
+    F_cmd = kff * fd + s["Rc"] * vcl - kv * vr
+    vc2 = float(vcl @ vcl)
+    p = float((fs - fd) @ vcl - F_cmd @ vr) * dt
+    s["PO"] += p
+    s["window"].append(p)
+    if s["PO"] + s["stored"] + s["Ecorr"] > 0:
+        while len(s["window"]) > window:
+            if s["PO"] + s["Ecorr"] + s["stored"] > s["window"][0]:
+                if s["window"][0] > 0:
+                    s["PO"] -= s["window"][0]
+                s["window"].pop(0)
+            else:
+                break
+    if s["counter"] <= 0:
+        s["counter"] = max_counter
+        old = s["Rc"]
+        if s["PO"] + s["stored"] + s["Ecorr"] < 0:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rc = 1 + np.float64(s["PO"] + s["stored"] + s["Ecorr"]) / np.float64(s["vsum"] * dt)
+            if rc > 1:
+                rc = 1.0
+            if rc < 0:
+                rc = 0.0
+            s["Rc"] = float(rc)
+        else:
+            s["Rc"] = (1 + (0.1 * max_counter - 1) * s["Rc"]) / (0.1 * max_counter)
+        s["Ecorr"] += (1 - old) * s["vsum"] * dt
+        s["vsum"] = 0.0
+    s["counter"] -= 1
+    s["vsum"] += vc2
+    return s["Rc"]
+
+
 def forward_dynamics(model: RobotModel, q, dq, tau, g=(0.0, 0.0, -9.81), damping=0.0, eps=1e-5):
     """qdd (B,n) from the Lagrange equations, independent of any recursive Newton-Euler code:
     M qdd + Mdot dq - 1/2 grad_q(dq^T M dq) + dU/dq = tau - damping dq,  with dM/dq_k by central differences of mass_matrix.
@@ -572,7 +612,11 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
                 fb = sig_f @ (-t.get("kp_force", 0.7) * (f_sw - goal_force) - t.get("ki_force", 1.3) * ifo)
                 if np.linalg.norm(fb) > t.get("max_force_fb", 20.0):
                     fb = fb * t.get("max_force_fb", 20.0) / np.linalg.norm(fb)
-                F_force = sig_f @ fb - t["kv_force"] * (sig_f @ v)
+                rc = 1.0
+                if t.get("passivity") and st is not None:
+                    rc = popc_step(st.setdefault("popc", popc_new()), t["dt"], t.get("kff_force", 0.95), t["kv_force"],
+                                   sig_f @ goal_force, sig_f @ f_sw, sig_f @ fb, sig_f @ v)   # :344-348
+                F_force = rc * (sig_f @ fb) - t["kv_force"] * (sig_f @ v)
             else:
                 F_force = sig_f @ (-t["kv_force"] * v)               # open loop, :350-354
             if cl_m:                                                 # :357-378
