@@ -54,10 +54,11 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SAIP_LIB", LIB_PATH)  # A/B measurements of two builds inside one GPU session
+    if not os.path.exists(path):
         raise SaipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(the engine has no CPU path)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     dp, vp, ip = C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)
     u8p = C.POINTER(C.c_ubyte)
     sig = {

@@ -41,10 +41,14 @@ __device__ unsigned long long saip_stamps[256];
 		}                                                                                  \
 		__builtin_amdgcn_sched_barrier(0);                                                 \
 	} while (0)
+#define DIAG_STAMP() PHASE_FENCE()
 #elif defined(SAIP_NO_FENCE)
 #define PHASE_FENCE()
 #else
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef DIAG_STAMP
+#define DIAG_STAMP()  // extra stamps of the diagnostic build only: no scheduling effect in the shipped kernels
 #endif
 
 // sin/cos for joint angles: Cody-Waite reduction by pi/2 (two FMA terms, exact for |x| < 1e5) + fdlibm kernel polynomials on
@@ -540,6 +544,18 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 	(void)LD; (void)P_Z; (void)P_O; (void)P_CAP; (void)md;
 	// ======================================================== JointTask (RJ rows in the range basis)
 	const int m = tk->m;
+	// control-law inputs (goal rows, joint velocities) are requested NOW so that their HBM / L2 latency is covered by the range-basis
+	// and Lambda algebra below; they are consumed ~7000 clocks later (the loads cannot cross the phase fences)
+	double pre_goal[3 * N], pre_dq[N];
+	if (!PF) {
+		UNR for (int i = 0; i < N; i++) {
+			const int ii = (i < m) ? i : 0;
+			pre_goal[i] = tk->goal[(size_t)ii * ld + b];
+			pre_goal[N + i] = tk->goal[(size_t)(m + ii) * ld + b];
+			pre_goal[2 * N + i] = tk->goal[(size_t)(2 * m + ii) * ld + b];
+			pre_dq[i] = P.dq[(size_t)i * ld + b];
+		}
+	}
 	double U[N][RJ], Jh[RJ][N];
 	int r_lane = 0;
 	bool need_exact = false;
@@ -703,6 +719,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 	PHASE_FENCE();
 	double Lam[RJ][RJ], Lmod[RJ][RJ], T1[RJ][N];
 	opspace_lambda<N, RJ, SMT::MINV_LDS>(Jh, Minv, MBinv, bie, r_lane, tk->decoupling, Lam, Lmod, T1);
+	DIAG_STAMP();
 
 	tk = launder(tk);
 	// ---- control law (JointTask.cpp:285-356, OTG off, no velocity saturation)
@@ -715,9 +732,10 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 			UNR for (int j = 0; j < N; j++) s = fma(mr[j], tau[j], s);
 			w[i] = s;
 		}
+		DIAG_STAMP();
 		UNR for (int j = 0; j < N; j++) {
-			qv[j] = PF ? sm.pf[j][lane] : P.q[(size_t)j * ld + b];
-			dqv[j] = PF ? sm.pf[N + j][lane] : P.dq[(size_t)j * ld + b];
+			qv[j] = PF ? sm.pf[j][lane] : sm.qsh[j][lane];  // the joint angles are still parked in LDS from the kinematics
+			dqv[j] = PF ? sm.pf[N + j][lane] : pre_dq[j];
 		}
 		double a1[RJ], b1[RJ];
 		UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
@@ -736,7 +754,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 						sw = fma(sij, w[j], sw);
 					}
 				}
-				const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : tk->goal[(size_t)i * ld + b]);
+				const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : pre_goal[i]);
 				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
 				ie += e * tk->dt;  // :323-324
 				if (track && live && !singular) tk->integ[(size_t)i * ld + b] = ie;
@@ -746,21 +764,23 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 					vdes = fmin(fmax(vdes, -tk->sat[i]), tk->sat[i]);
 					fi = -tk->kv[i] * (vel - vdes);
 				} else {
-					fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : tk->goal[(size_t)(m + i) * ld + b])) - tk->ki[i] * ie;  // :342-345
+					fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : pre_goal[N + i])) - tk->ki[i] * ie;  // :342-345
 				}
-				const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : tk->goal[(size_t)(2 * m + i) * ld + b]) - sw;
+				const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : pre_goal[2 * N + i]) - sw;
 				UNR for (int c = 0; c < RJ; c++) {
 					a1[c] = fma(U[i][c], ai, a1[c]);
 					b1[c] = fma(U[i][c], fi, b1[c]);
 				}
 			}
 		}
+		DIAG_STAMP();
 		UNR for (int a = 0; a < RJ; a++) {  // g = Lambda a1 + Lambda_mod b1  (:348-351)
 			double s = 0.0;
 			UNR for (int c = 0; c < RJ; c++) s = fma(Lam[a][c], a1[c], fma(Lmod[a][c], b1[c], s));
 			g[a] = (a < r_lane) ? s : 0.0;
 		}
 	}
+	DIAG_STAMP();
 	apply_task<N, RJ>(Jh, g, Lam, T1, r_lane, first, last, tau, Np);
 }
 
@@ -795,7 +815,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		for (int t = 0; t < P.nt; t++) {
 			const TaskCPtr tk = tasks + t;
 			acc += tk->dt + tk->rot[0] + tk->Bm[0] + tk->Bm[8] + tk->Bm[16] + tk->Bm[24] + tk->Bm[32] + tk->Ppos[4] + tk->sig_p[0] + tk->sig_o[0] +
-				   tk->kp_pos[0] + tk->kp_ori[2] + tk->kp[0] + tk->kp[8];
+				   tk->kp_pos[0] + tk->kp_ori[2] + tk->kp[0] + tk->kp[8] + tk->kv[0] + tk->ki[0];
 		}
 		asm volatile("" ::"s"(acc));
 	}
@@ -1140,10 +1160,8 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	*supported = inst != 0;
 	if (!inst) return hipSuccess;
 	const bool mf_jt = (P.nt == 2 && !P.lane_task_is_joint[0] && P.lane_task_is_joint[1]);
-	// latency variant: inputs prefetched into LDS (100 KB per wavefront).  Only worth it while a CU hosts one wavefront,
-	// and its layout assumes a full joint task (3 dof goal rows) below one motion-force task.
-	static const bool want_pf = getenv("SAIP_LANE_PF") != nullptr;  // measured SLOWER (33.0 vs 28.9 us at cfg2): off unless asked for
-	const bool pf = mf_jt && P.lane_prefetch_ok && P.B <= 64 * 256 && want_pf;
+	// (a variant that prefetched every input into LDS at kernel entry, template parameter PF, measured no faster -- 22.9 vs 22.8 us at
+	// cfg2 -- and is no longer instantiated; the joint-task inputs are requested early in registers instead, see lane_joint_task)
 	// throughput variant once the batch needs more than one wavefront per CU: 36 KB LDS per wavefront instead of 100 KB
 	static const char* lean_env = getenv("SAIP_LANE_LEAN");  // "0"/"1" forces the choice (profiling)
 	const bool lean = lean_env ? (lean_env[0] == '1') : (P.B > 64 * 256);
@@ -1151,7 +1169,6 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 #define LAUNCH(NN, RR, SS, PP, GG) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false, GG>), grid, block, 0, stream, P)
 	const bool gl = P.lane_general != 0;
 	if (P.n == 7 && inst == 1 && mf_jt && !gl && lean) hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true, false>), grid, block, 0, stream, P);
-	else if (P.n == 7 && inst == 1 && mf_jt && !gl && pf) LAUNCH(7, 1, SIG_MF_JT, true, false);
 	else if (P.n == 7 && inst == 1 && mf_jt && !gl) LAUNCH(7, 1, SIG_MF_JT, false, false);
 #ifndef SAIP_LANE_ONLY_71
 	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false, true);
