@@ -54,8 +54,14 @@ typedef enum { SAIP_TASK_UNDEFINED = 0, SAIP_TASK_JOINT_LIMIT_AVOIDANCE = 1, SAI
 /* SaiPrimitives::DynamicDecouplingType, helper_modules/SaiPrimitivesCommonDefinitions.h:14-20 (same values) */
 typedef enum { SAIP_FULL_DYNAMIC_DECOUPLING = 0, SAIP_BOUNDED_INERTIA_ESTIMATES = 1, SAIP_IMPEDANCE = 2 } saip_decoupling_type;
 
-/* per-instance status written by a cycle */
-enum { SAIP_INSTANCE_OK = 0, SAIP_INSTANCE_SINGULAR = 1 /* left SingularityHandler's non-singular branch: torques = NaN */ };
+/* per-instance status written by a cycle (uint8).  SINGULAR excludes the others; TRUNCATED and POPC_OVERFLOW are informational bits
+ * on valid torques and may combine. */
+enum {
+	SAIP_INSTANCE_OK = 0,
+	SAIP_INSTANCE_SINGULAR = 1,       /* left SingularityHandler's non-singular branch with the handling strategy enabled: torques = NaN */
+	SAIP_INSTANCE_TRUNCATED = 2,      /* handling disabled: a motion-force task was reduced to its non-singular subspace (or passed through) */
+	SAIP_INSTANCE_POPC_OVERFLOW = 4   /* the passivity observer's energy window exceeded the 1024 samples kept on the device */
+};
 
 /* One URDF link + the joint that attaches it to its parent (what sai-model/sai-urdfreader read from a URDF).
  * Link i's parent is link i-1 (serial chain); link 0 hangs off the fixed base.  Fixed links are merged into
