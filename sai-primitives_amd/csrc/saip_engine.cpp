@@ -369,6 +369,7 @@ extern "C" void saip_batch_destroy(saip_batch* b) {
 	if (!b) return;
 	if (has_device(b)) {
 		(void)hipSetDevice(b->device);
+		if (b->stream) (void)hipStreamSynchronize(b->stream);  // nothing of this batch may still be in flight
 		for (void* p : b->allocs) (void)hipFree(p);
 		if (b->stream) (void)hipStreamDestroy(b->stream);
 	}
@@ -1233,7 +1234,12 @@ static saip_status launch_reinit_masked(saip_batch* b, int task, int mask) {
 	for (auto& T : b->tasks) otg.push_back(T.otg_enabled), T.otg_enabled = false;  // reinit does not depend on the OTG flag
 	CycleParams P;
 	saip_status st = make_params(b, P, false);
-	for (size_t i = 0; i < b->tasks.size(); i++) b->tasks[i].otg_enabled = otg[i];
+	bool any_otg = false;
+	for (size_t i = 0; i < b->tasks.size(); i++) {
+		b->tasks[i].otg_enabled = otg[i];
+		any_otg = any_otg || otg[i];
+	}
+	if (any_otg) b->config_dirty = true;  // the upload above pointed the tasks at the raw goal rows: the next cycle must re-point them at the OTG output
 	if (st) return st;
 	P.reinit_task = task;
 	P.reinit_mask = mask;

@@ -82,7 +82,17 @@ def test_on_device_closed_loop_rollout_tracks_otg_trajectory():
     goal = x0 + np.array([0.05, -0.04, 0.03])
     mf.setGoalPosition(goal)
     ctrl.updateControllerTaskModels()
-    ctrl.rolloutAsync(1500, 5e-4, 2, gravity=(0.0, 0.0, 0.0))
+    ctrl.rolloutAsync(100, 5e-4, 2, gravity=(0.0, 0.0, 0.0))
+    ctrl.synchronize()
+    qm, _ = ctrl.pullState()
+    frm = W.fk(model, qm)
+    lim = model.link_index("end-effector")
+    xm = frm[lim][1] + frm[lim][0] @ np.array([0.0, 0.0, 0.07])
+    des = mf.getDesiredPosition()
+    # after 0.1 s the end effector follows the OTG's acceleration-limited profile (<= 1/2 * 2 m/s^2 * (0.1 s)^2 = 1 cm per axis), not the raw goal
+    assert np.abs(des - x0).max() <= 0.0101 and np.abs(xm - des).max() < 2e-3 and np.abs(xm - goal).max() > 0.02
+    ctrl.updateControllerTaskModels()
+    ctrl.rolloutAsync(1400, 5e-4, 2, gravity=(0.0, 0.0, 0.0))
     ctrl.synchronize()
     q1, dq1 = ctrl.pullState()
     fr = W.fk(model, q1)

@@ -251,6 +251,50 @@ def test_closed_loop_force_control_with_passivity_controller():
     tasks[0].enablePassivity()
 
 
+def test_everything_on_at_once():
+    """interaction test: internal OTGs on both tasks (Cartesian + joint), closed-loop force control with the passivity controller,
+    singularity handling disabled, torque saturation and gravity compensation, 200 cycles.  The engine's desired states are fed to
+    the oracle as goals, so every cycle checks the whole chain OTG -> law -> hierarchy -> post-processing."""
+    from oracle import Oracle
+    B = 96
+    d = W.make_inputs(13, B)
+    spec = W.config_tasks(13)
+    spec[0]["passivity"] = True
+    spec[0]["singularity_handling"] = False
+    orc = Oracle(d["model"], spec, gravity_comp=True, torque_saturation=True)
+    robot, ctrl, tasks = _engine(d["model"].name, spec, B, disable_otg=False)
+    ctrl.enableGravityCompensation(True)
+    ctrl.enableTorqueSaturation(True)
+    mf, jt = tasks
+    robot.setQ(d["q"])
+    robot.setDq(d["dq"])
+    robot.updateModel()
+    ctrl.reinitializeTasks()
+    rng = np.random.default_rng(4)
+    g0, g1 = d["goals"][0].copy(), d["goals"][1].copy()
+    mf.setGoalPosition(g0[:, 0:3])
+    mf.setGoalOrientation(g0[:, 3:12].reshape(B, 3, 3))
+    mf.setGoalForce(g0[:, 24:27])
+    mf.setGoalMoment(g0[:, 27:30])
+    jt.setGoalPosition(g1[:, 0:7])
+    worst = 0.0
+    for k in range(200):
+        if k % 10 == 0:
+            g0[:, 30:33], g0[:, 33:36] = g0[:, 24:27] + rng.uniform(-3, 3, (B, 3)), rng.uniform(-1, 1, (B, 3))
+            mf.updateSensedForceAndMoment(g0[:, 30:33], g0[:, 33:36])
+        ctrl.updateControllerTaskModels()
+        tau = ctrl.computeControlTorques()
+        des0 = mf._desired_block()                     # OTG output + pass-through force rows, goal layout
+        des1 = jt._desired_block()
+        assert np.array_equal(des0[:, 24:36], g0[:, 24:36])
+        ref, st = orc.step(d["q"], d["dq"], [des0, des1], nthreads=8)
+        assert np.array_equal(ctrl.status & 3, st & 3) and (st != 1).all()
+        worst = max(worst, W.torque_error(tau, ref))
+    print("everything on, 200 cycles, kernel", ctrl.kernelName(), "worst err", worst)
+    assert worst < TOL
+    assert np.abs(des0[:, 0:3] - d["goals"][0][:, 0:3]).max() < 0.06 and np.abs(des0[:, 0:3] - g0[:, 0:3]).max() < 0.051
+
+
 def test_task_nullspaces_match_oracle():
     from oracle import Oracle
     d = W.make_inputs(3, 32)
