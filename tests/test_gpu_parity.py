@@ -295,6 +295,47 @@ def test_everything_on_at_once():
     assert np.abs(des0[:, 0:3] - d["goals"][0][:, 0:3]).max() < 0.06 and np.abs(des0[:, 0:3] - g0[:, 0:3]).max() < 0.051
 
 
+@pytest.mark.parametrize("cfg,B,opts", [(12, 192, {}), (11, 128, dict(joint_limit_avoidance=True, gravity_comp=True, torque_saturation=True)),
+                                        (5, 24, {}), (3, 128, {}), (9, 128, {})])
+def test_internal_otg_with_every_stack(cfg, B, opts):
+    """the control law must track the internal OTGs' output on every kind of stack and kernel path: near-singular instances through
+    the slow path (12), joint-limit avoidance + gravity + saturation (11), the 30-dof chain with two Cartesian OTGs and a 32-lane joint
+    OTG (5), partial tasks (3), hybrid force/velocity-saturation laws (9).  Torques = oracle evaluated at the desired states, 6 cycles,
+    a re-initialisation in the middle."""
+    from oracle import Oracle
+    d = W.make_inputs(cfg, B)
+    orc = Oracle(d["model"], d["tasks"], **opts)
+    robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], B, disable_otg=False)
+    ctrl.enableJointLimitAvoidance(opts.get("joint_limit_avoidance", False))
+    ctrl.enableGravityCompensation(opts.get("gravity_comp", False))
+    ctrl.enableTorqueSaturation(opts.get("torque_saturation", False))
+    robot.setQ(d["q"])
+    robot.setDq(d["dq"])
+    robot.updateModel()
+    ctrl.reinitializeTasks()
+    ctrl.setGoals(d["goals"])
+    worst = 0.0
+    for k in range(6):
+        if k == 3:
+            ctrl.reinitializeTasks()
+            orc.reset_state()
+            ctrl.setGoals(d["goals"])
+        ctrl.updateControllerTaskModels()
+        tau = ctrl.computeControlTorques()
+        des = []
+        for t, g in zip(tasks, d["goals"]):
+            x = t._desired_block()
+            des.append(x[:, :g.shape[1]])
+        ref, st = orc.step(d["q"], d["dq"], des, nthreads=8)
+        assert np.array_equal(ctrl.status, st) and (st != 1).all()
+        worst = max(worst, W.torque_error(tau, ref))
+        for t, x, g in zip(tasks, des, d["goals"]):     # the desired state has not jumped to the goal
+            if g.shape[1] >= 24:
+                assert np.abs(x[:, 0:3] - g[:, 0:3]).max() > 1e-3
+    print("cfg", cfg, ctrl.kernelName(), "OTG on every task, worst err", worst)
+    assert worst < TOL
+
+
 def test_task_nullspaces_match_oracle():
     from oracle import Oracle
     d = W.make_inputs(3, 32)
