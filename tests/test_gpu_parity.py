@@ -336,6 +336,33 @@ def test_internal_otg_with_every_stack(cfg, B, opts):
     assert worst < TOL
 
 
+@pytest.mark.parametrize("cfg", [3, 6, 8])
+def test_singularity_handling_disabled_on_partial_and_multi_task_stacks(cfg):
+    """rank-truncated motion-force tasks beyond the full 6-dof case: a 3-dof position task (3), two motion-force tasks on the 8-dof
+    sliding-base Panda (6), a planar partial task with IMPEDANCE decoupling (8); every second instance has the elbow nearly straight.
+    Status (0 / 2) and torques against the oracle on both kernel paths."""
+    from oracle import Oracle
+    B = 96
+    d = W.make_inputs(cfg, B)
+    spec = W.config_tasks(cfg)
+    for t in spec:
+        if t["type"] == "motion_force":
+            t["singularity_handling"] = False
+    q = d["q"].copy()
+    col = 3 if d["model"].dof == 7 else 4
+    q[::2, col] = -0.07 - 0.25 * np.random.default_rng(cfg).uniform(size=B // 2)
+    ref, st = Oracle(d["model"], spec).step(q, d["dq"], d["goals"], nthreads=8)
+    assert (st == 2).sum() >= 8 and (st == 1).sum() == 0
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(d["model"].name, spec, B)
+        ctrl.setKernel(kernel)
+        tau = _run(robot, ctrl, q, d["dq"], d["goals"])
+        assert np.array_equal(ctrl.status, st)
+        err = W.torque_error(tau, ref)
+        print("cfg", cfg, ctrl.kernelName(), "truncated", int((st == 2).sum()), "err", err)
+        assert err < TOL
+
+
 def test_task_nullspaces_match_oracle():
     from oracle import Oracle
     d = W.make_inputs(3, 32)
