@@ -570,7 +570,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 			UNR for (int i = 0; i < N; i++)
 				UNR for (int j = 0; j < N; j++) {
 					double s = 0.0;
-					UNR for (int l = 0; l < N; l++) s = fma((i < m) ? tk->S[i * N + l] : 0.0, Np[l][j], s);
+					UNR for (int l = 0; l < N; l++) s = fma(tk->S[i * N + l], Np[l][j], s);  // rows >= m of the stored S are zero (host zero-fills): no branch per element
 					Wc[i][j] = s;
 				}
 		}
@@ -636,7 +636,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 				UNR for (int i = 0; i < N; i++)
 					UNR for (int j = 0; j < N; j++) {
 						double sacc = 0.0;
-						UNR for (int l = 0; l < N; l++) sacc = fma((i < m) ? tk->S[i * N + l] : 0.0, Np[l][j], sacc);
+						UNR for (int l = 0; l < N; l++) sacc = fma(tk->S[i * N + l], Np[l][j], sacc);
 						Jp[i][j] = sacc;
 					}
 				double trg = 0.0;
