@@ -323,19 +323,16 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 				o[e] = sm.park[P_O + 3 * j + e][lane];
 			}
 			const bool on = (j <= bd);
-			if (md->jtype[j] == 1) {
+			{  // branch-free: revolute (z x r; z) or prismatic (z; 0), zero beyond the task's body
+				const bool rev = md->jtype[j] == 1;
 				const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
-				Jw[0][j] = on ? z[1] * rz - z[2] * ry : 0.0;
-				Jw[1][j] = on ? z[2] * rx - z[0] * rz : 0.0;
-				Jw[2][j] = on ? z[0] * ry - z[1] * rx : 0.0;
-				Jw[3][j] = on ? z[0] : 0.0;
-				Jw[4][j] = on ? z[1] : 0.0;
-				Jw[5][j] = on ? z[2] : 0.0;
-			} else {
-				Jw[0][j] = on ? z[0] : 0.0;
-				Jw[1][j] = on ? z[1] : 0.0;
-				Jw[2][j] = on ? z[2] : 0.0;
-				Jw[3][j] = Jw[4][j] = Jw[5][j] = 0.0;
+				const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
+				Jw[0][j] = on ? (rev ? c0 : z[0]) : 0.0;
+				Jw[1][j] = on ? (rev ? c1 : z[1]) : 0.0;
+				Jw[2][j] = on ? (rev ? c2 : z[2]) : 0.0;
+				Jw[3][j] = (on && rev) ? z[0] : 0.0;
+				Jw[4][j] = (on && rev) ? z[1] : 0.0;
+				Jw[5][j] = (on && rev) ? z[2] : 0.0;
 			}
 			const double dqj = PF ? sm.pf[N + j][lane] : P.dq[(size_t)j * ld + b];
 			UNR for (int e = 0; e < 6; e++) vw[e] = fma(Jw[e][j], dqj, vw[e]);
@@ -739,41 +736,43 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 		}
 		double a1[RJ], b1[RJ];
 		UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
+		// straight-line over all N rows: rows >= m of U are zero (zero rows of S), so they drop out of a1 / b1 without a branch per row;
+		// only the integrator traffic is guarded
+		const bool s_id = tk->s_identity != 0;
+		const double dt_ = tk->dt;
 		UNR for (int i = 0; i < N; i++) {
-			if (i < m) {
-				double cur = 0.0, vel = 0.0, sw = 0.0;
-				if (tk->s_identity) {
-					cur = qv[i];
-					vel = dqv[i];
-					sw = w[i];
-				} else {
-					UNR for (int j = 0; j < N; j++) {
-						const double sij = tk->S[i * N + j];
-						cur = fma(sij, qv[j], cur);
-						vel = fma(sij, dqv[j], vel);
-						sw = fma(sij, w[j], sw);
-					}
-				}
-				const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : pre_goal[i]);
-				double ie = track ? tk->integ[(size_t)i * ld + b] : 0.0;
-				ie += e * tk->dt;  // :323-324
-				if (track && live && !singular) tk->integ[(size_t)i * ld + b] = ie;
-				double fi;
-				if (GL && tk->vel_sat) {  // JointTask.cpp:327-341
-					double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;
-					vdes = fmin(fmax(vdes, -tk->sat[i]), tk->sat[i]);
-					fi = -tk->kv[i] * (vel - vdes);
-				} else {
-					fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : pre_goal[N + i])) - tk->ki[i] * ie;  // :342-345
-				}
-				const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : pre_goal[2 * N + i]) - sw;
-				UNR for (int c = 0; c < RJ; c++) {
-					a1[c] = fma(U[i][c], ai, a1[c]);
-					b1[c] = fma(U[i][c], fi, b1[c]);
+			double cur = 0.0, vel = 0.0, sw = 0.0;
+			if (s_id) {
+				cur = qv[i];
+				vel = dqv[i];
+				sw = w[i];
+			} else {
+				UNR for (int j = 0; j < N; j++) {
+					const double sij = tk->S[i * N + j];
+					cur = fma(sij, qv[j], cur);
+					vel = fma(sij, dqv[j], vel);
+					sw = fma(sij, w[j], sw);
 				}
 			}
+			const double e = cur - (PF ? sm.pf[2 * N + 24 + i][lane] : pre_goal[i]);
+			double ie = 0.0;
+			if (track && i < m) ie = tk->integ[(size_t)i * ld + b];
+			ie += e * dt_;  // :323-324
+			if (track && live && !singular && i < m) tk->integ[(size_t)i * ld + b] = ie;
+			double fi;
+			if (GL && tk->vel_sat) {  // JointTask.cpp:327-341
+				double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;
+				vdes = fmin(fmax(vdes, -tk->sat[i]), tk->sat[i]);
+				fi = -tk->kv[i] * (vel - vdes);
+			} else {
+				fi = -tk->kp[i] * e - tk->kv[i] * (vel - (PF ? sm.pf[2 * N + 24 + N + i][lane] : pre_goal[N + i])) - tk->ki[i] * ie;  // :342-345
+			}
+			const double ai = (PF ? sm.pf[2 * N + 24 + 2 * N + i][lane] : pre_goal[2 * N + i]) - sw;
+			UNR for (int c = 0; c < RJ; c++) {
+				a1[c] = fma(U[i][c], ai, a1[c]);
+				b1[c] = fma(U[i][c], fi, b1[c]);
+			}
 		}
-		DIAG_STAMP();
 		UNR for (int a = 0; a < RJ; a++) {  // g = Lambda a1 + Lambda_mod b1  (:348-351)
 			double s = 0.0;
 			UNR for (int c = 0; c < RJ; c++) s = fma(Lam[a][c], a1[c], fma(Lmod[a][c], b1[c], s));
@@ -988,16 +987,13 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 					z[e] = sm.park[P_Z + 3 * j + e][lane];
 					o[e] = sm.park[P_O + 3 * j + e][lane];
 				}
-				if (md->jtype[j] == 1) {
-					UNR for (int e = 0; e < 3; e++) Sw[j][e] = z[e];
-					Sv[j][0] = o[1] * z[2] - o[2] * z[1];
-					Sv[j][1] = o[2] * z[0] - o[0] * z[2];
-					Sv[j][2] = o[0] * z[1] - o[1] * z[0];
-				} else {
-					UNR for (int e = 0; e < 3; e++) {
-						Sw[j][e] = 0.0;
-						Sv[j][e] = z[e];
-					}
+				{  // unit motion of joint j about the world origin, branch-free (a branch per joint splits the unrolled code into tiny blocks)
+					const bool rev = md->jtype[j] == 1;
+					const double cx = o[1] * z[2] - o[2] * z[1], cy = o[2] * z[0] - o[0] * z[2], cz = o[0] * z[1] - o[1] * z[0];
+					UNR for (int e = 0; e < 3; e++) Sw[j][e] = rev ? z[e] : 0.0;
+					Sv[j][0] = rev ? cx : z[0];
+					Sv[j][1] = rev ? cy : z[1];
+					Sv[j][2] = rev ? cz : z[2];
 				}
 			}
 			double Ic[10];
