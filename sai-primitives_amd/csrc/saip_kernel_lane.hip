@@ -385,44 +385,57 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 				if (a == c) tr += s;
 			}
 		const double itr = 1.0 / tr;
-		double Gs[6][6], G2[6][6], Gt[6][6];
-		UNR for (int a = 0; a < 6; a++)
-			UNR for (int c = 0; c < 6; c++) {
-				Gs[a][c] = G[a][c] * itr;
-				G2[a][c] = Gs[a][c];
-			}
-		UNR for (int rep = 0; rep < 2; rep++) {  // G2 <- G2^2: Gs^2, Gs^4
+		const double smax2 = tk->s_max * tk->s_max, tol2 = tk->s_abs_tol * tk->s_abs_tol;
+		// LDL^T pivots of Gs - shift I on the k x k block (padded diagonal entries are set to 1): all > 0 <=> lambda_min(Gs) > shift
+		auto ldl_positive = [&](const double shift) {
+			double Gs[6][6];
 			UNR for (int a = 0; a < 6; a++)
-				UNR for (int c = 0; c <= a; c++) {
-					double s = 0.0;
-					UNR for (int l = 0; l < 6; l++) s = fma(G2[a][l], G2[l][c], s);
-					Gt[a][c] = s;
+				UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
+			bool pos = true;
+			UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < k) ? Gs[a][a] - shift : 1.0;
+			UNR for (int kk = 0; kk < 6; kk++) {
+				const double d = Gs[kk][kk];
+				pos = pos && (d > 1e-13);
+				const double id = 1.0 / d;
+				UNR for (int i = kk + 1; i < 6; i++) {
+					const double lik = Gs[i][kk] * id;
+					UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
 				}
-			UNR for (int a = 0; a < 6; a++)
-				UNR for (int c = 0; c <= a; c++) {
-					G2[a][c] = Gt[a][c];
-					G2[c][a] = Gt[a][c];
-				}
-		}
-		double t8 = 0.0;  // trace(Gs^8) = ||Gs^4||_F^2
-		UNR for (int a = 0; a < 6; a++)
-			UNR for (int c = 0; c < 6; c++) t8 = fma(G2[a][c], G2[a][c], t8);
-		const double u = sqrt(sqrt(sqrt(t8)));  // lambda_max(Gs) <= u <= k^(1/8) lambda_max(Gs)
-		const bool ok_s0 = (u * tk->cert_kroot * tr >= tk->s_abs_tol * tk->s_abs_tol);
-		const double shift = tk->s_max * tk->s_max * u;
-		// LDL^T pivots of Gs - shift I on the k x k block (padded diagonal entries are set to 1)
-		bool pos = true;
-		UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < k) ? Gs[a][a] - shift : 1.0;
-		UNR for (int kk = 0; kk < 6; kk++) {
-			const double d = Gs[kk][kk];
-			pos = pos && (d > 1e-13);
-			const double id = 1.0 / d;
-			UNR for (int i = kk + 1; i < 6; i++) {
-				const double lik = Gs[i][kk] * id;
-				UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
 			}
+			return pos;
+		};
+		// stage 1: lambda_max(Gs) <= trace(Gs) = 1 and lambda_max(G) >= trace(G) / k.  Passes whenever the smallest eigenvalue is above
+		// s_max^2 of the TRACE -- the usual case -- and costs one LDL^T sweep.
+		// Tried for the first task of the stack only: a task projected through an earlier nullspace has a flatter, smaller spectrum
+		// and mostly needs stage 2 anyway.
+		const bool cheap = first && (tr > 0.0) && (tr >= (double)k * tol2) && ldl_positive(smax2);
+		need_exact = !cheap;
+		if (__any(need_exact)) {
+			// stage 2 (some lane of the wavefront is closer to the bound): the tighter trace-power bound lambda_max <= ||Gs^4||_F^(1/4)
+			double G2[6][6], Gt[6][6];
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c < 6; c++) G2[a][c] = G[a][c] * itr;
+			UNR for (int rep = 0; rep < 2; rep++) {  // G2 <- G2^2: Gs^2, Gs^4
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						double s = 0.0;
+						UNR for (int l = 0; l < 6; l++) s = fma(G2[a][l], G2[l][c], s);
+						Gt[a][c] = s;
+					}
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						G2[a][c] = Gt[a][c];
+						G2[c][a] = Gt[a][c];
+					}
+			}
+			double t8 = 0.0;  // trace(Gs^8) = ||Gs^4||_F^2
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c < 6; c++) t8 = fma(G2[a][c], G2[a][c], t8);
+			const double u = sqrt(sqrt(sqrt(t8)));  // lambda_max(Gs) <= u <= k^(1/8) lambda_max(Gs)
+			const bool ok_s0 = (u * tk->cert_kroot * tr >= tol2);
+			const bool pos = ldl_positive(smax2 * u);
+			need_exact = need_exact && !(ok_s0 && pos && tr > 0.0);
 		}
-		need_exact = !(ok_s0 && pos && tr > 0.0);
 	}
 	// exact path (rare): wave-cooperative Jacobi eigen-solve of this lane's Gram matrix
 	unsigned long long need = __ballot(need_exact);
