@@ -93,6 +93,8 @@ struct LaneSmem {
 	static constexpr bool MINV_LDS = !LEAN;              // latency variant: M^-1 and M_BIE^-1 parked in LDS, rows streamed on use
 	double minv[MINV_LDS ? N * (N + 1) : 1][64];        // two symmetric matrices, N(N+1)/2 rows each
 	double qsh[N][64];                                   // joint angles, fetched with one exposed memory latency for the rolled FK loop
+	double dqsh[(PF || LEAN) ? 1 : N][64];               // joint velocities, fetched in the same burst (latency variant)
+	static constexpr bool DQ_LDS = !(PF || LEAN);
 	double A[8 * LD], V[8 * LD], Jp[8 * LD], cs[4 * 5];
 	int colidx[8];
 	int flag, rank;
@@ -334,7 +336,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 				Jw[4][j] = (on && rev) ? z[1] : 0.0;
 				Jw[5][j] = (on && rev) ? z[2] : 0.0;
 			}
-			const double dqj = PF ? sm.pf[N + j][lane] : P.dq[(size_t)j * ld + b];
+			const double dqj = PF ? sm.pf[N + j][lane] : (SMT::DQ_LDS ? sm.dqsh[j][lane] : P.dq[(size_t)j * ld + b]);
 			UNR for (int e = 0; e < 6; e++) vw[e] = fma(Jw[e][j], dqj, vw[e]);
 		}
 		if (tk->bm_identity) {
@@ -563,7 +565,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 			pre_goal[i] = tk->goal[(size_t)ii * ld + b];
 			pre_goal[N + i] = tk->goal[(size_t)(m + ii) * ld + b];
 			pre_goal[2 * N + i] = tk->goal[(size_t)(2 * m + ii) * ld + b];
-			pre_dq[i] = P.dq[(size_t)i * ld + b];
+			pre_dq[i] = SMT::DQ_LDS ? 0.0 : P.dq[(size_t)i * ld + b];
 		}
 	}
 	double U[N][RJ], Jh[RJ][N];
@@ -745,7 +747,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 		DIAG_STAMP();
 		UNR for (int j = 0; j < N; j++) {
 			qv[j] = PF ? sm.pf[j][lane] : sm.qsh[j][lane];  // the joint angles are still parked in LDS from the kinematics
-			dqv[j] = PF ? sm.pf[N + j][lane] : pre_dq[j];
+			dqv[j] = PF ? sm.pf[N + j][lane] : (SMT::DQ_LDS ? sm.dqsh[j][lane] : pre_dq[j]);
 		}
 		double a1[RJ], b1[RJ];
 		UNR for (int c = 0; c < RJ; c++) a1[c] = b1[c] = 0.0;
@@ -866,9 +868,15 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		{
 			double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
 			if (!PF) {  // all joint angles in flight at once (one exposed HBM latency instead of one per loop iteration)
-				double qv[N];
+				double qv[N], dv[SM::DQ_LDS ? N : 1];
 				UNR for (int j = 0; j < N; j++) qv[j] = P.q[(size_t)j * ld + b];
+				if (SM::DQ_LDS) {
+					UNR for (int j = 0; j < N; j++) dv[j] = P.dq[(size_t)j * ld + b];
+				}
 				UNR for (int j = 0; j < N; j++) sm.qsh[j][lane] = qv[j];
+				if (SM::DQ_LDS) {
+					UNR for (int j = 0; j < N; j++) sm.dqsh[j][lane] = dv[j];
+				}
 			}
 			_Pragma("unroll 1") for (int j = 0; j < N; j++) {
 				const JointRec CONSTANT_AS* jr = md->jrec + j;
