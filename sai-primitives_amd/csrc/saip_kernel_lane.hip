@@ -42,10 +42,12 @@ __device__ unsigned long long saip_stamps[256];
 		__builtin_amdgcn_sched_barrier(0);                                                 \
 	} while (0)
 #define DIAG_STAMP() PHASE_FENCE()
-#elif defined(SAIP_NO_FENCE)
-#define PHASE_FENCE()
-#else
+#elif defined(SAIP_FENCE)
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+// Scheduling barriers between the phases paid off under the default machine scheduler; with the max-ilp strategy the kernels are
+// 0.4-1.5 % faster without them (A/B in one session, tools/ab_multi.sh), so they are now a diagnostic option (-DSAIP_FENCE).
+#define PHASE_FENCE()
 #endif
 #ifndef DIAG_STAMP
 #define DIAG_STAMP()  // extra stamps of the diagnostic build only: no scheduling effect in the shipped kernels
@@ -817,7 +819,7 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 	const ModelCPtr md = (ModelCPtr)P.model;
 	const TaskCPtr tasks = (TaskCPtr)P.tasks;
 	const size_t ld = P.ld;
-#ifndef SAIP_NO_PREWARM
+#ifdef SAIP_PREWARM  // scalar-cache prewarm: helped the first versions, costs 1 % now (kept for experiments)
 	{
 		// warm the scalar cache: one double of every 64-byte line of the per-joint records and of the head of the task constants,
 		// all loads in flight at once (one exposed L2 latency) instead of one cold miss per FK iteration / per task phase
