@@ -81,7 +81,9 @@ typedef const TaskDev CONSTANT_AS* TaskCPtr;
 // above it (they would otherwise all be issued at kernel entry and exhaust the SGPR file -> v_writelane/v_readlane spills).
 template <typename Ptr>
 __device__ __forceinline__ Ptr launder(Ptr p) {
+#ifndef SAIP_NO_LAUNDER
 	asm volatile("" : "+s"(p));
+#endif
 	return p;
 }
 
