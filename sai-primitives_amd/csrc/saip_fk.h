@@ -6,6 +6,27 @@
 
 namespace saip {
 
+// sin/cos for joint angles: Cody-Waite reduction by pi/2 (two FMA terms, exact for |x| < 1e5) + fdlibm kernel polynomials on
+// [-pi/4, pi/4] (errors < 1 ulp); the rare |x| >= 1e5 takes the library path.  ~35 instructions instead of ~110.
+__device__ __forceinline__ void sincos_joint(const double x, double* sn, double* cs) {
+	if (!(fabs(x) < 1.0e5)) {
+		sincos(x, sn, cs);
+		return;
+	}
+	const double k = rint(x * 6.36619772367581382433e-01);
+	double r = fma(-k, 1.57079632673412561417e+00, x);
+	r = fma(-k, 6.07710050650619224932e-11, r);
+	const double z = r * r;
+	const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+	const double s0 = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+	const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+	const double c0 = 1.0 - fma(0.5, z, -z * pc);
+	const int q = (int)k & 3;
+	const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+	*sn = (q & 2) ? -sa : sa;
+	*cs = ((q + 1) & 2) ? -ca : ca;
+}
+
 __device__ __forceinline__ void fk_mat3_vec(const double* R, const double* v, double* o) {
 	o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
 	o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
@@ -25,7 +46,7 @@ __device__ inline void fk_control_frame(const ModelDev& md, const TaskDev& tk, c
 		const double ax = md.axis[j][0], ay = md.axis[j][1], az = md.axis[j][2];
 		if (md.jtype[j] == 1) {
 			double s, c;
-			sincos(qj, &s, &c);
+			sincos_joint(qj, &s, &c);
 			const double v = 1.0 - c;
 			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
 								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
