@@ -46,7 +46,8 @@ __device__ inline void fk_control_frame(const ModelDev& md, const TaskDev& tk, c
 		const double ax = md.axis[j][0], ay = md.axis[j][1], az = md.axis[j][2];
 		if (md.jtype[j] == 1) {
 			double s, c;
-			sincos_joint(qj, &s, &c);
+			sincos(qj, &s, &c);  // library sin/cos on purpose: this pose seeds the OTG state, whose knife-edge decisions (collinearity
+			                     // within 2^-52) are compared against reference fixtures generated with the same arithmetic
 			const double v = 1.0 - c;
 			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
 								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
