@@ -1153,6 +1153,17 @@ static int pick_rj(int n, int rj) {
 	return 0;
 }
 
+#if defined(SAIP_LANE_LEAN_TU)
+// Translation unit of the throughput (LEAN) instantiation only: built with the default machine scheduler, under which it is 6 %
+// faster than under max-ilp (the latency variants are the other way round); see capi.build_library.
+hipError_t launch_cycle_lane_lean(const CycleParams& P, hipStream_t stream) {
+	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
+	hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true, false>), grid, block, 0, stream, P);
+	return hipGetLastError();
+}
+#else
+hipError_t launch_cycle_lane_lean(const CycleParams& P, hipStream_t stream);
+
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported) {
 	int rj = 1;
 	for (int t = 0; t < P.nt; t++)
@@ -1169,7 +1180,7 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 	const dim3 grid((P.B + P.lane_active - 1) / P.lane_active), block(64);
 #define LAUNCH(NN, RR, SS, PP, GG) hipLaunchKernelGGL((saip_cycle_lane<NN, RR, SS, PP, false, GG>), grid, block, 0, stream, P)
 	const bool gl = P.lane_general != 0;
-	if (P.n == 7 && inst == 1 && mf_jt && !gl && lean) hipLaunchKernelGGL((saip_cycle_lane<7, 1, SIG_MF_JT, false, true, false>), grid, block, 0, stream, P);
+	if (P.n == 7 && inst == 1 && mf_jt && !gl && lean) return launch_cycle_lane_lean(P, stream);
 	else if (P.n == 7 && inst == 1 && mf_jt && !gl) LAUNCH(7, 1, SIG_MF_JT, false, false);
 #ifndef SAIP_LANE_ONLY_71
 	else if (P.n == 7 && inst == 1 && mf_jt) LAUNCH(7, 1, SIG_MF_JT, false, true);
@@ -1187,6 +1198,7 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 #undef LAUNCH
 	return hipGetLastError();
 }
+#endif  // SAIP_LANE_LEAN_TU
 
 #if defined(SAIP_STAMP)
 extern "C" int saip_debug_stamps(unsigned long long* out, int n) {
