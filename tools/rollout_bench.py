@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 import workloads as W  # noqa: E402
 from sai_primitives_amd.controller import controller_from_specs  # noqa: E402
 
-for B in (4096, 65536):
+for B in [int(x) for x in os.environ.get("BATCHES", "4096,65536").split(",")]:
     d = W.make_inputs(2, B)
     robot, ctrl, tasks = controller_from_specs(d["model"].name, d["tasks"], B, device=0, disable_otg=False)
     robot.setQ(d["q"])
