@@ -145,6 +145,32 @@ def test_singular_instances_are_flagged_not_wrong():
     assert W.torque_error(tau[st == 0], ref[st == 0]) < TOL
 
 
+@pytest.mark.parametrize("cfg", [2, 3, 6])
+def test_branch_predicates_on_unfiltered_configurations(cfg):
+    """the workloads reject near-singular samples; here 4096 joint configurations are drawn over the WHOLE joint range without any
+    rejection, so the certificate / exact-eigenvalue fast paths of the kernels see the full spread of conditioning, including
+    the blending region of SingularityHandler.  Every instance must get the oracle's status (1 = outside the non-singular branch)
+    and, where valid, the oracle's torques, on both kernel paths."""
+    from oracle import Oracle
+    B = 4096
+    d = W.make_inputs(cfg, B)
+    model = d["model"]
+    rng = np.random.default_rng(100 + cfg)
+    q = model.q_lower + (model.q_upper - model.q_lower) * rng.uniform(0.02, 0.98, (B, model.dof))
+    ref, st = Oracle(model, d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    assert 0 < (st == 1).sum() < B
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(model.name, d["tasks"], B)
+        ctrl.setKernel(kernel)
+        tau = _run(robot, ctrl, q, d["dq"], d["goals"])
+        differ = np.flatnonzero(ctrl.status != st)
+        assert differ.size == 0, (ctrl.kernelName(), differ[:10], W._task_sv_ratio(model, d["tasks"], q[differ[:10]]))
+        assert np.isnan(tau[st == 1]).all()
+        err = W.torque_error(tau[st == 0], ref[st == 0])
+        print("cfg", cfg, ctrl.kernelName(), "flagged", int((st == 1).sum()), "of", B, "err on the rest", err)
+        assert err < TOL
+
+
 def test_singularity_handling_disabled_full_size():
     """disableSingularityHandling() (MotionForceTask.h:723): near-singular instances are not flagged any more, the motion-force task
     acts on its non-singular subspace (SingularityHandler.cpp:107-115, 146-148, 319-330).  Lane kernel + device-side slow path and
