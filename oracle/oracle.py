@@ -39,6 +39,7 @@ def lib():
         L.orc_set_singularity_bounds.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.orc_set_timestep.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_set_singularity_handling.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_singularity_strategies.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_goal_size.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_mf_force_spaces.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double]
@@ -101,6 +102,7 @@ class Oracle:
                 L.orc_set_mf_gains(self._h, tid, *[x[1] for x in g])
                 L.orc_set_singularity_bounds(self._h, tid, t["s_min"], t["s_max"])
                 L.orc_set_singularity_handling(self._h, tid, int(bool(t.get("singularity_handling", True))))
+                L.orc_set_singularity_strategies(self._h, tid, int(bool(t.get("singularity_strategies", False))))
                 fa, ma = _d(_vec3(t.get("force_axis", [0, 0, 1]))), _d(_vec3(t.get("moment_axis", [0, 0, 1])))
                 L.orc_set_mf_force_spaces(self._h, tid, int(t.get("force_dim", 0)), fa[1], int(t.get("moment_dim", 0)), ma[1],
                                           int(bool(t.get("param_in_compliant_frame", False))), float(t.get("kv_force", 10.0)), float(t.get("kv_moment", 10.0)))

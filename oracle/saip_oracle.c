@@ -42,7 +42,7 @@
 enum { JT_FIXED = 0, JT_REVOLUTE = 1, JT_PRISMATIC = 2 };
 enum { TASK_MOTION_FORCE = 1, TASK_JOINT = 2 };
 enum { FULL_DYNAMIC_DECOUPLING = 0, BOUNDED_INERTIA_ESTIMATES = 1, IMPEDANCE = 2 };
-enum { ST_OK = 0, ST_SINGULAR = 1, ST_TRUNCATED = 2 };
+enum { ST_OK = 0, ST_SINGULAR = 1, ST_TRUNCATED = 2, ST_BLENDED = 8 };
 
 typedef struct {
 	int type;
@@ -57,6 +57,7 @@ typedef struct {
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double s_min, s_max, s_abs_tol;
 	int sing_handling;     /* SingularityHandler::_enforce_handling_strategy (default true, SingularityHandler.cpp:61) */
+	int sing_strategies;   /* blended type-1 / type-2 strategies restated (sh_blend_*); otherwise such instances are flagged */
 	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
 	/* closed-loop force / moment control, MotionForceTask.h:50-60 */
@@ -86,6 +87,7 @@ typedef struct {
 	double* integ; /* [B][MAXT][MAXN] (motion force: 12) */
 	void* popc;    /* [B][popc_tasks] passivity observer states (tasks with enablePassivity), lazily sized */
 	int popc_tasks, popc_slot[MAXT];
+	void* sh;      /* [B][MAXT] blended-strategy states (sh_state), allocated when a task has sing_strategies */
 } orc_ctx;
 
 /* ------------------------------------------------------------------ small dense helpers (row-major) */
@@ -456,6 +458,19 @@ static double popc_step(popc_state* s, double dt, double kff, double kv, const d
 	return s->Rc;
 }
 
+/* SingularityHandler state that persists across cycles (SingularityHandler.h:197-230), per instance and motion-force task */
+#define SH_BUFFER 200
+#define SH_KP1 50.0
+#define SH_KV1 14.0
+#define SH_KV2 5.0
+#define SH_TYPE2_RATIO 1e-2
+#define SH_TYPE2_ANGLE (5 * M_PI / 180)
+typedef struct {
+	int inited, ntypes, c1, c2, head, size;
+	unsigned char hist[SH_BUFFER];
+	double q_prior[MAXN], dir[MAXN];
+} sh_state;
+
 /* ------------------------------------------------------------------ per-task cached models */
 typedef struct {
 	double N_prec[MAXN * MAXN], N[MAXN * MAXN];
@@ -466,11 +481,114 @@ typedef struct {
 	double sv[6];
 	int singular;
 	int truncated, skip;   /* handling disabled: task reduced to its non-singular part / passed through (fully singular) */
+	/* blended strategies (handling enforced): singular part of the task and the joint-space strategy */
+	int blend, nsg;        /* nsg = number of singular directions */
+	double alpha, U_s[36], V_s[MAXN * 6], J_s[6 * MAXN], Lambda_s_mod[36], Jpp[6 * MAXN], Lambda_js_mod[36];
+	sh_state* sh;
 	/* joint */
 	int r, empty;
 	double jt_projected_jacobian[MAXN * MAXN], current_task_range[MAXN * MAXN], M_partial[MAXN * MAXN],
 		M_partial_modified[MAXN * MAXN];
 } task_model;
+
+
+/* Blended singularity strategies (handling enforced): updateTaskModel :83-121, 146-228 and classifySingularity :230-295, with the
+ * three choices documented at workloads.sh_blend (sign-invariant classification, intended type-2 torque ratio, invariance of the
+ * torque formulas).  Returns 0 when the task is fully non-singular (the caller continues on the ordinary path). */
+static void position_in_world(const robot_state* rs, int link, const double pos_in_link[3], double p[3]);
+static void orientation_error(const double Rd[9], const double Rc[9], double e[3]);
+static void lambda_modified(const orc_task* t, const robot_state* rs, int n, const double* J, int rows, const double* Lambda, double* out) {
+	if (t->decoupling == FULL_DYNAMIC_DECOUPLING) memcpy(out, Lambda, sizeof(double) * rows * rows);
+	else if (t->decoupling == IMPEDANCE) eye(out, rows);
+	else {
+		double MinvB[MAXN * MAXN], T[6 * MAXN], Li[36];
+		bie_inverse(rs, n, t->bie_threshold, MinvB);
+		mm(J, MinvB, T, rows, n, n);
+		mmT(T, J, Li, rows, n, rows);
+		inverse(Li, out, rows);
+	}
+}
+static int sh_blend_update(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm, const double* U, const double* s,
+						   const double* V, int r, int k, int ns) {
+	int n = c->n;
+	sh_state* st = tm->sh;
+	if (!st) return 0;
+	if (!st->inited) { /* SingularityHandler.cpp:55-63 */
+		memset(st, 0, sizeof(*st));
+		for (int i = 0; i < n; i++) {
+			st->q_prior[i] = 0.5 * (c->q_lo[i] + c->q_hi[i]);
+			st->dir[i] = 1.0;
+		}
+		st->inited = 1;
+	}
+	if (st->ntypes == 0 || st->c2 > st->c1) memcpy(st->q_prior, rs->q, sizeof(double) * n); /* :232-235 */
+	if (ns == k) { /* :238-244 */
+		st->ntypes = st->c1 = st->c2 = st->head = st->size = 0;
+		return 0;
+	}
+	const int nsg = k - ns;
+	tm->blend = 1;
+	tm->nsg = nsg;
+	tm->k = ns;
+	tm->alpha = ns == 0 ? 0.0 : fmin(fmax((s[ns] / s[0] - t->s_min) / (t->s_max - t->s_min), 0.0), 1.0);
+	for (int i = 0; i < 6; i++)
+		for (int j = 0; j < nsg; j++) tm->U_s[i * nsg + j] = U[i * r + ns + j];
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < nsg; j++) tm->V_s[i * nsg + j] = V[i * r + ns + j];
+	mTm(tm->U_s, tm->projected_jacobian, tm->J_s, 6, nsg, n);
+	if (ns == 0) { /* fully singular: _N = N_prec (:149-151), torques zero (:316-317) */
+		memcpy(tm->N, tm->N_prec, sizeof(double) * n * n);
+	} else {
+		double Jbar[MAXN * 6], N_ns[MAXN * MAXN], N_js[MAXN * MAXN], Lam_s[36], Lam_js[36], T[MAXN * MAXN], T2[MAXN * MAXN], A[36];
+		for (int i = 0; i < 6; i++)
+			for (int j = 0; j < ns; j++) tm->task_range_ns[i * ns + j] = U[i * r + j];
+		mTm(tm->task_range_ns, tm->projected_jacobian, tm->projected_jacobian_ns, 6, ns, n);
+		op_space_matrices(rs, n, tm->projected_jacobian_ns, ns, tm->Lambda_ns, Jbar, N_ns);
+		lambda_modified(t, rs, n, tm->projected_jacobian_ns, ns, tm->Lambda_ns, tm->Lambda_ns_modified);
+		mm(tm->J_s, rs->Minv, T, nsg, n, n); /* Lambda_s = (J_s M^-1 J_s^T)^-1, :117 */
+		mmT(T, tm->J_s, A, nsg, n, nsg);
+		inverse(A, Lam_s, nsg);
+		lambda_modified(t, rs, n, tm->J_s, nsg, Lam_s, tm->Lambda_s_mod);
+		mm(N_ns, tm->N_prec, T, n, n, n); /* _posture_projected_jacobian = V_s^T N_ns N_prec, :153 */
+		mTm(tm->V_s, T, tm->Jpp, n, nsg, n);
+		op_space_matrices(rs, n, tm->Jpp, nsg, Lam_js, Jbar, N_js);
+		lambda_modified(t, rs, n, tm->Jpp, nsg, Lam_js, tm->Lambda_js_mod);
+		mm(N_js, N_ns, tm->N, n, n, n); /* :157 */
+		(void)T2;
+	}
+	/* classifySingularity :246-294 (sign-invariant: the larger motion of q + 5 v and q - 5 v) */
+	double x0[3], Rc0[9];
+	position_in_world(rs, t->link, t->pos_in_link, x0);
+	mm(rs->R[t->link], t->rot_in_link, Rc0, 3, 3, 3);
+	int any1 = 0;
+	for (int cidx = 0; cidx < nsg; cidx++) {
+		double motion = 0;
+		for (int sg = 0; sg < 2; sg++) {
+			robot_state r2;
+			memcpy(r2.q, rs->q, sizeof(double) * n);
+			for (int i = 0; i < n; i++) r2.q[i] += (sg ? -5.0 : 5.0) * tm->V_s[i * nsg + cidx];
+			update_kinematics(c, &r2);
+			double x1[3], Rc1[9], dphi[3], d = 0;
+			position_in_world(&r2, t->link, t->pos_in_link, x1);
+			mm(r2.R[t->link], t->rot_in_link, Rc1, 3, 3, 3);
+			orientation_error(Rc1, Rc0, dphi);
+			for (int e = 0; e < 3; e++) d += (x1[e] - x0[e]) * tm->U_s[e * nsg + cidx] + dphi[e] * tm->U_s[(3 + e) * nsg + cidx];
+			if (fabs(d) > motion) motion = fabs(d);
+		}
+		if (motion > 0.5) any1 = 1;
+	}
+	st->ntypes = nsg;
+	unsigned char ty = any1 ? 1 : 2;
+	if (st->size == SH_BUFFER) { /* pop the oldest (:285-292); pushing first and popping when size > buffer is the same thing */
+		if (st->hist[st->head] == 1) st->c1--; else st->c2--;
+		st->head = (st->head + 1) % SH_BUFFER;
+		st->size--;
+	}
+	st->hist[(st->head + st->size) % SH_BUFFER] = ty;
+	st->size++;
+	if (ty == 1) st->c1++; else st->c2++;
+	return 1;
+}
 
 /* SingularityHandler::updateTaskModel, SingularityHandler.cpp:75-228 (non-singular branch :123-141,146-148,175-193) */
 static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robot_state* rs, task_model* tm) {
@@ -486,6 +604,15 @@ static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	if (k < 2) { /* :100 loop never runs: rank-1 tasks leave stale state */
 		tm->singular = 1;
 		return;
+	}
+	tm->blend = 0;
+	if (t->sing_handling && t->sing_strategies) { /* blended strategies restated: sh_blend_update decides */
+		int ns = k;
+		if (s[0] < t->s_abs_tol) ns = 0;
+		else
+			for (int i = 1; i < k; i++)
+				if (s[i] / s[0] < t->s_max) { ns = i; break; }
+		if (sh_blend_update(c, t, rs, tm, U, s, V, r, k, ns)) return;
 	}
 	if (s[0] < t->s_abs_tol) { /* :83 fully singular */
 		if (t->sing_handling) {
@@ -698,6 +825,60 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	mat3v(sig_m, goal_moment, tmp);
 	for (int i = 0; i < 3; i++) F_f[3 + i] += (t->cl_force ? t->kff_moment : 1.0) * tmp[i];
 	/* SingularityHandler::computeTorques, :307-309 (and :316-330 with the handling strategy disabled) */
+	if (tm->blend) { /* computeTorques in the singular branches, :310-367 (conventions: workloads.sh_blend_torques) */
+		sh_state* st = tm->sh;
+		const int ns = tm->k, nsg = tm->nsg;
+		for (int i = 0; i < n; i++) tau[i] = 0;
+		if (ns == 0) return; /* :316-317 */
+		double a[6], b[6], f[6], tns[MAXN], ts[MAXN], tjs[MAXN], unit[MAXN], u[6], lu[6];
+		mTm(tm->task_range_ns, F_um, a, 6, ns, 1);
+		mTm(tm->task_range_ns, F_f, b, 6, ns, 1);
+		if (t->decoupling == IMPEDANCE) { /* :311-313 */
+			for (int i = 0; i < ns; i++) f[i] = a[i] + b[i];
+			mTm(tm->projected_jacobian_ns, f, tau, ns, n, 1);
+			return;
+		}
+		mm(tm->Lambda_ns_modified, a, f, ns, ns, 1);
+		for (int i = 0; i < ns; i++) f[i] += b[i];
+		mTm(tm->projected_jacobian_ns, f, tns, ns, n, 1);
+		if (st->c1 > st->c2) { /* type-1 strategy: hold the entering posture, :333-336 */
+			for (int i = 0; i < n; i++) unit[i] = -SH_KP1 * (rs->q[i] - st->q_prior[i]) - SH_KV1 * rs->dq[i];
+			mTm(tm->V_s, unit, u, n, nsg, 1);
+			mm(tm->Lambda_js_mod, u, lu, nsg, nsg, 1);
+			mTm(tm->Jpp, lu, tjs, nsg, n, 1);
+		} else { /* type-2 strategy, :337-355 */
+			for (int i = 0; i < n; i++)
+				if (tm->V_s[i * nsg] != 0) {
+					if (fabs(rs->q[i] - c->q_hi[i]) < SH_TYPE2_ANGLE) st->dir[i] = -1;
+					else if (fabs(rs->q[i] - c->q_lo[i]) < SH_TYPE2_ANGLE) st->dir[i] = 1;
+				}
+			double fn = 0, fTd = 0;
+			for (int i = 0; i < 6; i++) fn += (F_um[i] + F_f[i]) * (F_um[i] + F_f[i]);
+			fn = sqrt(fn);
+			for (int i = 0; i < 6; i++) fTd += (F_um[i] + F_f[i]) / fn * tm->U_s[i * nsg];
+			for (int i = 0; i < n; i++) unit[i] = st->dir[i] * (fabs(fTd) * SH_TYPE2_RATIO * c->effort[i]);
+			mTm(tm->V_s, unit, u, n, nsg, 1);
+			mTm(tm->Jpp, u, tjs, nsg, n, 1);
+			for (int i = 0; i < n; i++) unit[i] = -SH_KV2 * rs->dq[i];
+			mTm(tm->V_s, unit, u, n, nsg, 1);
+			mm(tm->Lambda_js_mod, u, lu, nsg, nsg, 1);
+			mTm(tm->Jpp, lu, unit, nsg, n, 1);
+			for (int i = 0; i < n; i++) tjs[i] += unit[i];
+		}
+		mTm(tm->U_s, F_um, a, 6, nsg, 1); /* :358-359 */
+		mTm(tm->U_s, F_f, b, 6, nsg, 1);
+		mm(tm->Lambda_s_mod, a, f, nsg, nsg, 1);
+		for (int i = 0; i < nsg; i++) f[i] += b[i];
+		mTm(tm->J_s, f, ts, nsg, n, 1);
+		for (int i = 0; i < n; i++) {
+			double v = ts[i];
+			if (v != v) v = 0;
+			else if (v > c->effort[i]) v = c->effort[i];
+			else if (v < -c->effort[i]) v = -c->effort[i];
+			tau[i] = tns[i] + tm->alpha * v + (1 - tm->alpha) * tjs[i];
+		}
+		return;
+	}
 	if (tm->skip) { /* fully singular task passed through: the integrators above still advanced, the torque is zero */
 		for (int i = 0; i < n; i++) tau[i] = 0;
 		return;
@@ -936,7 +1117,7 @@ typedef struct {
 } orc_details;
 
 static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* dq, const double* const* goal, double* integ,
-							  popc_state* popc, double* tau, orc_details* det) {
+							  popc_state* popc, sh_state* sh, double* tau, orc_details* det) {
 	int n = c->n;
 	robot_state rs;
 	task_model tm[MAXT];
@@ -954,9 +1135,11 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 	for (int t = 0; t < c->nt; t++) {
 		const orc_task* tk = &c->task[t];
 		if (tk->type == TASK_MOTION_FORCE) {
+			tm[t].sh = sh ? sh + t : NULL;
 			mf_update_task_model(c, tk, &rs, N_prec, &tm[t]);
+			if (tm[t].blend) info |= ST_BLENDED;
 			if (tm[t].singular) status = ST_SINGULAR;
-			if (tm[t].truncated) info = ST_TRUNCATED;
+			if (tm[t].truncated) info |= ST_TRUNCATED;
 			if (det && det->sv_out) memcpy(det->sv_out + 6 * t, tm[t].sv, sizeof(double) * 6);
 			if (status != ST_OK) break;
 			if (det && det->Lambda_out) memcpy(det->Lambda_out + t * MAXN * MAXN, tm[t].Lambda_ns, sizeof(double) * tm[t].k * tm[t].k);
@@ -1043,7 +1226,7 @@ orc_ctx* orc_create(int n_links, const int* joint_type, const double* xyz, const
 	return c;
 }
 void orc_destroy(orc_ctx* c) {
-	if (c) { free(c->integ); free(c->popc); free(c); }
+	if (c) { free(c->integ); free(c->popc); free(c->sh); free(c); }
 }
 int orc_dof(const orc_ctx* c) { return c->n; }
 
@@ -1153,6 +1336,10 @@ void orc_set_singularity_bounds(orc_ctx* c, int task, double s_min, double s_max
 	c->task[task].s_max = s_max;
 }
 void orc_set_singularity_handling(orc_ctx* c, int task, int enabled) { c->task[task].sing_handling = enabled != 0; }
+void orc_set_singularity_strategies(orc_ctx* c, int task, int enabled) {
+	c->task[task].sing_strategies = enabled != 0;
+	c->state_B = 0; /* state is re-sized on the next step */
+}
 void orc_set_timestep(orc_ctx* c, int task, double dt) { c->task[task].dt = dt; }
 int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {
 	c->jla_enabled = jla;
@@ -1192,6 +1379,8 @@ void orc_reset_state(orc_ctx* c) {
 	c->integ = NULL;
 	free(c->popc);
 	c->popc = NULL;
+	free(c->sh);
+	c->sh = NULL;
 	c->state_B = 0;
 }
 
@@ -1219,7 +1408,8 @@ static void* worker(void* p) {
 			gp[t] = gbuf[t];
 		}
 		int st = orc_instance_cycle(c, q, dq, gp, a->integ + (size_t)b * MAXT * MAXN,
-									c->popc ? (popc_state*)c->popc + (size_t)b * c->popc_tasks : NULL, tau, NULL);
+									c->popc ? (popc_state*)c->popc + (size_t)b * c->popc_tasks : NULL,
+									c->sh ? (sh_state*)c->sh + (size_t)b * MAXT : NULL, tau, NULL);
 		for (int i = 0; i < n; i++) a->tau[(size_t)i * B + b] = tau[i];
 		if (a->status) a->status[b] = (unsigned char)st;
 	}
@@ -1239,6 +1429,10 @@ int orc_step_batch(orc_ctx* c, int B, const double* q, const double* dq, const d
 		for (int t = 0; t < c->nt; t++)
 			if (c->task[t].type == TASK_MOTION_FORCE && c->task[t].passivity) c->popc_slot[t] = c->popc_tasks++;
 		if (c->popc_tasks) c->popc = calloc((size_t)B * c->popc_tasks, sizeof(popc_state));  /* inited = 0: re-initialised on first use */
+		free(c->sh);
+		c->sh = NULL;
+		for (int t = 0; t < c->nt; t++)
+			if (c->task[t].type == TASK_MOTION_FORCE && c->task[t].sing_strategies && !c->sh) c->sh = calloc((size_t)B * MAXT, sizeof(sh_state));
 		c->state_B = B;
 	}
 	if (nthreads < 1) nthreads = 1;
@@ -1262,6 +1456,6 @@ int orc_step_details(const orc_ctx* c, const double* q, const double* dq, const 
 	double integ[MAXT * MAXN];
 	memset(integ, 0, sizeof(integ));
 	orc_details d = {N_out, Lambda_out, sv_out, M_out, task_tau};
-	return orc_instance_cycle(c, q, dq, goals, integ, NULL, tau, &d);
+	return orc_instance_cycle(c, q, dq, goals, integ, NULL, NULL, tau, &d);
 }
 int orc_maxn(void) { return MAXN; }

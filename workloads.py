@@ -499,6 +499,110 @@ class Singular(Exception):
     pass
 
 
+# ---------------------------------------------------------------- SingularityHandler: blended type-1 / type-2 strategies
+# Restated from SingularityHandler.cpp:75-368 with three documented choices where the reference is not well defined:
+#  (1) classification (:252-273) perturbs q along the right singular vector, whose SIGN is an artefact of the SVD implementation;
+#      here a direction is TYPE_1 when the larger of the two motions (q + 5 v, q - 5 v) exceeds the tolerance (sign-invariant);
+#  (2) _type_2_torque_vector is built from _type_2_torque_ratio before that member is assigned (:48 vs :69); the intended
+#      TYPE_2_TORQUE_RATIO = 1e-2 is used;
+#  (3) everything else -- the torque formulas -- is invariant to the signs and to the basis inside each singular subspace.
+SH_TYPE_1_TOL, SH_PERTURB, SH_BUFFER, SH_KP1, SH_KV1, SH_KV2 = 0.5, 5.0, 200, 50.0, 14.0, 5.0
+SH_TYPE2_RATIO, SH_TYPE2_ANGLE = 1e-2, 5 * np.pi / 180
+
+
+def sh_state_new(model):
+    n = model.dof
+    return dict(q_prior=0.5 * (model.q_lower + model.q_upper), c1=0, c2=0, history=[], dir=np.ones(n), ntypes=0)
+
+
+def sh_blend(model, t, li, q, dq, frames1, M, Minv, N_prec, Jp, U, s, V, k, ns, st):
+    """updateTaskModel in the blending / fully singular branches with the handling strategy enforced (:83-121, 146-228) + classifySingularity
+    (:230-295).  Returns None when the task is fully non-singular (after updating the handler state like :237-243)."""
+    n = model.dof
+    if st is None:
+        st = sh_state_new(model)
+    if st["ntypes"] == 0 or st["c2"] > st["c1"]:                     # :232-235
+        st["q_prior"] = q.copy()
+    if ns == k:                                                      # no singular directions: :238-244
+        st["ntypes"], st["history"], st["c1"], st["c2"] = 0, [], 0, 0
+        return None
+    U_s, V_s = U[:, ns:k], V[:, ns:k]
+    alpha = 0.0 if ns == 0 else float(np.clip((s[ns] / s[0] - t["s_min"]) / (t["s_max"] - t["s_min"]), 0.0, 1.0))
+    J_s = U_s.T @ Jp
+    A_s = J_s @ Minv @ J_s.T
+    Lam_s = np.linalg.pinv(A_s) if ns == 0 else np.linalg.inv(A_s)   # :97-98 / :117
+    out = dict(blend=True, alpha=alpha, U_s=U_s, V_s=V_s, J_s=J_s, ns=ns)
+    Mb_inv = np.linalg.inv(bie_mass(M, t["bie_threshold"]))
+    dec = t["decoupling"]
+    mod = lambda Jx, Lam: Lam if dec == FULL_DYNAMIC_DECOUPLING else (np.eye(Jx.shape[0]) if dec == IMPEDANCE else np.linalg.inv(Jx @ Mb_inv @ Jx.T))
+    if ns == 0:                                                      # fully singular: :149-151 _N = N_prec, torques 0 (:316-317)
+        out.update(N=N_prec.copy(), U_ns=None)
+    else:
+        U_ns = U[:, :ns]
+        J_ns = U_ns.T @ Jp
+        Lam_ns, _, N_ns = op_space_matrices(J_ns, Minv)
+        Jpp = V_s.T @ N_ns @ N_prec                                  # :153
+        Lam_js, _, N_js = op_space_matrices(Jpp, Minv)
+        out.update(U_ns=U_ns, J_ns=J_ns, Lam_ns_mod=mod(J_ns, Lam_ns), Lam_s_mod=mod(J_s, Lam_s), Jpp=Jpp, Lam_js_mod=mod(Jpp, Lam_js),
+                   N=N_js @ N_ns)
+    # classifySingularity, :246-294
+    R0, o0 = frames1[li]
+    x0, Rc0 = o0 + R0 @ np.asarray(t["pos_in_link"]), R0 @ np.asarray(t["rot_in_link"])
+    types = []
+    for c in range(k - ns):
+        motion = 0.0
+        for sgn in (1.0, -1.0):
+            fr = fk(model, (q + sgn * SH_PERTURB * V_s[:, c])[None])
+            R1, o1 = fr[li][0][0], fr[li][1][0]
+            dx = o1 + R1 @ np.asarray(t["pos_in_link"]) - x0
+            dphi = orientation_error(R1 @ np.asarray(t["rot_in_link"]), Rc0)
+            motion = max(motion, abs(np.concatenate([dx, dphi]) @ U_s[:, c]))
+        types.append(1 if motion > SH_TYPE_1_TOL else 2)
+    st["ntypes"] = len(types)
+    if 1 in types:
+        st["history"].append(1)
+        st["c1"] += 1
+    else:
+        st["history"].append(2)
+        st["c2"] += 1
+    if len(st["history"]) > SH_BUFFER:
+        if st["history"].pop(0) == 1:
+            st["c1"] -= 1
+        else:
+            st["c2"] -= 1
+    out["st"] = st
+    return out
+
+
+def sh_blend_torques(model, t, m, q, dq, F_um, F_f, st):
+    """computeTorques in the singular branches, :310-367"""
+    n = model.dof
+    st = m["st"]
+    if m["U_ns"] is None:
+        return np.zeros(n)                                           # :316-317
+    if t["decoupling"] == IMPEDANCE:                                 # :311-313
+        return m["J_ns"].T @ (m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)
+    tau_ns = m["J_ns"].T @ (m["Lam_ns_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)
+    V_s, Jpp = m["V_s"], m["Jpp"]
+    if st["c1"] > st["c2"]:                                          # type-1 strategy: hold the entering posture, :333-336
+        unit = -SH_KP1 * (q - st["q_prior"]) - SH_KV1 * dq
+        tau_js = Jpp.T @ m["Lam_js_mod"] @ V_s.T @ unit
+    else:                                                            # type-2 strategy, :337-355
+        for i in range(n):
+            if V_s[i, 0] != 0:
+                if abs(q[i] - model.q_upper[i]) < SH_TYPE2_ANGLE:
+                    st["dir"][i] = -1
+                elif abs(q[i] - model.q_lower[i]) < SH_TYPE2_ANGLE:
+                    st["dir"][i] = 1
+        f = F_um + F_f
+        fTd = (f / np.linalg.norm(f)) @ m["U_s"][:, 0]
+        unit = st["dir"] * (abs(fTd) * SH_TYPE2_RATIO * model.effort)
+        tau_js = Jpp.T @ V_s.T @ unit + Jpp.T @ m["Lam_js_mod"] @ V_s.T @ (-SH_KV2 * dq)
+    tau_s = m["J_s"].T @ (m["Lam_s_mod"] @ m["U_s"].T @ F_um + m["U_s"].T @ F_f)   # :358-359
+    tau_s = np.where(np.isnan(tau_s), 0.0, np.clip(tau_s, -model.effort, model.effort))
+    return tau_ns + m["alpha"] * tau_s + (1 - m["alpha"]) * tau_js
+
+
 def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_comp=False,
                            torque_saturation=False, joint_limit_avoidance=False, details=None, info=None):
     """One control cycle for ONE instance, literal reference path (SVDs, explicit inverses).
@@ -525,20 +629,31 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
             Jp = J @ N_prec                                         # :264
             U, s, Vt = np.linalg.svd(Jp, full_matrices=False)       # SingularityHandler.cpp:78-81
             handling = t.get("singularity_handling", True)           # _enforce_handling_strategy, :61
+            strategies = handling and t.get("singularity_strategies", False)   # blended type-1 / type-2 strategies restated (see sh_blend)
             if k == 1:
                 raise Singular("rank-1 motion force task unsupported (SURVEY App. C-4)")
             ns = k
             if s[0] < 1e-3:
-                if handling:
+                if handling and not strategies:
                     raise Singular("fully singular")
                 ns = 0                                               # :83-98 + :316-317: the task is passed through
             else:
                 for i in range(1, k):
                     if s[i] / s[0] < t["s_max"]:
-                        if handling:
+                        if handling and not strategies:
                             raise Singular("blending region")       # :100-121: needs the blended strategies
                         ns = i                                       # handling disabled: _N = _N_ns, tau = tau_ns (:146-148, 319-330)
                         break
+            if strategies:
+                shs = None if state is None else state[len(tm)].setdefault("sh", sh_state_new(model))
+                blend = sh_blend(model, t, li, q, dq, frames1, M, Minv, N_prec, Jp, U, s, Vt.T, k, ns, shs)
+                if blend is not None:
+                    if info is not None:
+                        info["blended"] = True                       # reported as status 8
+                    blend.update(J=J, Jp=Jp, N_prec=N_prec, P=P, R=R_l @ np.asarray(t["rot_in_link"]), x=p, sv=s)
+                    tm.append(blend)
+                    N_prec = blend["N"] @ N_prec
+                    continue
             if ns < k and info is not None:
                 info["truncated"] = True                             # reported as status 2
             if ns == 0:
@@ -656,7 +771,9 @@ def controller_step_single(model, tasks, q, dq, goals, *, state=None, gravity_co
                 st["int_pos"], st["int_ori"] = ipos, iori
             F_um = np.concatenate([F_p, F_o])                        # :475-478
             F_f = np.concatenate([F_force + kff_f * (sig_f @ goal_force), F_moment + kff_m * (sig_m @ goal_moment)])   # :471-487
-            if m.get("skip"):
+            if m.get("blend"):
+                tt = sh_blend_torques(model, t, m, q, dq, F_um, F_f, None if st is None else st.get("sh"))
+            elif m.get("skip"):
                 tt = np.zeros(n)
             else:
                 tt = m["J_ns"].T @ (m["Lam_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)  # SH.cpp:307-309
@@ -714,6 +831,8 @@ def controller_step(model, tasks, q, dq, goals, **kw):
             tau[b] = controller_step_single(model, tasks, q[b], dq[b], [g[b] for g in goals], info=info, **kw)
             if info.get("truncated"):
                 status[b] = 2   # singularity handling disabled: a task was reduced to its non-singular subspace
+            if info.get("blended"):
+                status[b] |= 8  # a blended singularity strategy is active
         except Singular:
             status[b] = 1
     return tau, status
