@@ -60,7 +60,8 @@ enum {
 	SAIP_INSTANCE_OK = 0,
 	SAIP_INSTANCE_SINGULAR = 1,       /* left SingularityHandler's non-singular branch with the handling strategy enabled: torques = NaN */
 	SAIP_INSTANCE_TRUNCATED = 2,      /* handling disabled: a motion-force task was reduced to its non-singular subspace (or passed through) */
-	SAIP_INSTANCE_POPC_OVERFLOW = 4   /* the passivity observer's energy window exceeded the 1024 samples kept on the device */
+	SAIP_INSTANCE_POPC_OVERFLOW = 4,  /* the passivity observer's energy window exceeded the 1024 samples kept on the device */
+	SAIP_INSTANCE_BLENDED = 8         /* a motion-force task ran the blended type-1 / type-2 singularity strategies (valid torques) */
 };
 
 /* One URDF link + the joint that attaches it to its parent (what sai-model/sai-urdfreader read from a URDF).
@@ -136,6 +137,22 @@ saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold
  * Implemented: such instances finish with valid torques and status 2 (flagged by the lane kernel, recomputed by the general
  * kernel launched behind it as a device-side slow path). */
 saip_status saip_batch_set_singularity_handling(saip_batch*, int task, int enabled);
+/* Blended singularity strategies of SingularityHandler (updateTaskModel :100-121, 146-228; classifySingularity :230-295;
+ * computeTorques :310-367) for instances inside the bounds (s_min, s_max), with the handling strategy enabled.  Off by default
+ * (such instances are then flagged, see above).  On: the task is split into its non-singular and singular directions, the
+ * singular ones are blended out by alpha = (sigma_s/sigma_0 - s_min)/(s_max - s_min) in favour of a joint strategy (type 1: hold
+ * the entering posture, kp 50 / kv 14; type 2: constant torque 1e-2 x the torque limit along the open direction, damping kv 5),
+ * chosen by the majority of the last 200 classifications; status bit 8.  Per-instance handler state (entering posture, type
+ * window, type-2 direction) lives on the device and is reset by this call.  Conventions where the reference depends on the sign
+ * its SVD happens to return are fixed as DESIGN.md states; sigma_0 < 1e-3 or sigma_min/sigma_0 < 1e-6 -> status 1. */
+saip_status saip_batch_set_singularity_strategies(saip_batch*, int task, int enabled);
+/* MotionForceTask::setSingularityHandlingGains (.h:749 -> SingularityHandler.h:119; defaults 50, 14, 5) */
+saip_status saip_batch_set_singularity_gains(saip_batch*, int task, double kp_type_1, double kv_type_1, double kv_type_2);
+/* MotionForceTask::handleAllSingularitiesAsType1 (.h:698 -> SingularityHandler.h:131) */
+saip_status saip_batch_set_all_singularities_type1(saip_batch*, int task, int flag);
+/* MotionForceTask::setType1Posture (.h:707 -> SingularityHandler.h:140): the posture the type-1 strategy holds, q_des[dof]
+ * (per_instance = 0) or [B][dof] (1).  As in the reference it lasts until an instance next ENTERS a singular region (:232-235). */
+saip_status saip_batch_set_type1_posture(saip_batch*, int task, const double* q_des, int per_instance);
 /* MotionForceTask::setSingularityHandlingBounds (.h:736) */
 saip_status saip_batch_set_singularity_bounds(saip_batch*, int task, double s_min, double s_max);
 /* disableInternalOtg / enableInternalOtg* (MotionForceTask.h:423, JointTask.h:323).  The reference default is ENABLED.

@@ -181,6 +181,15 @@ public:
 	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void enableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 1); }); }    // MotionForceTask.h:715
 	void disableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 0); }); }  // :723
+	// blended type-1 / type-2 strategies for instances inside the singularity bounds (default: such instances are flagged)
+	void setSingularityStrategies(bool enabled) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_strategies(b, id, enabled ? 1 : 0); }); }
+	void setSingularityHandlingGains(double kp_type_1, double kv_type_1, double kv_type_2) {  // MotionForceTask.h:749
+		cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_gains(b, id, kp_type_1, kv_type_1, kv_type_2); });
+	}
+	void handleAllSingularitiesAsType1(bool flag) { cfg([=](saip_batch* b, int id) { return saip_batch_set_all_singularities_type1(b, id, flag ? 1 : 0); }); }  // :698
+	void setType1Posture(const std::vector<double>& q_des) {  // :707, one posture for every instance
+		cfg([q_des](saip_batch* b, int id) { return saip_batch_set_type1_posture(b, id, q_des.data(), 0); });
+	}
 	void setSingularityHandlingBounds(double s_min, double s_max) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_bounds(b, id, s_min, s_max); }); }
 	// MotionForceTask.cpp:510-523 (defaults MotionForceTask.h:68-71); the jerk-limited variant throws (not on the device)
 	void enableInternalOtgAccelerationLimited(double max_linear_velocity = 0.3, double max_linear_acceleration = 2.0,

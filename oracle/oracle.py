@@ -40,6 +40,9 @@ def lib():
         L.orc_set_timestep.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_set_singularity_handling.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_set_singularity_strategies.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_singularity_gains.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_set_all_singularities_type1.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_type1_posture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
         L.orc_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_goal_size.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_mf_force_spaces.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double]
@@ -103,6 +106,9 @@ class Oracle:
                 L.orc_set_singularity_bounds(self._h, tid, t["s_min"], t["s_max"])
                 L.orc_set_singularity_handling(self._h, tid, int(bool(t.get("singularity_handling", True))))
                 L.orc_set_singularity_strategies(self._h, tid, int(bool(t.get("singularity_strategies", False))))
+                if "sh_gains" in t:
+                    L.orc_set_singularity_gains(self._h, tid, *map(float, t["sh_gains"]))
+                L.orc_set_all_singularities_type1(self._h, tid, int(bool(t.get("sh_all_type1", False))))
                 fa, ma = _d(_vec3(t.get("force_axis", [0, 0, 1]))), _d(_vec3(t.get("moment_axis", [0, 0, 1])))
                 L.orc_set_mf_force_spaces(self._h, tid, int(t.get("force_dim", 0)), fa[1], int(t.get("moment_dim", 0)), ma[1],
                                           int(bool(t.get("param_in_compliant_frame", False))), float(t.get("kv_force", 10.0)), float(t.get("kv_moment", 10.0)))
@@ -141,6 +147,11 @@ class Oracle:
 
     def reset_state(self):
         lib().orc_reset_state(self._h)
+
+    def set_type1_posture(self, task, q_des):
+        """setType1Posture (SingularityHandler.h:140); q_des (n,) or (B,n)"""
+        q = np.ascontiguousarray(q_des, dtype=np.float64)
+        lib().orc_set_type1_posture(self._h, task, q.ctypes.data_as(C.POINTER(C.c_double)), int(q.ndim == 2))
 
     def step(self, q, dq, goals, nthreads: int = 1):
         """q,dq (B,n); goals[t] (B,goal_size). Returns tau (B,n), status (B,)."""

@@ -11,8 +11,10 @@
  *   RobotController.cpp:68-118                 -> orc_instance_cycle()
  *   tasks/MotionForceTask.cpp:247-268          -> mf_update_task_model()
  *   tasks/MotionForceTask.cpp:270-509,892-971  -> mf_compute_torques()
- *   tasks/SingularityHandler.cpp:75-228        -> sh_update_task_model()   (non-singular branch; others flagged)
- *   tasks/SingularityHandler.cpp:297-309       -> sh_compute_torques()
+ *   tasks/SingularityHandler.cpp:75-228        -> sh_update_task_model()   (non-singular branch; truncated branch with the handling disabled)
+ *   tasks/SingularityHandler.cpp:100-121,146-228,230-295 -> sh_blend_update()  (blended strategies + classifySingularity, opt-in; three stated
+ *                                                 conventions where the reference depends on SVD signs / an unassigned member)
+ *   tasks/SingularityHandler.cpp:297-367       -> tail of mf_compute_torques()
  *   tasks/JointTask.cpp:218-283, 285-356       -> jt_update_task_model(), jt_compute_torques()
  *   tasks/JointLimitAvoidanceTask.cpp:16-36, 124-421 -> jla_update_limit_status(), jla_update_task_model(), jla_compute_torques()
  *   tasks/MotionForceTask.cpp:28,55-87,143-168 -> orc_add_motion_force_task() (partial task projector)
@@ -57,7 +59,8 @@ typedef struct {
 	double kp_pos[3], kv_pos[3], ki_pos[3], kp_ori[3], kv_ori[3], ki_ori[3];
 	double s_min, s_max, s_abs_tol;
 	int sing_handling;     /* SingularityHandler::_enforce_handling_strategy (default true, SingularityHandler.cpp:61) */
-	int sing_strategies;   /* blended type-1 / type-2 strategies restated (sh_blend_*); otherwise such instances are flagged */
+	int sing_strategies, sh_force_type1;
+	double sh_kp1, sh_kv1, sh_kv2; /* setSingularityHandlingGains, SingularityHandler.h:119 */   /* blended type-1 / type-2 strategies restated (sh_blend_*); otherwise such instances are flagged */
 	double kv_force, kv_moment, lin_sat, ang_sat; /* MotionForceTask.h:50-66 */
 	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
 	/* closed-loop force / moment control, MotionForceTask.h:50-60 */
@@ -460,9 +463,6 @@ static double popc_step(popc_state* s, double dt, double kff, double kv, const d
 
 /* SingularityHandler state that persists across cycles (SingularityHandler.h:197-230), per instance and motion-force task */
 #define SH_BUFFER 200
-#define SH_KP1 50.0
-#define SH_KV1 14.0
-#define SH_KV2 5.0
 #define SH_TYPE2_RATIO 1e-2
 #define SH_TYPE2_ANGLE (5 * M_PI / 180)
 typedef struct {
@@ -841,8 +841,8 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 		mm(tm->Lambda_ns_modified, a, f, ns, ns, 1);
 		for (int i = 0; i < ns; i++) f[i] += b[i];
 		mTm(tm->projected_jacobian_ns, f, tns, ns, n, 1);
-		if (st->c1 > st->c2) { /* type-1 strategy: hold the entering posture, :333-336 */
-			for (int i = 0; i < n; i++) unit[i] = -SH_KP1 * (rs->q[i] - st->q_prior[i]) - SH_KV1 * rs->dq[i];
+		if (st->c1 > st->c2 || t->sh_force_type1) { /* type-1 strategy: hold the entering posture, :329-336 */
+			for (int i = 0; i < n; i++) unit[i] = -t->sh_kp1 * (rs->q[i] - st->q_prior[i]) - t->sh_kv1 * rs->dq[i];
 			mTm(tm->V_s, unit, u, n, nsg, 1);
 			mm(tm->Lambda_js_mod, u, lu, nsg, nsg, 1);
 			mTm(tm->Jpp, lu, tjs, nsg, n, 1);
@@ -859,7 +859,7 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 			for (int i = 0; i < n; i++) unit[i] = st->dir[i] * (fabs(fTd) * SH_TYPE2_RATIO * c->effort[i]);
 			mTm(tm->V_s, unit, u, n, nsg, 1);
 			mTm(tm->Jpp, u, tjs, nsg, n, 1);
-			for (int i = 0; i < n; i++) unit[i] = -SH_KV2 * rs->dq[i];
+			for (int i = 0; i < n; i++) unit[i] = -t->sh_kv2 * rs->dq[i];
 			mTm(tm->V_s, unit, u, n, nsg, 1);
 			mm(tm->Lambda_js_mod, u, lu, nsg, nsg, 1);
 			mTm(tm->Jpp, lu, unit, nsg, n, 1);
@@ -1292,6 +1292,7 @@ int orc_add_motion_force_task(orc_ctx* c, int link, const double* pos_in_link, c
 	t->s_min = 6e-3; t->s_max = 6e-2; /* MotionForceTask.cpp:197 */
 	t->s_abs_tol = 1e-3;              /* SingularityHandler.cpp:11 */
 	t->sing_handling = 1;             /* :61 */
+	t->sh_kp1 = 50.0; t->sh_kv1 = 14.0; t->sh_kv2 = 5.0; /* KP_TYPE_1, KV_TYPE_1, KV_TYPE_2, :17-19 */
 	t->kv_force = 10.0; t->kv_moment = 10.0; /* MotionForceTask.h:51,54 */
 	t->lin_sat = 0.3; t->ang_sat = M_PI / 3;  /* :63-64 */
 	t->force_axis[2] = 1.0; t->moment_axis[2] = 1.0;
@@ -1339,6 +1340,19 @@ void orc_set_singularity_handling(orc_ctx* c, int task, int enabled) { c->task[t
 void orc_set_singularity_strategies(orc_ctx* c, int task, int enabled) {
 	c->task[task].sing_strategies = enabled != 0;
 	c->state_B = 0; /* state is re-sized on the next step */
+}
+void orc_set_singularity_gains(orc_ctx* c, int task, double kp1, double kv1, double kv2) {
+	c->task[task].sh_kp1 = kp1; c->task[task].sh_kv1 = kv1; c->task[task].sh_kv2 = kv2;
+}
+void orc_set_all_singularities_type1(orc_ctx* c, int task, int flag) { c->task[task].sh_force_type1 = flag != 0; }
+/* setType1Posture, SingularityHandler.h:140: q_des [B][n] or [n]; before the first cycle the state does not exist yet and the posture would be
+ * overwritten on entering a singular region anyway (:232-235) */
+void orc_set_type1_posture(orc_ctx* c, int task, const double* q_des, int per_instance) {
+	if (!c->sh) return;
+	for (int b = 0; b < c->state_B; b++) {
+		sh_state* st = (sh_state*)c->sh + (size_t)b * MAXT + task;
+		for (int i = 0; i < c->n; i++) st->q_prior[i] = per_instance ? q_des[(size_t)b * c->n + i] : q_des[i];
+	}
 }
 void orc_set_timestep(orc_ctx* c, int task, double dt) { c->task[task].dt = dt; }
 int orc_set_options(orc_ctx* c, int gravity_comp, int jla, int torque_sat) {

@@ -406,6 +406,21 @@ class MotionForceTask(_Task):
         """near-singular instances then use the non-singular part of the task only (status 2) instead of being flagged (status 1)"""
         self._cfg("saip_batch_set_singularity_handling", 0)
 
+    def setSingularityStrategies(self, enabled=True):
+        """blended type-1 / type-2 strategies of SingularityHandler for instances inside the singularity bounds (status bit 8);
+        off (default): such instances are flagged (status 1)"""
+        self._cfg("saip_batch_set_singularity_strategies", int(bool(enabled)))
+
+    def setSingularityHandlingGains(self, kp_type_1, kv_type_1, kv_type_2):  # MotionForceTask.h:749
+        self._cfg("saip_batch_set_singularity_gains", float(kp_type_1), float(kv_type_1), float(kv_type_2))
+
+    def handleAllSingularitiesAsType1(self, flag):  # MotionForceTask.h:698
+        self._cfg("saip_batch_set_all_singularities_type1", int(bool(flag)))
+
+    def setType1Posture(self, q_des):  # MotionForceTask.h:707; (dof,) for every instance or (B, dof)
+        q = np.ascontiguousarray(q_des, dtype=np.float64)
+        self._cfg("saip_batch_set_type1_posture", q.ctypes.data_as(C.POINTER(C.c_double)), int(q.ndim == 2))
+
     def setSingularityHandlingBounds(self, s_min, s_max):  # MotionForceTask.h:736
         self._cfg("saip_batch_set_singularity_bounds", float(s_min), float(s_max))
 
@@ -674,6 +689,12 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
             o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
             if not t.get("singularity_handling", True):
                 o.disableSingularityHandling()
+            if t.get("singularity_strategies", False):
+                o.setSingularityStrategies(True)
+            if "sh_gains" in t:
+                o.setSingularityHandlingGains(*t["sh_gains"])
+            if t.get("sh_all_type1", False):
+                o.handleAllSingularitiesAsType1(True)
             if t.get("cl_force") or t.get("cl_moment"):
                 o.setForceControlParameters(t.get("kff_force", 0.95), t.get("kff_moment", 0.95), t.get("max_force_fb", 20.0), t.get("max_moment_fb", 10.0))
                 o.setControlToSensorTransform(t.get("Rcs", np.eye(3)), t.get("tcs", np.zeros(3)))

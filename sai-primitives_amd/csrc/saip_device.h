@@ -38,6 +38,17 @@ struct ModelDev {
 };
 
 enum { TASK_JOINT = 2, TASK_MOTION_FORCE = 3 };
+
+// SingularityHandler state of one instance of one motion-force task with the blended strategies on (SingularityHandler.h:226-243):
+// entering posture, type-2 torque direction (bit i set = -1), type counters and their 200-cycle window.  Zero-initialised.
+enum { SH_BUFFER = 200 };
+struct ShState {
+	double q_prior[SAIP_MAXN];
+	unsigned dir_neg;
+	int ntypes, c1, c2, head, size;
+	unsigned char hist[SH_BUFFER];
+};
+
 enum { DEC_FULL = 0, DEC_BIE = 1, DEC_IMPEDANCE = 2 };
 
 struct TaskDev {
@@ -51,7 +62,10 @@ struct TaskDev {
 	int goal_comps;
 	int bm_identity;   // motion force: Bm == I6 (full task)
 	int sing_handling; // motion force: SingularityHandler::_enforce_handling_strategy (1 = reference default)
+	int sing_strategies; // motion force: blended type-1 / type-2 strategies on the device (general kernel) instead of flagging
+	int sh_force_type1;  // handleAllSingularitiesAsType1 (SingularityHandler.h:131)
 	double dt, bie_threshold, s_min, s_max, s_abs_tol;
+	double sh_kp1, sh_kv1, sh_kv2;  // setSingularityHandlingGains (SingularityHandler.h:119; defaults 50, 14, 5)
 	double cert_kroot; // k^(-1/8): lower/upper bound ratio of the trace-power bound on lambda_max (singular-value certificate)
 	double pos[3];     // control point in the body frame
 	double rot[9];     // control frame rotation in the body frame
@@ -76,6 +90,7 @@ struct TaskDev {
 	double* goal;      // [goal_comps][ld]
 	double* integ;     // [6 or m][ld]
 	double* diag_N;    // optional [n*n][ld] task nullspace dump (diagnostic variant), else nullptr
+	ShState* sh;       // [B] handler states when sing_strategies, else nullptr
 	double* popc;      // [7 + popc_cap][ld] passivity observer state: PO, E_correction, Rc, sum |vcl|^2, counter, ring head, ring size, ring
 };
 

@@ -474,6 +474,9 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_max = 6e-2;
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
 	T.dev.sing_handling = 1; // _enforce_handling_strategy = true, SingularityHandler.cpp:61
+	T.dev.sh_kp1 = 50.0;     // KP_TYPE_1, KV_TYPE_1, KV_TYPE_2, SingularityHandler.cpp:17-19
+	T.dev.sh_kv1 = 14.0;
+	T.dev.sh_kv2 = 5.0;
 	T.integ_rows = 12;  // position 3, orientation 3, force 3, moment 3
 	T.dev.kp_force = T.dev.kp_moment = 0.7;  // MotionForceTask.h:50-59
 	T.dev.ki_force = T.dev.ki_moment = 1.3;
@@ -753,6 +756,62 @@ extern "C" saip_status saip_batch_set_singularity_handling(saip_batch* b, int t,
 	if (st) return st;
 	b->tasks[t].dev.sing_handling = enabled ? 1 : 0;
 	b->config_dirty = true;
+	return SAIP_OK;
+}
+// SingularityHandler state of every instance back to "never singular" (SingularityHandler.cpp:55-63); allocates on first use
+static saip_status sh_reinit(saip_batch* b, TaskHost& T) {
+	if (!T.dev.sh) {
+		saip_status st = dev_alloc(b, &T.dev.sh, (size_t)b->ld);
+		if (st) return st;
+	}
+	HIP_TRY(hipMemsetAsync(T.dev.sh, 0, (size_t)b->ld * sizeof(saip::ShState), b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_singularity_strategies(saip_batch* b, int t, int enabled) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_singularity_strategies");
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	T.dev.sing_strategies = enabled ? 1 : 0;
+	b->config_dirty = true;
+	if (enabled && b->finalized && has_device(b)) {
+		if ((st = need_ready(b, "saip_batch_set_singularity_strategies"))) return st;
+		return sh_reinit(b, T);
+	}
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_singularity_gains(saip_batch* b, int t, double kp_type_1, double kv_type_1, double kv_type_2) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_singularity_gains");
+	if (st) return st;
+	b->tasks[t].dev.sh_kp1 = kp_type_1;
+	b->tasks[t].dev.sh_kv1 = kv_type_1;
+	b->tasks[t].dev.sh_kv2 = kv_type_2;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_all_singularities_type1(saip_batch* b, int t, int flag) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_all_singularities_type1");
+	if (st) return st;
+	b->tasks[t].dev.sh_force_type1 = flag ? 1 : 0;
+	b->config_dirty = true;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_set_type1_posture(saip_batch* b, int t, const double* q_des, int per_instance) {
+	saip_status st = need_type(b, t, saip::TASK_MOTION_FORCE, "saip_batch_set_type1_posture");
+	if (st) return st;
+	if (!q_des) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_set_type1_posture: null posture");
+	TaskHost& T = b->tasks[t];
+	// _q_prior is overwritten with the current posture whenever an instance enters a singular region (SingularityHandler.cpp:232-235):
+	// the call only matters for instances that are inside one, which needs the device state
+	if (!T.dev.sing_strategies || !T.dev.sh || !b->finalized || !has_device(b)) return SAIP_OK;
+	if ((st = need_ready(b, "saip_batch_set_type1_posture"))) return st;
+	const int n = b->model->n;
+	std::vector<double> host((size_t)b->B * n);
+	for (int i = 0; i < b->B; i++)
+		for (int j = 0; j < n; j++) host[(size_t)i * n + j] = per_instance ? q_des[(size_t)i * n + j] : q_des[j];
+	HIP_TRY(hipMemcpy2DAsync(T.dev.sh, sizeof(saip::ShState), host.data(), (size_t)n * sizeof(double), (size_t)n * sizeof(double), (size_t)b->B,
+							 hipMemcpyHostToDevice, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_set_internal_otg(saip_batch* b, int t, int enabled) {
@@ -1109,6 +1168,11 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 			saip_status st = ensure_otg(b, T);
 			if (st) return st;
 		}
+		if (T.dev.type == saip::TASK_MOTION_FORCE && T.dev.sing_strategies && !T.dev.sh) {  // enabled before finalize
+			saip_status st = sh_reinit(b, T);
+			if (st) return st;
+			b->config_dirty = true;
+		}
 		if (T.dev.type == saip::TASK_MOTION_FORCE && T.dev.popc_enabled && !T.dev.popc) {  // enabled before finalize
 			saip_status st = popc_reinit(b, T);
 			if (st) return st;
@@ -1213,11 +1277,12 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
 			b->kernel_name = "saip_cycle_lane";
 			// slow path: instances the lane kernel flagged (outside the fully non-singular branch) are recomputed by the general kernel
-			// when a task can handle them there (singularity handling disabled: the task is reduced to its non-singular subspace);
+			// when a task can handle them there (singularity handling disabled: the task is reduced to its non-singular subspace;
+			// blended strategies switched on: type-1 / type-2 handling);
 			// workgroups of unflagged instances exit at once, no host round trip
 			bool slow = false;
 			for (auto& T : b->tasks)
-				if (T.dev.type == saip::TASK_MOTION_FORCE && !T.dev.sing_handling) slow = true;
+				if (T.dev.type == saip::TASK_MOTION_FORCE && (!T.dev.sing_handling || T.dev.sing_strategies)) slow = true;
 			if (slow) {
 				P.only_flagged = 1;
 				hipError_t e2 = saip::launch_cycle_wg(P, b->stream);

@@ -73,7 +73,14 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	const int tid = threadIdx.x;
 	const int b = blockIdx.x;
 	if (b >= P.B) return;
-	if (P.only_flagged && P.status[b] == 0) return;  // slow-path launch behind the lane kernel (workgroup-uniform)
+	if (P.only_flagged && P.status[b] == 0) {  // slow-path launch behind the lane kernel (workgroup-uniform)
+		// the lane kernel found every task of this instance non-singular: SingularityHandler.cpp:238-244 for the handler states
+		if (tid < P.nt && P.tasks[tid].type == TASK_MOTION_FORCE && P.tasks[tid].sing_strategies && P.tasks[tid].sh) {
+			ShState& st = P.tasks[tid].sh[b];
+			st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
+		}
+		return;
+	}
 	const int n = P.n;
 	const ModelDev& md = *P.model;
 
@@ -252,6 +259,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 
 	bool singular = false;
 	bool truncated = false;  // some motion-force task was reduced to its non-singular subspace (singularity handling disabled)
+	bool blended = false;    // some motion-force task ran the blended type-1 / type-2 singularity strategies
 	// ---------------------------------------------------------------- task hierarchy
 	for (int t = 0; t < P.nt; t++) {
 		const TaskDev& tk = P.tasks[t];
@@ -260,6 +268,8 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		bool empty = false;  // JointTask with no controllable dof left
 		bool u_identity = true;
 		bool mf_trunc = false;  // this motion-force task acts on the top-r left singular directions only; W[3] = their k x r coordinates
+		bool blend = false;     // this motion-force task has r < k non-singular directions and the blended strategies are on
+		const bool strategies = tk.type == TASK_MOTION_FORCE && tk.sing_handling && tk.sing_strategies && tk.sh;
 		const int gs = tk.goal_comps;
 		for (int e = tid; e < gs; e += T) sm.goal[e] = tk.goal[(size_t)e * P.ld + b];
 
@@ -355,12 +365,12 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				SYNC();
 				r = k;
 				if (!certified) {  // exact path: singular values from the Gram eigenvalues (SingularityHandler.cpp:78-121)
-					jacobi_eig<T>(sm.W[1], tk.sing_handling ? nullptr : sm.W[2], k, LD, sm.cs, &sm.flag, tid);
+					jacobi_eig<T>(sm.W[1], (tk.sing_handling && !strategies) ? nullptr : sm.W[2], k, LD, sm.cs, &sm.flag, tid);
 					double lmax = 0.0;
 					for (int i = 0; i < k; i++) lmax = fmax(lmax, sm.W[1][i * LD + i]);
 					double s0 = sqrt(lmax);
-					if (tk.sing_handling) {
-						// handling strategy enforced (reference default): the blended / singular strategies are not on the device -> flagged
+					if (tk.sing_handling && !strategies) {
+						// handling strategy enforced (reference default) without the blended strategies switched on -> flagged
 						sing = !(s0 >= tk.s_abs_tol);
 						for (int i = 0; i < k; i++) {
 							double si = sqrt(fmax(sm.W[1][i * LD + i], 0.0));
@@ -391,7 +401,16 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 						}
 						SYNC();
 						r = sm.rank;
-						if (r < k) {
+						if (strategies) {
+							if (r < k) {
+								// V_s = Jp^T U_s / sigma_s needs sigma_s well above the rounding noise of the Gram eigenvalues; a fully singular
+								// task (sigma_0 < 1e-3) or sigma_min / sigma_0 < 1e-6 is reported as singular instead
+								double lmin = lmax;
+								for (int i = 0; i < k; i++) lmin = fmin(lmin, sm.W[1][i * LD + i]);
+								if (r == 0 || !(lmin >= 1e-12 * lmax)) sing = true;
+								else blend = true;
+							}
+						} else if (r < k) {
 							truncated = true;
 							if (r == 0) {
 								empty = true;
@@ -414,6 +433,10 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				}
 			}
 			if (sing) singular = true;
+			if (strategies && !blend && tid == 0) {  // no singular directions: SingularityHandler.cpp:238-244
+				ShState& st = tk.sh[b];
+				st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
+			}
 			SYNC();
 		} else {
 			const int m = tk.m;
@@ -558,22 +581,26 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		double* Lam = sm.W[2];
 		double* Lmod = sm.W[7];
 		double* Nt = sm.W[6];
-		if (!empty && !singular) {
-			// operationalSpaceMatrices(Jh): Lambda = (Jh M^-1 Jh^T)^-1, N = I - M^-1 Jh^T Lambda Jh
-			gemm<T>(sm.W[0], LD, Jh, LD, 1, sm.Minv, LD, 1, r, n, n, tid);  // T1 = Jh Minv
+		// operationalSpaceMatrices(J) (rows x n): Lambda = (J M^-1 J^T)^-1 -> Lam, N = I - M^-1 J^T Lambda J -> Nt (when asked for),
+		// Lambda_modified by the task's decoupling type -> Lmod (SingularityHandler.cpp:175-193).  Scratch: W[0], W[1], W[5], W[6].
+		auto osm = [&](const double* J, int rows, bool want_N) {
+			gemm<T>(sm.W[0], LD, J, LD, 1, sm.Minv, LD, 1, rows, n, n, tid);  // T1 = J Minv
 			SYNC();
-			gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, Jh, 1, LD, r, n, r, tid);  // A = T1 Jh^T
+			gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, J, 1, LD, rows, n, rows, tid);  // A = T1 J^T
 			SYNC();
-			spd_inverse<T>(sm.W[1], Lam, sm.W[5], sm.W[6], sm.dv, r, LD, tid);
-			gemm<T>(sm.W[5], LD, Lam, LD, 1, sm.W[0], LD, 1, r, r, n, tid);  // T2 = Lambda T1 = Jbar^T
-			SYNC();
-			gemm<T>(Nt, LD, sm.W[5], 1, LD, Jh, LD, 1, n, r, n, tid, GEMM_I_MINUS);  // N = I - T2^T Jh
-			SYNC();
+			spd_inverse<T>(sm.W[1], Lam, sm.W[5], sm.W[6], sm.dv, rows, LD, tid);
+			if (want_N) {
+				gemm<T>(sm.W[5], LD, Lam, LD, 1, sm.W[0], LD, 1, rows, rows, n, tid);  // T2 = Lambda T1 = Jbar^T
+				SYNC();
+				gemm<T>(Nt, LD, sm.W[5], 1, LD, J, LD, 1, n, rows, n, tid, GEMM_I_MINUS);  // N = I - T2^T J
+				SYNC();
+			}
+			Lmod = sm.W[7];
 			if (tk.decoupling == DEC_FULL) {
 				Lmod = Lam;
 			} else if (tk.decoupling == DEC_IMPEDANCE) {
-				for (int e = tid; e < r * r; e += T) {
-					int i = e / r, j = e - i * r;
+				for (int e = tid; e < rows * rows; e += T) {
+					int i = e / rows, j = e - i * rows;
 					Lmod[i * LD + j] = (i == j) ? 1.0 : 0.0;
 				}
 				SYNC();
@@ -589,12 +616,238 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					spd_inverse<T>(sm.W[1], sm.MBinv, sm.W[0], sm.W[5], sm.dv, n, LD, tid);
 					cur_bie_thr = tk.bie_threshold;
 				}
-				gemm<T>(sm.W[0], LD, Jh, LD, 1, sm.MBinv, LD, 1, r, n, n, tid);
+				gemm<T>(sm.W[0], LD, J, LD, 1, sm.MBinv, LD, 1, rows, n, n, tid);
 				SYNC();
-				gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, Jh, 1, LD, r, n, r, tid);
+				gemm<T>(sm.W[1], LD, sm.W[0], LD, 1, J, 1, LD, rows, n, rows, tid);
 				SYNC();
-				spd_inverse<T>(sm.W[1], Lmod, sm.W[5], sm.W[0], sm.dv, r, LD, tid);
+				spd_inverse<T>(sm.W[1], Lmod, sm.W[5], sm.W[0], sm.dv, rows, LD, tid);
 			}
+		};
+		const bool track = (tk.has_ki || P.integ_always);
+		// MotionForceTask::computeTorques up to the task forces: F_um -> sm.Fum, F_f -> sm.Ff, their range(P) coordinates -> v0, v1
+		auto mf_law = [&]() {
+			if (tid == 0) {
+				const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3, f3, m3
+				double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
+				if (track)
+					for (int i = 0; i < 3; i++) {
+						ip[i] = tk.integ[(size_t)i * P.ld + b];
+						io[i] = tk.integ[(size_t)(3 + i) * P.ld + b];
+					}
+				// general law (velocity saturation, force/moment spaces) reduces to MotionForceTask.cpp:411-468 for the defaults
+				double ifm[6] = {0, 0, 0, 0, 0, 0};
+				const bool closed = tk.cl_force || tk.cl_moment;
+				if (closed)
+					for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * P.ld + b];
+				bool ovf = false;
+				law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, P.ld, &ovf);
+				if (ovf) sm.flag2 = 1;
+				if (closed)
+					for (int i = 0; i < 6; i++) tk.integ[(size_t)(6 + i) * P.ld + b] = ifm[i];
+				if (track)
+					for (int i = 0; i < 3; i++) {
+						tk.integ[(size_t)i * P.ld + b] = ip[i];
+						tk.integ[(size_t)(3 + i) * P.ld + b] = io[i];
+					}
+			}
+			SYNC();
+			if (tid < tk.k) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
+				double s = 0.0, s2 = 0.0;
+				for (int i = 0; i < 6; i++) {
+					s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
+					s2 = fma(tk.Bm[i * 6 + tid], sm.Ff[i], s2);
+				}
+				sm.v0[tid] = s;
+				sm.v1[tid] = s2;
+			}
+			SYNC();
+		};
+		if (blend && !singular) {
+			// ------------------------------------------------------------ blended singularity strategies, SingularityHandler.cpp:100-121,
+			// 146-228 (model), 230-295 (classification), 310-367 (torques); sign conventions as DESIGN.md states.
+			// Everything in range(P) coordinates: U (k x k, sorted by singular value) = eigenvectors of Jh Jh^T, V_s^T = diag(1/sigma_s) U_s^T Jh.
+			blended = true;
+			const int k = tk.k, ns = r, nsg = k - r;
+			ShState& st = tk.sh[b];
+			double* tns = sm.Jw;            // Jw is dead once Jb and vw exist: rows 0..4 = tau_ns, tau_s, tau_js, wA, wB
+			double* ts = sm.Jw + LD;
+			double* wA = sm.Jw + 3 * LD;
+			double* wB = sm.Jw + 4 * LD;
+			for (int e = tid; e < k * k; e += T) {
+				int i = e / k, c = e - i * k;
+				sm.W[3][i * LD + c] = sm.W[2][i * LD + sm.colidx[c]];
+			}
+			if (tid < k) sm.dv[tid] = sqrt(fmax(sm.W[1][sm.colidx[tid] * LD + sm.colidx[tid]], 0.0));
+			SYNC();
+			gemm<T>(sm.W[0], LD, sm.W[3], 1, LD, Jh, LD, 1, k, k, n, tid);  // rows 0..ns-1: J_ns = U_ns^T Jh, rows ns..k-1: J_s = U_s^T Jh
+			SYNC();
+			for (int e = tid; e < k * n; e += T) {
+				int i = e / n, j = e - i * n;
+				Jh[i * LD + j] = sm.W[0][i * LD + j];
+			}
+			const double alpha = fmin(fmax((sm.dv[ns] / sm.dv[0] - tk.s_min) / (tk.s_max - tk.s_min), 0.0), 1.0);  // :114-115
+			mf_law();
+			{
+				double s = 0.0, s2 = 0.0;
+				if (tid < k)
+					for (int i = 0; i < k; i++) {
+						s = fma(sm.W[3][i * LD + tid], sm.v0[i], s);
+						s2 = fma(sm.W[3][i * LD + tid], sm.v1[i], s2);
+					}
+				SYNC();
+				if (tid < k) {
+					sm.v2[tid] = s;   // U^T F_um
+					sm.v4[tid] = s2;  // U^T F_f
+				}
+				SYNC();
+			}
+			double fn2 = 0.0;
+			for (int i = 0; i < 6; i++) fn2 = fma(sm.Fum[i] + sm.Ff[i], sm.Fum[i] + sm.Ff[i], fn2);
+			const double fTd = (sm.v2[ns] + sm.v4[ns]) / sqrt(fn2);  // :346-347
+			// non-singular part (:104-112): Lambda_ns, N_ns, tau_ns (:321-322)
+			osm(Jh, ns, true);
+			if (tid < ns) {
+				double s = sm.v4[tid];
+				for (int i = 0; i < ns; i++) s = fma(Lmod[tid * LD + i], sm.v2[i], s);
+				sm.v3[tid] = s;
+			}
+			SYNC();
+			for (int j = tid; j < n; j += T) {
+				double s = 0.0;
+				for (int c = 0; c < ns; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+				tns[j] = s;
+			}
+			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);  // X = N_ns N_prec
+			SYNC();
+			// singular part (:116-121): Lambda_s, tau_s clamped to the torque limits (:358-366)
+			osm(Jh + ns * LD, nsg, false);
+			if (tid < nsg) {
+				double s = sm.v4[ns + tid];
+				for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], sm.v2[ns + i], s);
+				sm.v3[tid] = s;
+			}
+			SYNC();
+			for (int j = tid; j < n; j += T) {
+				double s = 0.0;
+				for (int c = 0; c < nsg; c++) s = fma(Jh[(ns + c) * LD + j], sm.v3[c], s);
+				const double lim = md.effort[j];
+				ts[j] = (s != s) ? 0.0 : fmin(fmax(s, -lim), lim);
+			}
+			// classifySingularity (:230-295): task-space motion along u_c of the control frame at q +- 5 v_c
+			double* qp = sm.W[5];  // [2 nsg][n] perturbed postures (W[5] and W[6] are contiguous)
+			for (int e = tid; e < 2 * nsg * n; e += T) {
+				int pidx = e / n, j = e - pidx * n, c = pidx >> 1;
+				qp[e] = sm.q[j] + ((pidx & 1) ? -5.0 : 5.0) * (Jh[(ns + c) * LD + j] / sm.dv[ns + c]);
+			}
+			if (tid < n) {  // :232-235 with the counters of the previous cycle
+				double qpr = st.q_prior[tid];
+				if (st.ntypes == 0 || st.c2 > st.c1) {
+					qpr = sm.q[tid];
+					st.q_prior[tid] = qpr;
+				}
+				sm.v0[tid] = qpr;
+			}
+			SYNC();
+			if (tid < 2 * nsg) {
+				double x1[3], R1[9], w6[6] = {0, 0, 0, 0, 0, 0};
+				fk_control_frame(md, tk, qp + tid * n, 1, 0, x1, R1);
+				for (int e = 0; e < 3; e++) w6[e] = x1[e] - sm.xp[e];
+				for (int col = 0; col < 3; col++) {  // orientation error of R1 with respect to Rc
+					const double a0 = sm.Rc[col], a1 = sm.Rc[3 + col], a2 = sm.Rc[6 + col];
+					const double b0 = R1[col], b1 = R1[3 + col], b2 = R1[6 + col];
+					w6[3] -= 0.5 * (a1 * b2 - a2 * b1);
+					w6[4] -= 0.5 * (a2 * b0 - a0 * b2);
+					w6[5] -= 0.5 * (a0 * b1 - a1 * b0);
+				}
+				const int c = tid >> 1;
+				double d = 0.0;
+				for (int i = 0; i < k; i++) {
+					double bi = 0.0;
+					for (int e = 0; e < 6; e++) bi = fma(tk.Bm[e * 6 + i], w6[e], bi);
+					d = fma(bi, sm.W[3][i * LD + ns + c], d);
+				}
+				sm.cs[tid] = fabs(d);
+			}
+			SYNC();
+			if (tid == 0) {
+				bool any1 = false;
+				for (int c = 0; c < nsg; c++)
+					if (fmax(sm.cs[2 * c], sm.cs[2 * c + 1]) > 0.5) any1 = true;  // _type_1_tol
+				st.ntypes = nsg;
+				int head = st.head, size = st.size, c1 = st.c1, c2 = st.c2;
+				if (size == SH_BUFFER) {  // :285-292
+					if (st.hist[head] == 1) c1--;
+					else c2--;
+					head = (head + 1) % SH_BUFFER;
+					size--;
+				}
+				st.hist[(head + size) % SH_BUFFER] = any1 ? 1 : 2;
+				size++;
+				if (any1) c1++;
+				else c2++;
+				st.head = head;
+				st.size = size;
+				st.c1 = c1;
+				st.c2 = c2;
+				unsigned dn = st.dir_neg;
+				const bool t1 = (c1 > c2) || tk.sh_force_type1;  // :329
+				if (!t1) {  // type-2 strategy: torque direction flips near the joint limits (:339-345)
+					for (int j = 0; j < n; j++)
+						if (Jh[ns * LD + j] != 0.0) {
+							if (fabs(sm.q[j] - md.q_upper[j]) < 5.0 * M_PI / 180.0) dn |= 1u << j;
+							else if (fabs(sm.q[j] - md.q_lower[j]) < 5.0 * M_PI / 180.0) dn &= ~(1u << j);
+						}
+					st.dir_neg = dn;
+				}
+				sm.flag = t1 ? 1 : 0;
+				sm.rank = (int)dn;
+			}
+			SYNC();
+			const bool type1 = sm.flag != 0;
+			const unsigned dir_neg = (unsigned)sm.rank;
+			if (tid < n) {
+				if (type1) {  // hold the entering posture (:333-336)
+					sm.v1[tid] = -tk.sh_kp1 * (sm.q[tid] - sm.v0[tid]) - tk.sh_kv1 * sm.dq[tid];
+				} else {      // :346-354
+					sm.v1[tid] = (((dir_neg >> tid) & 1u) ? -1.0 : 1.0) * (fabs(fTd) * 1e-2 * md.effort[tid]);
+					sm.v2[tid] = -tk.sh_kv2 * sm.dq[tid];
+				}
+			}
+			SYNC();
+			if (tid < nsg) {  // V_s^T unit
+				double a = 0.0, b2 = 0.0;
+				for (int j = 0; j < n; j++) {
+					a = fma(Jh[(ns + tid) * LD + j], sm.v1[j], a);
+					if (!type1) b2 = fma(Jh[(ns + tid) * LD + j], sm.v2[j], b2);
+				}
+				wA[tid] = a / sm.dv[ns + tid];
+				wB[tid] = b2 / sm.dv[ns + tid];
+			}
+			// joint strategy: posture Jacobian V_s^T N_ns N_prec (:153), Lambda_js, N_js
+			gemm<T>(sm.W[0], LD, Jh + ns * LD, LD, 1, Np2, LD, 1, nsg, n, n, tid);
+			SYNC();
+			for (int e = tid; e < nsg * n; e += T) {
+				int c = e / n, j = e - c * n;
+				Jh[c * LD + j] = sm.W[0][c * LD + j] / sm.dv[ns + c];
+			}
+			SYNC();
+			osm(Jh, nsg, true);
+			if (tid < nsg) {
+				double s = type1 ? 0.0 : wA[tid];
+				for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], type1 ? wA[i] : wB[i], s);
+				sm.v3[tid] = s;
+			}
+			SYNC();
+			for (int j = tid; j < n; j += T) {
+				double s = 0.0;
+				for (int c = 0; c < nsg; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+				if (tk.decoupling == DEC_IMPEDANCE) sm.tau[j] += tns[j];  // :311-313
+				else sm.tau[j] += tns[j] + alpha * ts[j] + (1.0 - alpha) * s;  // :367
+			}
+			gemm<T>(Np, LD, Nt, LD, 1, Np2, LD, 1, n, n, n, tid);  // N_prec <- N_js N_ns N_prec (:157 + getTaskAndPreviousNullspace)
+			SYNC();
+		} else if (!empty && !singular) {
+			osm(Jh, r, true);
 			if (P.diag && tk.diag_N) {
 				for (int e = tid; e < n * n; e += T) {
 					int i = e / n, j = e - i * n;
@@ -603,43 +856,8 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 
 			// ------------------------------------------------------------ control law -> g (r) in v3, then tau_t = Jh^T g
-			const bool track = (tk.has_ki || P.integ_always);
 			if (tk.type == TASK_MOTION_FORCE) {
-				if (tid == 0) {
-					const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3, f3, m3
-					double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
-					if (track)
-						for (int i = 0; i < 3; i++) {
-							ip[i] = tk.integ[(size_t)i * P.ld + b];
-							io[i] = tk.integ[(size_t)(3 + i) * P.ld + b];
-						}
-					// general law (velocity saturation, force/moment spaces) reduces to MotionForceTask.cpp:411-468 for the defaults
-					double ifm[6] = {0, 0, 0, 0, 0, 0};
-					const bool closed = tk.cl_force || tk.cl_moment;
-					if (closed)
-						for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * P.ld + b];
-					bool ovf = false;
-					law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, P.ld, &ovf);
-					if (ovf) sm.flag2 = 1;
-					if (closed)
-						for (int i = 0; i < 6; i++) tk.integ[(size_t)(6 + i) * P.ld + b] = ifm[i];
-					if (track)
-						for (int i = 0; i < 3; i++) {
-							tk.integ[(size_t)i * P.ld + b] = ip[i];
-							tk.integ[(size_t)(3 + i) * P.ld + b] = io[i];
-						}
-				}
-				SYNC();
-				if (tid < tk.k) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
-					double s = 0.0, s2 = 0.0;
-					for (int i = 0; i < 6; i++) {
-						s = fma(tk.Bm[i * 6 + tid], sm.Fum[i], s);
-						s2 = fma(tk.Bm[i * 6 + tid], sm.Ff[i], s2);
-					}
-					sm.v0[tid] = s;
-					sm.v1[tid] = s2;
-				}
-				SYNC();
+				mf_law();
 				if (mf_trunc) {  // U_ns^T of both (task_range_ns^T F, SingularityHandler.cpp:321-322)
 					double s = 0.0, s2 = 0.0;
 					if (tid < r)
@@ -813,7 +1031,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		if (singular) tv = __builtin_nan("");
 		P.tau[(size_t)tid * P.ld + b] = tv;
 	}
-	if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0));
+	if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0) | (blended ? 8 : 0));
 }
 
 // ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)

@@ -31,6 +31,7 @@ SCENARIOS = {
     "cfg11_jla_gravity": (11, 32, dict(joint_limit_avoidance=True, gravity_comp=True)),
     "cfg12_handling_disabled_truncated": (12, 48, {}),
     "cfg13_closed_loop_force": (13, 32, {}),
+    "cfg14_blended_strategies": (14, 48, {}),
 }
 
 
@@ -39,7 +40,7 @@ def main():
     for name, (cfg, B, opts) in SCENARIOS.items():
         d = W.make_inputs(cfg, B)
         tau, status = W.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"], **opts)
-        assert (status != 1).all(), name   # status 2 = task reduced to its non-singular subspace (config 12)
+        assert (status != 1).all(), name   # status 2 = task reduced to its non-singular subspace (config 12), 8 = blended strategies (14)
         arrs = dict(cfg=np.int64(cfg), q=d["q"], dq=d["dq"], tau=tau, status=status,
                     gravity_comp=np.bool_(opts.get("gravity_comp", False)),
                     torque_saturation=np.bool_(opts.get("torque_saturation", False)),

@@ -1,0 +1,175 @@
+"""Blended singularity strategies of SingularityHandler on the device (general kernel, also as the slow path behind the lane kernel)
+against the CPU oracle: SingularityHandler.cpp:100-121, 146-228 (task model), 230-295 (type classification over a 200-cycle window),
+310-367 (torques).  Status bit 8, handler state (entering posture, counters, type-2 direction) carried on the device across cycles."""
+import numpy as np
+import pytest
+
+import workloads as W
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _engine(model_name, tasks, B):
+    from sai_primitives_amd.controller import controller_from_specs
+    return controller_from_specs(model_name, tasks, B, device=0)
+
+
+def _cycle(robot, ctrl, q, dq, goals):
+    robot.setQ(q)
+    robot.setDq(dq)
+    robot.updateModel()
+    ctrl.updateControllerTaskModels()
+    ctrl.setGoals(goals)
+    return ctrl.computeControlTorques()
+
+
+def _strategies(spec):
+    for t in spec:
+        if t["type"] == "motion_force":
+            t["singularity_handling"] = True
+            t["singularity_strategies"] = True
+    return spec
+
+
+def _walk(d, spec, B, cycles, q0, rng, step=2e-3):
+    """same state sequence through the oracle and both kernel paths; returns the worst torque error and the status history"""
+    from oracle import Oracle
+    seq = [q0]
+    for _ in range(cycles - 1):
+        seq.append(seq[-1] + 1e-3 * d["dq"] + step * rng.standard_normal(q0.shape))
+    orc = Oracle(d["model"], spec)
+    refs = [orc.step(q, d["dq"], d["goals"], nthreads=8) for q in seq]
+    worst = 0.0
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(d["model"].name, spec, B)
+        ctrl.setKernel(kernel)
+        for c, q in enumerate(seq):
+            tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+            ref, st = refs[c]
+            assert np.array_equal(ctrl.status, st), (kernel, c, np.flatnonzero(ctrl.status != st)[:8], ctrl.status[ctrl.status != st][:8], st[ctrl.status != st][:8])
+            ok = st != 1
+            assert np.isfinite(tau[ok]).all() and np.isnan(tau[~ok]).all()
+            worst = max(worst, W.torque_error(tau[ok], ref[ok]))
+    return worst, np.array([r[1] for r in refs])
+
+
+def test_blended_strategies_over_cycles_panda():
+    """config 12's postures (a third inside the blending region, elbow nearly straight), handling enforced with the strategies on:
+    eight cycles of a slowly drifting state, lane kernel + slow path and the general kernel alone."""
+    B = 1024
+    d = W.make_inputs(12, B)
+    spec = _strategies(W.config_tasks(12))
+    worst, st = _walk(d, spec, B, 8, d["q"].copy(), np.random.default_rng(1))
+    nb = int((st[0] == 8).sum())
+    print("cfg12 blended", nb, "of", B, "worst err", worst)
+    assert nb > B // 4 and (st == 1).sum() == 0
+    assert worst < TOL
+
+
+def test_blended_strategies_uniform_postures():
+    """uniformly random Panda postures: more than half leave the non-singular branch (wrist and elbow singularities, one or two
+    singular directions); all of them get valid torques with the strategies on."""
+    B = 1024
+    d = W.make_inputs(2, B)
+    spec = _strategies(W.config_tasks(2))
+    rng = np.random.default_rng(3)
+    q0 = rng.uniform(d["model"].q_lower, d["model"].q_upper, size=d["q"].shape)
+    worst, st = _walk(d, spec, B, 4, q0, rng)
+    print("uniform postures: blended", int((st[0] == 8).sum()), "flagged", int((st[0] == 1).sum()), "worst err", worst)
+    assert (st[0] == 8).sum() > B // 3 and (st == 1).sum() <= 2
+    assert worst < TOL
+
+
+def test_type_window_and_type_two_strategy():
+    """more cycles than the 200-entry classification window: the oldest entries are dropped (:285-292), instances enter and leave the
+    singular region (state reset :238-244), and both strategies are exercised (the majority type decides, :333-355)."""
+    from oracle import Oracle
+    B = 64
+    d = W.make_inputs(2, B)
+    spec = _strategies(W.config_tasks(2))
+    rng = np.random.default_rng(5)
+    q0 = d["q"].copy()
+    q0[:, 5] = 0.03 * rng.uniform(0.3, 1.0, B)       # wrist nearly aligned (type 2, next to the lower limit of joint 6: direction flips)
+    q0[::4, 3] = -0.07 - 0.1 * rng.uniform(size=B // 4)  # every fourth with the elbow nearly straight as well (type 1 wins)
+    worst, st = _walk(d, spec, B, 230, q0, rng, step=1.5e-3)
+    changed = int((st[1:] != st[:-1]).any(axis=0).sum())
+    print("window test: blended at start", int((st[0] == 8).sum()), "instances that changed status", changed, "worst err", worst)
+    assert worst < TOL
+
+
+@pytest.mark.parametrize("cfg", [3, 6, 8])
+def test_blended_strategies_partial_and_multi_task_stacks(cfg):
+    """3-dof position task (3), two motion-force tasks on the 8-dof sliding-base Panda (6), planar partial task with IMPEDANCE
+    decoupling (8); every second instance has the elbow nearly straight."""
+    B = 96
+    d = W.make_inputs(cfg, B)
+    spec = _strategies(W.config_tasks(cfg))
+    q = d["q"].copy()
+    col = 3 if d["model"].dof == 7 else 4
+    q[::2, col] = -0.07 - 0.25 * np.random.default_rng(cfg).uniform(size=B // 2)
+    worst, st = _walk(d, spec, B, 5, q, np.random.default_rng(cfg + 40))
+    print("cfg", cfg, "blended", int(((st[0] & 8) > 0).sum()), "flagged", int((st[0] == 1).sum()), "worst err", worst)
+    assert ((st[0] & 8) > 0).sum() >= 8
+    assert worst < TOL
+
+
+def test_strategy_gains_forced_type_one_and_posture():
+    """setSingularityHandlingGains, handleAllSingularitiesAsType1, setType1Posture (MotionForceTask.h:698-753): non-default gains with the
+    type-1 strategy enforced on wrist-singular (type-2) instances; a posture set between cycles replaces the held one for instances inside
+    a singular region and is forgotten by those that enter one later (SingularityHandler.cpp:232-235).  Re-enabling the strategies resets
+    the handler states."""
+    from oracle import Oracle
+    B = 192
+    d = W.make_inputs(14, B)
+    spec = W.config_tasks(14)
+    spec[0].update(sh_gains=(35.0, 9.0, 2.5), sh_all_type1=True)
+    rng = np.random.default_rng(21)
+    q_des = d["model"].q_nominal + 0.05 * rng.standard_normal((B, d["model"].dof))
+    for kernel in (0, 1):
+        orc = Oracle(d["model"], spec)
+        robot, ctrl, tasks = _engine(d["model"].name, spec, B)
+        ctrl.setKernel(kernel)
+        q = d["q"].copy()
+        walk = np.random.default_rng(22)
+        for c in range(6):
+            if c == 2:
+                orc.set_type1_posture(0, q_des)
+                tasks[0].setType1Posture(q_des)
+            if c == 4:
+                orc.set_type1_posture(0, q_des[0])
+                tasks[0].setType1Posture(q_des[0])
+            tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+            ref, st = orc.step(q, d["dq"], d["goals"], nthreads=8)
+            assert np.array_equal(ctrl.status, st) and (st != 1).all()
+            err = W.torque_error(tau, ref)
+            assert err < TOL, (kernel, c, err)
+            q = q + 1e-3 * d["dq"] + 1e-3 * walk.standard_normal(q.shape)
+        assert (st == 8).sum() > B // 3
+        # the plain type-2 behaviour differs: the enforcement is really acting
+        spec2 = W.config_tasks(14)
+        ref2, _ = Oracle(d["model"], spec2).step(d["q"], d["dq"], d["goals"], nthreads=8)
+        ref1, _ = Oracle(d["model"], spec).step(d["q"], d["dq"], d["goals"], nthreads=8)
+        assert W.torque_error(ref1, ref2) > 1e-3
+        # switching the strategies on again resets the states: the next cycle equals a fresh oracle's first cycle
+        tasks[0].setSingularityStrategies(True)
+        tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+        assert W.torque_error(tau, ref1) < TOL
+
+
+def test_strategies_off_by_default_and_switchable():
+    """the same postures without the strategies are flagged (status 1, NaN); switching them on and off on a live controller"""
+    from oracle import Oracle
+    B = 96
+    d = W.make_inputs(14, B)
+    spec = W.config_tasks(14)
+    ref, st = Oracle(d["model"], spec).step(d["q"], d["dq"], d["goals"], nthreads=8)
+    robot, ctrl, tasks = _engine(d["model"].name, W.config_tasks(2), B)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status == 1, st == 8) and np.isnan(tau[st == 8]).all()
+    tasks[0].setSingularityStrategies(True)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status, st) and W.torque_error(tau, ref) < TOL
+    tasks[0].setSingularityStrategies(False)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status == 1, st == 8)

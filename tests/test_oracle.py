@@ -196,3 +196,45 @@ def test_integrators_advance_like_reference():
         ref = np.stack([W.controller_step_single(d["model"], tasks, d["q"][b], d["dq"][b], [g[b] for g in d["goals"]],
                                                  state=states[b]) for b in range(4)])
         assert W.torque_error(tau, ref) < 1e-9
+
+
+def test_blended_singularity_strategies_c_vs_numpy_over_cycles():
+    """SingularityHandler's blended type-1 / type-2 strategies (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367) with their
+    per-instance state (entering posture, classification window, type-2 direction): the C oracle against the NumPy restatement over
+    several cycles of a drifting state, statuses included (8 = blended)."""
+    B = 36
+    d = W.make_inputs(14, B)
+    model, tasks = d["model"], d["tasks"]
+    orc = Oracle(model, tasks)
+    states = [[dict(int_pos=np.zeros(3), int_ori=np.zeros(3)), dict(int_err=0)] for _ in range(B)]
+    rng = np.random.default_rng(14)
+    q = d["q"].copy()
+    seen = set()
+    for cyc in range(5):
+        tn, sn = np.zeros_like(q), np.zeros(B, np.uint8)
+        for b in range(B):
+            info = {}
+            tn[b] = W.controller_step_single(model, tasks, q[b], d["dq"][b], [g[b] for g in d["goals"]], state=states[b], info=info)
+            sn[b] = 8 if info.get("blended") else 0
+            sh = states[b][0].get("sh")
+            if sh is not None and sh["ntypes"]:
+                seen.add(1 if sh["c1"] > sh["c2"] else 2)
+        to, so = orc.step(q, d["dq"], d["goals"])
+        assert np.array_equal(sn, so)
+        assert W.torque_error(to, tn) < 1e-9
+        q = q + 1e-3 * d["dq"] + 1e-3 * rng.standard_normal(q.shape)
+    assert (so == 8).sum() >= B // 3 and seen == {1, 2}   # both strategies were exercised
+
+
+def test_singularity_strategy_options_c_vs_numpy():
+    """setSingularityHandlingGains and handleAllSingularitiesAsType1 (SingularityHandler.h:119-133) in both restatements"""
+    B = 24
+    d = W.make_inputs(14, B)
+    tasks = W.config_tasks(14)
+    tasks[0].update(sh_gains=(35.0, 9.0, 2.5), sh_all_type1=True)
+    tn, sn = W.controller_step(d["model"], tasks, d["q"], d["dq"], d["goals"])
+    to, so = Oracle(d["model"], tasks).step(d["q"], d["dq"], d["goals"])
+    assert np.array_equal(sn, so) and (so == 8).sum() >= B // 3
+    assert W.torque_error(to, tn) < 1e-9
+    t0, _ = Oracle(d["model"], W.config_tasks(14)).step(d["q"], d["dq"], d["goals"])
+    assert W.torque_error(to, t0) > 1e-3

@@ -584,8 +584,9 @@ def sh_blend_torques(model, t, m, q, dq, F_um, F_f, st):
         return m["J_ns"].T @ (m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)
     tau_ns = m["J_ns"].T @ (m["Lam_ns_mod"] @ m["U_ns"].T @ F_um + m["U_ns"].T @ F_f)
     V_s, Jpp = m["V_s"], m["Jpp"]
-    if st["c1"] > st["c2"]:                                          # type-1 strategy: hold the entering posture, :333-336
-        unit = -SH_KP1 * (q - st["q_prior"]) - SH_KV1 * dq
+    kp1, kv1, kv2 = t.get("sh_gains", (SH_KP1, SH_KV1, SH_KV2))      # setSingularityHandlingGains, SingularityHandler.h:119
+    if st["c1"] > st["c2"] or t.get("sh_all_type1", False):         # type-1 strategy: hold the entering posture, :329-336
+        unit = -kp1 * (q - st["q_prior"]) - kv1 * dq
         tau_js = Jpp.T @ m["Lam_js_mod"] @ V_s.T @ unit
     else:                                                            # type-2 strategy, :337-355
         for i in range(n):
@@ -597,7 +598,7 @@ def sh_blend_torques(model, t, m, q, dq, F_um, F_f, st):
         f = F_um + F_f
         fTd = (f / np.linalg.norm(f)) @ m["U_s"][:, 0]
         unit = st["dir"] * (abs(fTd) * SH_TYPE2_RATIO * model.effort)
-        tau_js = Jpp.T @ V_s.T @ unit + Jpp.T @ m["Lam_js_mod"] @ V_s.T @ (-SH_KV2 * dq)
+        tau_js = Jpp.T @ V_s.T @ unit + Jpp.T @ m["Lam_js_mod"] @ V_s.T @ (-kv2 * dq)
     tau_s = m["J_s"].T @ (m["Lam_s_mod"] @ m["U_s"].T @ F_um + m["U_s"].T @ F_f)   # :358-359
     tau_s = np.where(np.isnan(tau_s), 0.0, np.clip(tau_s, -model.effort, model.effort))
     return tau_ns + m["alpha"] * tau_s + (1 - m["alpha"]) * tau_js
@@ -869,6 +870,8 @@ CONFIGS = {
              "|dq| up to the velocity limit): exercises RobotController's JLA wrap + torque saturation"),
     13: dict(robot="panda_arm", batch=256, desc="Panda, closed-loop force (1 axis) and moment (2 axes) control in the compliant frame with a rotated / offset "
              "force sensor, PI feedback with saturation, feed-forward gains; full JointTask in the nullspace"),
+    14: dict(robot="panda_arm", batch=256, desc="config-2 tasks with the blended singularity strategies switched on; every third instance has the elbow nearly "
+             "straight (type-1 singularity), every third the wrist nearly aligned next to the joint limit (type-2)"),
     12: dict(robot="panda_arm", batch=256, desc="config-2 tasks with disableSingularityHandling(); every third instance has the elbow nearly straight "
              "(inside SingularityHandler's blending region): the motion-force task is reduced to its non-singular subspace"),
 }
@@ -882,6 +885,9 @@ def config_tasks(cfg: int):
                 joint_task("joint_task")]
     if cfg == 12:
         return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07), singularity_handling=False),  # MotionForceTask.h:723
+                joint_task("joint_task")]
+    if cfg == 14:
+        return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07), singularity_strategies=True),
                 joint_task("joint_task")]
     if cfg == 3:
         return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07),
@@ -992,6 +998,10 @@ def make_inputs(cfg: int, batch: int | None = None, *, shard: int = 0, min_ratio
         near = (np.arange(B) % 3) == 0
         q4 = -0.07 - 0.28 * rng.uniform_range(0.0, 1.0, 1)[:, 0]     # elbow in [-0.35, -0.07] rad: sigma_5 / sigma_0 below s_max = 0.06
         q[:, 3] = np.where(near, q4, q[:, 3])
+    if cfg == 14:
+        u = rng.uniform_range(0.0, 1.0, 2)
+        q[:, 3] = np.where((np.arange(B) % 3) == 0, -0.07 - 0.28 * u[:, 0], q[:, 3])   # elbow, as config 12
+        q[:, 5] = np.where((np.arange(B) % 3) == 1, 0.005 + 0.03 * u[:, 1], q[:, 5])   # wrist: joints 5 and 7 nearly aligned
     dq = rng.uniform_range(-0.5, 0.5, n)
     if cfg == 11:
         dq = dq * 2.0 * model.vel_limit[None]    # up to +-vel_limit: velocity zones get entered
