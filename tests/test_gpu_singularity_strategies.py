@@ -173,3 +173,18 @@ def test_strategies_off_by_default_and_switchable():
     tasks[0].setSingularityStrategies(False)
     tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert np.array_equal(ctrl.status == 1, st == 8)
+
+
+def test_blended_strategies_on_the_30_dof_chain():
+    """the four-wavefront variant of the general kernel (NMAX = 32, MFMA matrix products): config 5's chain with both motion-force tasks
+    on the blended strategies, half of the instances folded towards the straight (singular) posture"""
+    B = 64
+    d = W.make_inputs(5, B)
+    spec = _strategies(W.config_tasks(5))
+    q = d["q"].copy()
+    q[::2] *= 0.3
+    q[1::4] *= 0.1
+    worst, st = _walk(d, spec, B, 4, q, np.random.default_rng(55), step=5e-4)
+    print("chain30 blended", int(((st[0] & 8) > 0).sum()), "flagged", int((st[0] == 1).sum()), "worst err", worst)
+    assert ((st[0] & 8) > 0).sum() >= B // 3 and (st == 1).sum() == 0
+    assert worst < TOL
