@@ -188,3 +188,58 @@ def test_blended_strategies_on_the_30_dof_chain():
     print("chain30 blended", int(((st[0] & 8) > 0).sum()), "flagged", int((st[0] == 1).sum()), "worst err", worst)
     assert ((st[0] & 8) > 0).sum() >= B // 3 and (st == 1).sum() == 0
     assert worst < TOL
+
+
+def test_arm_driven_into_the_elbow_singularity_under_dynamics():
+    """closed loop on the device (control cycle -> resident forward dynamics, gravity-free world as examples/05): the goal lies beyond the
+    arm's reach, so the elbow straightens and the motion-force task crosses s_max and s_min.  Every cycle's torques equal the oracle's at
+    the pulled state (the handler state evolves identically on both sides), they stay finite and inside the limits, and the arm comes to
+    rest stretched towards the goal instead of being flagged."""
+    from oracle import Oracle
+    B = 32
+    d = W.make_inputs(2, B)
+    model = d["model"]
+    spec = _strategies(W.config_tasks(2))
+    rng = np.random.default_rng(77)
+    q0 = np.tile(model.q_nominal, (B, 1)) + 0.05 * rng.standard_normal((B, 7))
+    q0[:, 3] = -0.9 + 0.1 * rng.standard_normal(B)
+    li = model.link_index("end-effector")
+    fr = W.fk(model, q0)
+    x0 = fr[li][1] + fr[li][0] @ np.array([0.0, 0.0, 0.07])
+    Rc = fr[li][0]
+    shoulder = fr[model.link_index("link2")][1]
+    radial = x0 - shoulder
+    radial /= np.linalg.norm(radial, axis=1, keepdims=True)
+    goals = [g.copy() for g in d["goals"]]
+    goals[0][:] = 0.0
+    goals[0][:, 0:3] = x0 + 0.6 * radial           # out of reach along the arm
+    goals[0][:, 3:12] = Rc.reshape(B, 9)
+    goals[1][:] = 0.0
+    goals[1][:, 0:7] = q0
+    orc = Oracle(model, spec, torque_saturation=True)
+    robot, ctrl, tasks = _engine(model.name, spec, B)
+    ctrl.enableTorqueSaturation(True)
+    robot.setQ(q0)
+    robot.setDq(np.zeros((B, 7)))
+    robot.updateModel()
+    ctrl.setGoals(goals)
+    worst, seen8 = 0.0, np.zeros(B, bool)
+    q, dq = q0, np.zeros((B, 7))
+    for k in range(700):
+        ctrl.updateControllerTaskModels()
+        tau = ctrl.computeControlTorques()
+        ref, st = orc.step(q, dq, goals, nthreads=8)
+        assert np.array_equal(ctrl.status, st), (k, ctrl.status, st)
+        assert (st != 1).all() and np.isfinite(tau).all() and (np.abs(tau) <= model.effort + 1e-9).all()
+        worst = max(worst, W.torque_error(tau, ref))
+        seen8 |= (st & 8) > 0
+        ctrl.integrate(1e-3, 2, gravity=(0.0, 0.0, 0.0))
+        q, dq = ctrl.pullState()
+    fr = W.fk(model, q)
+    x1 = fr[li][1] + fr[li][0] @ np.array([0.0, 0.0, 0.07])
+    adv = np.einsum("bi,bi->b", x1 - x0, radial)
+    print("driven into the singularity: blended", int(seen8.sum()), "of", B, "| worst err", worst, "| advance towards the goal", adv.min(), adv.max(),
+          "| final elbow", q[:, 3].min(), q[:, 3].max(), "| max |dq|", np.abs(dq).max())
+    assert seen8.all()
+    assert worst < TOL
+    assert adv.min() > 0.02 and np.abs(dq).max() < 1.0
