@@ -17,6 +17,7 @@ namespace saip {
 hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
+hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 int otg_state_fields();
@@ -1260,6 +1261,16 @@ static bool lane_eligible(const saip_batch* b) {
 	}
 	return nmf <= 2;
 }
+// eight-lanes-per-instance kernel (saip_kernel_oct.hip): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain, default laws
+static bool oct_eligible(const saip_batch* b, const CycleParams& P) {
+	if (b->model->n != 7 || b->tasks.size() != 2 || P.jla) return false;
+	const TaskDev& mf = b->tasks[0].dev;
+	const TaskDev& jt = b->tasks[1].dev;
+	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;
+	if (mf.k != 6 || !mf.bm_identity || mf.general_law || mf.cl_force || mf.cl_moment) return false;
+	if (jt.m != 7 || !jt.s_identity) return false;
+	return lane_eligible(b);
+}
 static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;
 	saip_status st = make_params(b, P, diag);
@@ -1271,11 +1282,17 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (!diag && (st = run_otg(b, (int)t, 0))) return st;  // a diagnostic re-launch must not advance the trajectory
 	}
 	bool lane_ok = false;
+	if (!diag && b->kernel_choice == 3 && !oct_eligible(b, P)) return fail(SAIP_ERR_UNSUPPORTED, "the eight-lanes-per-instance kernel does not cover this robot/task stack");
 	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
-		hipError_t e = saip::launch_cycle_lane(P, b->stream, &lane_ok);
+		// small batches of the headline stack: eight lanes per instance (the lane kernel would leave most of the chip idle)
+		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
+		const int oct_max = oct_env ? atoi(oct_env) : 16384;
+		const bool oct = oct_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
+		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
+		if (oct) lane_ok = true;
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
-			b->kernel_name = "saip_cycle_lane";
+			b->kernel_name = oct ? "saip_cycle_oct" : "saip_cycle_lane";
 			// slow path: instances the lane kernel flagged (outside the fully non-singular branch) are recomputed by the general kernel
 			// when a task can handle them there (singularity handling disabled: the task is reduced to its non-singular subspace;
 			// blended strategies switched on: type-1 / type-2 handling);
@@ -1391,7 +1408,7 @@ extern "C" saip_status saip_batch_get_task_nullspace_host(saip_batch* b, int t, 
 	return copy_d2h(b, N, T.diag_dev, n * n);
 }
 extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
-	if (!b || which < 0 || which > 2) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1 or 2");
+	if (!b || which < 0 || which > 3) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1, 2 or 3");
 	b->kernel_choice = which;
 	return SAIP_OK;
 }

@@ -1,0 +1,667 @@
+// Control-cycle kernel for SMALL batches of 7-dof arms: EIGHT LANES PER ROBOT INSTANCE (eight instances per wavefront).
+//
+// At the batch the headline metric is quoted on (4096 instances per GPU) the lane-per-instance kernel fills 64 of the 1024 SIMDs
+// of an MI355X and each of those wavefronts walks the whole ~5000-instruction cycle alone.  Here the rows of every matrix of
+// an instance are spread over eight lanes (lane r owns joint r / row r; lane 7 is padding), operands the other lanes need travel
+// through a small LDS block per instance, and the inherently serial factorisations are done redundantly (a Cholesky factor per
+// lane, then each lane solves for its own column of the inverse).  4096 instances become 512 wavefronts with ~1/4 of the
+// instructions each.  One wavefront per workgroup: __syncthreads() is a wave-local ordering point.
+//
+// Covers exactly the stack of BASELINE config 2 (and 12 / 14): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain with
+// the default control laws; everything else stays on saip_cycle_lane / saip_cycle_wg (engine: oct_eligible).
+//   SaiModel::updateModel()                       -> prefix-product kinematics, composite inertias, M, M^-1, M_BIE^-1
+//   RobotController::updateControllerTaskModels() -> /root/reference/src/RobotController.cpp:68-77, tasks/MotionForceTask.cpp:247-268,
+//       tasks/SingularityHandler.cpp:75-228 (non-singular branch; others flagged -> slow path), tasks/JointTask.cpp:218-283
+//   RobotController::computeControlTorques()      -> RobotController.cpp:79-118, MotionForceTask.cpp:270-509,
+//       SingularityHandler.cpp:297-309, JointTask.cpp:285-356
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "saip_device.h"
+
+namespace saip {
+
+#define UNR _Pragma("unroll")
+
+struct OctInst {
+	double X[2][8][12];  // forward-kinematics prefix product, ping-pong: per joint R (9, row-major) + o (3)
+	double zo[8][6];     // world joint axis z (3), joint origin o (3)
+	double body[8][10];  // spatial inertia about the world origin: m, h(3), Io(6: xx yy zz xy xz yz)
+	double M[8][8], Minv[8][8], MB[8][8];
+	double J[6][8], T1[6][8], A[6][8], Am[6][8], Lam[6][8];
+	double N1[8][8];
+	double vec[10][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions, 7 u, 8 d, 9 flags
+	double pad_[2];      // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+};
+
+__device__ __forceinline__ void oct_mat3_vec(const double* R, const double* v, double* out) {
+	UNR for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+
+// cyclic Jacobi eigen-solve of a symmetric n x n matrix in LDS by ONE lane (rare exact path): eigenvalues on the diagonal of A,
+// eigenvectors in the columns of V (optional)
+__device__ void oct_serial_jacobi(double* A, double* V, const int n, const int ld) {
+	if (V)
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < n; j++) V[i * ld + j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 14; sweep++) {
+		double off = 0.0, dg = 0.0;
+		for (int p = 0; p < n; p++) {
+			dg = fma(A[p * ld + p], A[p * ld + p], dg);
+			for (int q = p + 1; q < n; q++) off = fma(A[p * ld + q], A[p * ld + q], off);
+		}
+		if (!(off > 1e-36 * dg)) break;
+		for (int p = 0; p < n - 1; p++)
+			for (int q = p + 1; q < n; q++) {
+				const double apq = A[p * ld + q];
+				if (apq == 0.0) continue;
+				const double theta = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
+				const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+				const double c = rsqrt(fma(t, t, 1.0)), s = t * c;
+				for (int k = 0; k < n; k++) {  // A <- A R (columns p, q)
+					const double akp = A[k * ld + p], akq = A[k * ld + q];
+					A[k * ld + p] = c * akp - s * akq;
+					A[k * ld + q] = s * akp + c * akq;
+				}
+				for (int k = 0; k < n; k++) {  // A <- R^T A (rows p, q)
+					const double apk = A[p * ld + k], aqk = A[q * ld + k];
+					A[p * ld + k] = c * apk - s * aqk;
+					A[q * ld + k] = s * apk + c * aqk;
+				}
+				if (V)
+					for (int k = 0; k < n; k++) {
+						const double vkp = V[k * ld + p], vkq = V[k * ld + q];
+						V[k * ld + p] = c * vkp - s * vkq;
+						V[k * ld + q] = s * vkp + c * vkq;
+					}
+			}
+	}
+}
+
+// Cholesky factor of an SPD R x R matrix given by its lower triangle; L overwrites A's lower triangle, dinv = 1 / L_kk
+template <int R>
+__device__ __forceinline__ void oct_cholesky(double (&L)[R][R], double (&dinv)[R]) {
+	UNR for (int k = 0; k < R; k++) {
+		const double rs = rsqrt(L[k][k]);
+		dinv[k] = rs;
+		UNR for (int i = k + 1; i < R; i++) L[i][k] *= rs;
+		UNR for (int j = k + 1; j < R; j++)
+			UNR for (int i = j; i < R; i++) L[i][j] = fma(-L[i][k], L[j][k], L[i][j]);
+	}
+}
+// x = (L L^T)^-1 e_col, i.e. column (= row) `col` of the inverse; col is a lane variable
+template <int R>
+__device__ __forceinline__ void oct_solve_unit(const double (&L)[R][R], const double (&dinv)[R], const int col, double (&x)[R]) {
+	double y[R];
+	UNR for (int i = 0; i < R; i++) {
+		double s = (i == col) ? 1.0 : 0.0;
+		UNR for (int k = 0; k < i; k++) s = fma(-L[i][k], y[k], s);
+		y[i] = s * dinv[i];
+	}
+	UNR for (int i = R - 1; i >= 0; i--) {
+		double s = y[i];
+		UNR for (int k = i + 1; k < R; k++) s = fma(-L[k][i], x[k], s);
+		x[i] = s * dinv[i];
+	}
+}
+
+__global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
+	constexpr int N = 7;
+	__shared__ OctInst smem[8];
+	const int lane = threadIdx.x;
+	const int r = lane & 7, grp = lane >> 3;
+	const int rr = r < N ? r : N - 1;  // padding lane mirrors joint 6 and never writes
+	const bool act = r < N;
+	OctInst& sm = smem[grp];
+	const int b_raw = blockIdx.x * 8 + grp;
+	const bool live = b_raw < P.B;
+	const int b = live ? b_raw : P.B - 1;
+	const size_t ld = P.ld;
+	const ModelDev& md = *P.model;
+	const TaskDev& mf = P.tasks[0];
+	const TaskDev& jt = P.tasks[1];
+
+	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
+	const double q_r = P.q[(size_t)rr * ld + b];
+	const double dq_r = P.dq[(size_t)rr * ld + b];
+	double G24[24];
+	UNR for (int e = 0; e < 24; e++) G24[e] = mf.goal[(size_t)e * ld + b];
+	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
+	if (act) sm.vec[0][r] = dq_r;
+
+	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
+	double Tw[12];
+	{
+		const double* R0 = md.R0[rr];
+		const double ax = md.axis[rr][0], ay = md.axis[rr][1], az = md.axis[rr][2];
+		if (md.jtype[rr] == 1) {
+			double s, c;
+			sincos(q_r, &s, &c);
+			const double v = 1.0 - c;
+			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+								  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+			UNR for (int i = 0; i < 3; i++)
+				UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
+		} else {
+			UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
+			const double a[3] = {ax, ay, az};
+			double d[3];
+			oct_mat3_vec(R0, a, d);
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
+		}
+	}
+	UNR for (int e = 0; e < 12; e++) sm.X[0][r][e] = Tw[e];
+	__syncthreads();
+	UNR for (int step = 0; step < 3; step++) {
+		const int d = 1 << step, cur = step & 1;
+		if (r >= d) {  // T_r <- T_{r-d} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
+			double Xa[12], Tn[12];
+			UNR for (int e = 0; e < 12; e++) Xa[e] = sm.X[cur][r - d][e];
+			UNR for (int i = 0; i < 3; i++) {
+				UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j];
+				Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];
+			}
+			UNR for (int e = 0; e < 12; e++) Tw[e] = Tn[e];
+		}
+		UNR for (int e = 0; e < 12; e++) sm.X[cur ^ 1][r][e] = Tw[e];
+		__syncthreads();
+	}
+	// world frames of all bodies are now in X[1]; this lane's in Tw.  Padding lane 7 holds T_6 o T_6(local): unused.
+	double z[3], o[3];
+	{
+		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
+		oct_mat3_vec(Tw, a, z);
+		UNR for (int e = 0; e < 3; e++) o[e] = Tw[9 + e];
+	}
+	const bool rev = md.jtype[rr] == 1;
+	// per-body spatial inertia about the world origin
+	{
+		double c[3], Bd[10];
+		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
+		oct_mat3_vec(Tw, cl, c);
+		UNR for (int e = 0; e < 3; e++) c[e] += o[e];
+		const double* I6 = md.inertia[rr];
+		const double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+		double RI[9], Iw[9];
+		UNR for (int i = 0; i < 3; i++)
+			UNR for (int j = 0; j < 3; j++) RI[3 * i + j] = Tw[3 * i] * Il[j] + Tw[3 * i + 1] * Il[3 + j] + Tw[3 * i + 2] * Il[6 + j];
+		UNR for (int i = 0; i < 3; i++)
+			UNR for (int j = 0; j < 3; j++) Iw[3 * i + j] = RI[3 * i] * Tw[3 * j] + RI[3 * i + 1] * Tw[3 * j + 1] + RI[3 * i + 2] * Tw[3 * j + 2];
+		const double m = md.mass[rr], cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+		Bd[0] = m;
+		Bd[1] = m * c[0];
+		Bd[2] = m * c[1];
+		Bd[3] = m * c[2];
+		Bd[4] = Iw[0] + m * (cc2 - c[0] * c[0]);
+		Bd[5] = Iw[4] + m * (cc2 - c[1] * c[1]);
+		Bd[6] = Iw[8] + m * (cc2 - c[2] * c[2]);
+		Bd[7] = Iw[1] - m * c[0] * c[1];
+		Bd[8] = Iw[2] - m * c[0] * c[2];
+		Bd[9] = Iw[5] - m * c[1] * c[2];
+		if (act) {
+			UNR for (int e = 0; e < 10; e++) sm.body[r][e] = Bd[e];
+			UNR for (int e = 0; e < 3; e++) {
+				sm.zo[r][e] = z[e];
+				sm.zo[r][3 + e] = o[e];
+			}
+		}
+	}
+	__syncthreads();
+	double Ic[10];  // composite inertia of the subtree of joint rr (serial chain: bodies rr..6)
+	UNR for (int e = 0; e < 10; e++) Ic[e] = 0.0;
+	UNR for (int l = 0; l < N; l++) {
+		const bool in = l >= rr;
+		UNR for (int e = 0; e < 10; e++) Ic[e] += in ? sm.body[l][e] : 0.0;
+	}
+	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
+	{
+		double w[3], v[3];
+		w[0] = rev ? z[0] : 0.0; w[1] = rev ? z[1] : 0.0; w[2] = rev ? z[2] : 0.0;
+		v[0] = rev ? (o[1] * z[2] - o[2] * z[1]) : z[0];
+		v[1] = rev ? (o[2] * z[0] - o[0] * z[2]) : z[1];
+		v[2] = rev ? (o[0] * z[1] - o[1] * z[0]) : z[2];
+		const double m = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
+		const double f[3] = {m * v[0] + (w[1] * hz - w[2] * hy), m * v[1] + (w[2] * hx - w[0] * hz), m * v[2] + (w[0] * hy - w[1] * hx)};
+		const double nO[3] = {Ic[4] * w[0] + Ic[7] * w[1] + Ic[8] * w[2] + (hy * v[2] - hz * v[1]),
+							  Ic[7] * w[0] + Ic[5] * w[1] + Ic[9] * w[2] + (hz * v[0] - hx * v[2]),
+							  Ic[8] * w[0] + Ic[9] * w[1] + Ic[6] * w[2] + (hx * v[1] - hy * v[0])};
+		UNR for (int i = 0; i < N; i++) {
+			const double zi[3] = {sm.zo[i][0], sm.zo[i][1], sm.zo[i][2]}, oi[3] = {sm.zo[i][3], sm.zo[i][4], sm.zo[i][5]};
+			const bool revi = md.jtype[i] == 1;
+			const double vi[3] = {oi[1] * zi[2] - oi[2] * zi[1], oi[2] * zi[0] - oi[0] * zi[2], oi[0] * zi[1] - oi[1] * zi[0]};
+			const double vr = zi[0] * nO[0] + zi[1] * nO[1] + zi[2] * nO[2] + vi[0] * f[0] + vi[1] * f[1] + vi[2] * f[2];
+			const double vp = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
+			const double val = revi ? vr : vp;
+			if (act && i <= r) {
+				sm.M[i][r] = val;
+				sm.M[r][i] = val;
+			}
+		}
+	}
+	__syncthreads();
+	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
+	double mi[N], mb[N], mdiag[N];
+	{
+		double L[N][N], dinv[N];
+		UNR for (int i = 0; i < N; i++)
+			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.M[i][j];
+		UNR for (int i = 0; i < N; i++) mdiag[i] = L[i][i];
+		oct_cholesky<N>(L, dinv);
+		oct_solve_unit<N>(L, dinv, rr, mi);
+	}
+	UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
+	if (P.any_bie) {
+		// M_BIE = M + sum_e c_e e e^T (diagonal clamped from below, SingularityHandler.cpp:176-182): one Sherman-Morrison update of the
+		// row-distributed inverse per clamped entry
+		UNR for (int e = 0; e < N; e++) {
+			const double ce = fmax(P.bie_thr - mdiag[e], 0.0);
+			if (__any(ce > 0.0)) {
+				if (r == e) {
+					UNR for (int j = 0; j < N; j++) sm.MB[e][j] = mb[j];
+				}
+				__syncthreads();
+				double re[N];
+				UNR for (int j = 0; j < N; j++) re[j] = sm.MB[e][j];
+				const double gamma = ce / fma(ce, re[e], 1.0);
+				const double mbe = mb[e];
+				UNR for (int j = 0; j < N; j++) mb[j] = fma(-gamma * mbe, re[j], mb[j]);
+				__syncthreads();
+			}
+		}
+	}
+	if (act) {
+		UNR for (int j = 0; j < N; j++) {
+			sm.Minv[r][j] = mi[j];
+			sm.MB[r][j] = mb[j];
+		}
+	}
+	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
+	double pw[3], Rc[9];
+	{
+		const int bd = mf.body;
+		double Rb[12];
+		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[1][bd][e];
+		oct_mat3_vec(Rb, mf.pos, pw);
+		UNR for (int e = 0; e < 3; e++) pw[e] += Rb[9 + e];
+		UNR for (int i = 0; i < 3; i++)
+			UNR for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
+		const bool on = rr <= bd;
+		const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
+		const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
+		if (act) {
+			sm.J[0][r] = on ? (rev ? c0 : z[0]) : 0.0;
+			sm.J[1][r] = on ? (rev ? c1 : z[1]) : 0.0;
+			sm.J[2][r] = on ? (rev ? c2 : z[2]) : 0.0;
+			sm.J[3][r] = (on && rev) ? z[0] : 0.0;
+			sm.J[4][r] = (on && rev) ? z[1] : 0.0;
+			sm.J[5][r] = (on && rev) ? z[2] : 0.0;
+		}
+	}
+	__syncthreads();
+	double Jf[6][N];
+	UNR for (int a = 0; a < 6; a++)
+		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
+	double vw[6];
+	{
+		double dqa[N];
+		UNR for (int j = 0; j < N; j++) dqa[j] = sm.vec[0][j];
+		UNR for (int a = 0; a < 6; a++) {
+			double s = 0.0;
+			UNR for (int j = 0; j < N; j++) s = fma(Jf[a][j], dqa[j], s);
+			vw[a] = s;
+		}
+	}
+	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
+	bool singular = false;
+	{
+		double G[6][6], tr = 0.0;
+		UNR for (int a = 0; a < 6; a++)
+			UNR for (int c = 0; c <= a; c++) {
+				double s = 0.0;
+				UNR for (int j = 0; j < N; j++) s = fma(Jf[a][j], Jf[c][j], s);
+				G[a][c] = s;
+				G[c][a] = s;
+				if (a == c) tr += s;
+			}
+		const double itr = 1.0 / tr;
+		const double smax2 = mf.s_max * mf.s_max, tol2 = mf.s_abs_tol * mf.s_abs_tol;
+		auto ldl_positive = [&](const double shift) {
+			double Gs[6][6];
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
+			bool pos = true;
+			UNR for (int a = 0; a < 6; a++) Gs[a][a] -= shift;
+			UNR for (int kk = 0; kk < 6; kk++) {
+				const double d = Gs[kk][kk];
+				pos = pos && (d > 1e-13);
+				const double id = 1.0 / d;
+				UNR for (int i = kk + 1; i < 6; i++) {
+					const double lik = Gs[i][kk] * id;
+					UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
+				}
+			}
+			return pos;
+		};
+		// stage 1: lambda_max(Gs) <= trace(Gs) = 1, lambda_max(G) >= trace(G)/6; stage 2: trace-power bound (see saip_kernel_lane.hip)
+		bool need_exact = !((tr > 0.0) && (tr >= 6.0 * tol2) && ldl_positive(smax2));
+		if (__any(need_exact)) {
+			double G2[6][6], Gt[6][6];
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c < 6; c++) G2[a][c] = G[a][c] * itr;
+			UNR for (int rep = 0; rep < 2; rep++) {
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						double s = 0.0;
+						UNR for (int l = 0; l < 6; l++) s = fma(G2[a][l], G2[l][c], s);
+						Gt[a][c] = s;
+					}
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						G2[a][c] = Gt[a][c];
+						G2[c][a] = Gt[a][c];
+					}
+			}
+			double t8 = 0.0;
+			UNR for (int a = 0; a < 6; a++)
+				UNR for (int c = 0; c < 6; c++) t8 = fma(G2[a][c], G2[a][c], t8);
+			const double u = sqrt(sqrt(sqrt(t8)));
+			const bool ok_s0 = (u * mf.cert_kroot * tr >= tol2);
+			const bool pos = ldl_positive(smax2 * u);
+			need_exact = need_exact && !(ok_s0 && pos && tr > 0.0);
+			if (__any(need_exact)) {  // exact path (rare): singular values from the Gram eigenvalues, one lane per instance (SingularityHandler.cpp:78-121)
+				if (need_exact && r == 0) {
+					for (int a = 0; a < 6; a++)
+						for (int c = 0; c < 6; c++) sm.A[a][c] = G[a][c];
+					oct_serial_jacobi(&sm.A[0][0], nullptr, 6, 8);
+					double lmax = 0.0;
+					for (int i = 0; i < 6; i++) lmax = fmax(lmax, sm.A[i][i]);
+					const double s0 = sqrt(lmax);
+					bool sing = !(s0 >= mf.s_abs_tol);
+					for (int i = 0; i < 6; i++)
+						if (sqrt(fmax(sm.A[i][i], 0.0)) / s0 < mf.s_max) sing = true;
+					sm.vec[9][0] = sing ? 1.0 : 0.0;
+				}
+				__syncthreads();
+				if (need_exact) singular = sm.vec[9][0] != 0.0;
+				__syncthreads();
+			}
+		}
+	}
+	// ---- operationalSpaceMatrices(J): row a of T1 = J M^-1 and of A = T1 J^T (and the M_BIE variants) per lane
+	const int ra = r < 6 ? r : 5;
+	{
+		double t1[N], tb[N];
+		UNR for (int j = 0; j < N; j++) t1[j] = tb[j] = 0.0;
+		UNR for (int l = 0; l < N; l++) {
+			const double jal = sm.J[ra][l];
+			UNR for (int j = 0; j < N; j++) {
+				t1[j] = fma(jal, sm.Minv[l][j], t1[j]);
+				tb[j] = fma(jal, sm.MB[l][j], tb[j]);
+			}
+		}
+		if (r < 6) {
+			UNR for (int j = 0; j < N; j++) sm.T1[r][j] = t1[j];
+			UNR for (int c = 0; c < 6; c++) {
+				double s = 0.0, s2 = 0.0;
+				UNR for (int j = 0; j < N; j++) {
+					s = fma(t1[j], Jf[c][j], s);
+					s2 = fma(tb[j], Jf[c][j], s2);
+				}
+				sm.A[r][c] = s;
+				sm.Am[r][c] = s2;
+			}
+		}
+	}
+	__syncthreads();
+	double lam[6], lmod[6];
+	{
+		double L[6][6], dinv[6];
+		UNR for (int i = 0; i < 6; i++)
+			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.A[i][j];
+		oct_cholesky<6>(L, dinv);
+		oct_solve_unit<6>(L, dinv, ra, lam);
+		if (mf.decoupling == DEC_FULL) {
+			UNR for (int c = 0; c < 6; c++) lmod[c] = lam[c];
+		} else if (mf.decoupling == DEC_IMPEDANCE) {
+			UNR for (int c = 0; c < 6; c++) lmod[c] = (c == ra) ? 1.0 : 0.0;
+		} else {
+			UNR for (int i = 0; i < 6; i++)
+				UNR for (int j = 0; j <= i; j++) L[i][j] = sm.Am[i][j];
+			oct_cholesky<6>(L, dinv);
+			oct_solve_unit<6>(L, dinv, ra, lmod);
+		}
+	}
+	if (r < 6) {
+		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
+	}
+	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
+	const bool track_mf = (mf.has_ki || P.integ_always);
+	{
+		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
+		if (track_mf) {
+			UNR for (int i = 0; i < 3; i++) {
+				ip[i] = mf.integ[(size_t)i * ld + b];
+				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
+			}
+		}
+		double v[3], w[3], e3[3], tmp[3];
+		UNR for (int i = 0; i < 3; i++) {
+			v[i] = mf.Ppos[3 * i] * vw[0] + mf.Ppos[3 * i + 1] * vw[1] + mf.Ppos[3 * i + 2] * vw[2];
+			w[i] = mf.Pori[3 * i] * vw[3] + mf.Pori[3 * i + 1] * vw[4] + mf.Pori[3 * i + 2] * vw[5];
+		}
+		UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G24[i];
+		UNR for (int i = 0; i < 3; i++) ip[i] += (mf.sig_p[3 * i] * e3[0] + mf.sig_p[3 * i + 1] * e3[1] + mf.sig_p[3 * i + 2] * e3[2]) * mf.dt;
+		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - mf.kp_pos[i] * e3[i] - mf.kv_pos[i] * (v[i] - G24[12 + i]) - mf.ki_pos[i] * ip[i];
+		UNR for (int i = 0; i < 3; i++) Fum[i] = mf.sig_p[3 * i] * tmp[0] + mf.sig_p[3 * i + 1] * tmp[1] + mf.sig_p[3 * i + 2] * tmp[2];
+		double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+		UNR for (int c = 0; c < 3; c++) {
+			const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
+			oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+			oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+			oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+		}
+		double dphi[3];
+		UNR for (int i = 0; i < 3; i++) dphi[i] = mf.sig_o[3 * i] * oe[0] + mf.sig_o[3 * i + 1] * oe[1] + mf.sig_o[3 * i + 2] * oe[2];
+		UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * mf.dt;
+		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - mf.kp_ori[i] * dphi[i] - mf.kv_ori[i] * (w[i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
+		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = mf.sig_o[3 * i] * tmp[0] + mf.sig_o[3 * i + 1] * tmp[1] + mf.sig_o[3 * i + 2] * tmp[2];
+		if (track_mf && live && !singular && r == 0) {
+			UNR for (int i = 0; i < 3; i++) {
+				mf.integ[(size_t)i * ld + b] = ip[i];
+				mf.integ[(size_t)(3 + i) * ld + b] = io[i];
+			}
+		}
+		// g_a = (Lambda_mod F_um)_a  (SingularityHandler.cpp:307-309; F_f = 0 without a force space); Bm = I for the full task
+		double s = 0.0;
+		UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
+		if (r < 6) sm.vec[2][r] = s;
+	}
+	__syncthreads();
+	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J, row rr:  N1[i][j] = d_ij - sum_a (Lambda T1[:, i])_a J[a][j]
+	double tau_r;
+	double n1[N];
+	{
+		double g[6], t2[6], t1c[6];
+		UNR for (int a = 0; a < 6; a++) {
+			g[a] = sm.vec[2][a];
+			t1c[a] = sm.T1[a][rr];
+		}
+		double s = 0.0;
+		UNR for (int a = 0; a < 6; a++) s = fma(sm.J[a][rr], g[a], s);
+		tau_r = s;
+		UNR for (int a = 0; a < 6; a++) {
+			double acc = 0.0;
+			UNR for (int c = 0; c < 6; c++) acc = fma(sm.Lam[a][c], t1c[c], acc);
+			t2[a] = acc;
+		}
+		UNR for (int j = 0; j < N; j++) {
+			double acc = (j == rr) ? 1.0 : 0.0;
+			UNR for (int a = 0; a < 6; a++) acc = fma(-t2[a], Jf[a][j], acc);
+			n1[j] = acc;
+		}
+		if (act) {
+			UNR for (int j = 0; j < N; j++) sm.N1[r][j] = n1[j];
+			sm.vec[1][r] = tau_r;
+		}
+	}
+	__syncthreads();
+	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
+	double cj[N];  // column rr of N_1
+	double cn = 0.0;
+	UNR for (int i = 0; i < N; i++) {
+		cj[i] = sm.N1[i][rr];
+		cn = fma(cj[i], cj[i], cn);
+	}
+	sm.vec[3][r] = act ? cn : -1.0;
+	__syncthreads();
+	double best = -1.0, frob2 = 0.0;
+	int jb = 0;
+	UNR for (int j = 0; j < N; j++) {
+		const double c = sm.vec[3][j];
+		frob2 += c;
+		if (c > best) {
+			best = c;
+			jb = j;
+		}
+	}
+	bool empty = false, need_exact = false;
+	if (frob2 < 1e-6) empty = true;  // ||Jp||_F < 1e-3: empty range (matrixRangeBasis)
+	else if (best < 1e-5) need_exact = true;
+	double u[N], d_r, u_own;
+	{
+		const double inv = rsqrt(best);
+		u_own = sm.N1[rr][jb] * inv;
+		double dd = 0.0;
+		UNR for (int i = 0; i < N; i++) {
+			u[i] = sm.N1[i][jb] * inv;
+			dd = fma(u[i], cj[i], dd);
+		}
+		d_r = dd;  // (u^T Jp)_rr: the row of Jh = U^T Jp
+		double c2 = 0.0;
+		UNR for (int i = 0; i < N; i++) {
+			const double wv = fma(-u[i], d_r, cj[i]);
+			c2 = fma(wv, wv, c2);
+		}
+		sm.vec[4][r] = act ? c2 : -1.0;
+	}
+	__syncthreads();
+	{
+		double best2 = -1.0;
+		UNR for (int j = 0; j < N; j++) best2 = fmax(best2, sm.vec[4][j]);
+		if (!empty && !need_exact && !(best2 / best < 1e-20)) need_exact = true;  // not numerically rank one: the exact path decides
+	}
+	if (__any(need_exact)) {  // exact path (rare): Gram eigen-decomposition with the reference's tolerances, one lane per instance
+		if (need_exact && r == 0) {
+			double* Gm = &sm.M[0][0];   // M and the kinematics scratch are dead by now
+			double* Vm = &sm.X[0][0][0];
+			double trc = 0.0;
+			for (int a = 0; a < N; a++)
+				for (int c = 0; c < N; c++) {
+					double s = 0.0;
+					for (int j = 0; j < N; j++) s = fma(sm.N1[a][j], sm.N1[c][j], s);
+					Gm[a * 8 + c] = s;
+					if (a == c) trc += s;
+				}
+			oct_serial_jacobi(Gm, Vm, N, 8);
+			double lmax = 0.0;
+			for (int i = 0; i < N; i++) lmax = fmax(lmax, Gm[i * 8 + i]);
+			int cnt = 0, col = 0;
+			if (sqrt(fmax(trc, 0.0)) >= 1e-3 && sqrt(lmax) >= 1e-3)
+				for (int i = 0; i < N; i++)
+					if (sqrt(fmax(Gm[i * 8 + i], 0.0) / lmax) >= 1e-3) {
+						if (cnt == 0) col = i;
+						cnt++;
+					}
+			sm.vec[9][1] = (double)cnt;
+			for (int i = 0; i < N; i++) sm.vec[7][i] = cnt ? Vm[i * 8 + col] : 0.0;
+		}
+		__syncthreads();
+		if (need_exact) {
+			const int cnt = (int)sm.vec[9][1];
+			if (cnt > 1) singular = true;  // cannot happen while the motion-force task has rank 6; never silently truncate
+			empty = cnt == 0;
+			double dd = 0.0;
+			UNR for (int i = 0; i < N; i++) {
+				u[i] = sm.vec[7][i];
+				dd = fma(u[i], cj[i], dd);
+			}
+			d_r = dd;
+			u_own = sm.vec[7][rr];
+		}
+		__syncthreads();
+	}
+	if (act) sm.vec[8][r] = d_r;
+	__syncthreads();
+	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
+	double g_jt = 0.0;
+	{
+		double dv[N], tauv[N];
+		UNR for (int j = 0; j < N; j++) {
+			dv[j] = sm.vec[8][j];
+			tauv[j] = sm.vec[1][j];
+		}
+		double t1 = 0.0, tb = 0.0, wr = 0.0;
+		UNR for (int l = 0; l < N; l++) {
+			t1 = fma(dv[l], mi[l], t1);   // (Jh M^-1)_rr  (M^-1 symmetric: row rr = column rr)
+			tb = fma(dv[l], mb[l], tb);
+			wr = fma(mi[l], tauv[l], wr); // (M^-1 tau_prec)_rr
+		}
+		const bool track = (jt.has_ki || P.integ_always);
+		const double e = q_r - jg_q;
+		double ie = 0.0;
+		if (track) ie = jt.integ[(size_t)rr * ld + b];
+		ie += e * jt.dt;  // :323-324
+		if (track && live && !singular && act) jt.integ[(size_t)r * ld + b] = ie;
+		double fi;
+		if (jt.vel_sat) {  // :327-341
+			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
+			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
+			fi = -jt.kv[rr] * (dq_r - vdes);
+		} else {
+			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
+		}
+		const double ai = jg_ddq - wr;
+		sm.vec[3][r] = act ? t1 * d_r : 0.0;
+		sm.vec[4][r] = act ? tb * d_r : 0.0;
+		sm.vec[5][r] = act ? u_own * ai : 0.0;
+		sm.vec[6][r] = act ? u_own * fi : 0.0;
+		__syncthreads();
+		double A1 = 0.0, Ab = 0.0, a1 = 0.0, b1 = 0.0;
+		UNR for (int j = 0; j < N; j++) {
+			A1 += sm.vec[3][j];
+			Ab += sm.vec[4][j];
+			a1 += sm.vec[5][j];
+			b1 += sm.vec[6][j];
+		}
+		const double Lam1 = 1.0 / A1;
+		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : 1.0 / Ab);
+		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
+	}
+	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
+	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
+	if (P.torque_sat) {
+		const double lim = md.effort[rr];
+		tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
+	}
+	if (P.gravity_comp) {
+		const double* gv = md.gravity;
+		const double ax_ = Ic[1] - Ic[0] * o[0], ay_ = Ic[2] - Ic[0] * o[1], az_ = Ic[3] - Ic[0] * o[2];  // m (c - o)
+		const double cx = z[1] * az_ - z[2] * ay_, cy = z[2] * ax_ - z[0] * az_, cz = z[0] * ay_ - z[1] * ax_;
+		const double tgr = -(cx * gv[0] + cy * gv[1] + cz * gv[2]);
+		const double tgp = -Ic[0] * (z[0] * gv[0] + z[1] * gv[1] + z[2] * gv[2]);
+		tv += rev ? tgr : tgp;
+	}
+	if (singular) tv = __builtin_nan("");
+	if (live && act) P.tau[(size_t)r * ld + b] = tv;
+	if (live && r == 0) P.status[b] = singular ? 1 : 0;
+}
+
+hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
+	const dim3 grid((P.B + 7) / 8), block(64);
+	hipLaunchKernelGGL(saip_cycle_oct, grid, block, 0, stream, P);
+	return hipGetLastError();
+}
+
+}  // namespace saip

@@ -1,0 +1,132 @@
+"""Eight-lanes-per-instance kernel (saip_cycle_oct, the small-batch path of the headline stack) against the CPU oracle."""
+import numpy as np
+import pytest
+
+import workloads as W
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+OCT = 3
+
+
+def _engine(model_name, tasks, B):
+    from sai_primitives_amd.controller import controller_from_specs
+    return controller_from_specs(model_name, tasks, B, device=0)
+
+
+def _cycle(robot, ctrl, q, dq, goals):
+    robot.setQ(q)
+    robot.setDq(dq)
+    robot.updateModel()
+    ctrl.updateControllerTaskModels()
+    ctrl.setGoals(goals)
+    return ctrl.computeControlTorques()
+
+
+@pytest.mark.parametrize("B", [4096, 1001, 5])
+def test_oct_matches_oracle_config2(B):
+    from oracle import Oracle
+    d = W.make_inputs(2, B)
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(OCT)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_oct"
+    assert np.array_equal(ctrl.status, st)
+    err = W.torque_error(tau, ref)
+    print("oct cfg2 B", B, "err", err)
+    assert err < TOL
+
+
+def test_oct_is_the_default_for_the_headline_batch():
+    d = W.make_inputs(2, 4096)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 4096)
+    _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_oct"
+    d = W.make_inputs(3, 64)   # partial tasks: not covered
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
+    _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_lane"
+    ctrl.setKernel(OCT)
+    with pytest.raises(Exception):
+        _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+
+
+@pytest.mark.parametrize("variant", ["gravity_saturation", "full_decoupling", "impedance", "integrators_velsat", "two_thresholds_off"])
+def test_oct_options(variant):
+    from oracle import Oracle
+    B = 512
+    d = W.make_inputs(2, B)
+    spec = W.config_tasks(2)
+    opts = {}
+    cycles = 1
+    if variant == "gravity_saturation":
+        opts = dict(gravity_comp=True, torque_saturation=True)
+    elif variant == "full_decoupling":
+        spec[0]["decoupling"] = W.FULL_DYNAMIC_DECOUPLING
+        spec[1]["decoupling"] = W.FULL_DYNAMIC_DECOUPLING
+    elif variant == "impedance":
+        spec[0]["decoupling"] = W.IMPEDANCE
+        spec[1]["decoupling"] = W.IMPEDANCE
+    elif variant == "integrators_velsat":
+        spec[0].update(ki_pos=5.0, ki_ori=7.0)
+        spec[1].update(ki=3.0, vel_sat=True, sat=0.4)
+        cycles = 4
+    elif variant == "two_thresholds_off":
+        spec[0]["bie_threshold"] = 0.5   # several diagonal entries of M clamped: one Sherman-Morrison update each
+        spec[1]["bie_threshold"] = 0.5
+    orc = Oracle(d["model"], spec, **opts)
+    robot, ctrl, _ = _engine(d["model"].name, spec, B)
+    ctrl.setKernel(OCT)
+    ctrl.enableGravityCompensation(opts.get("gravity_comp", False))
+    ctrl.enableTorqueSaturation(opts.get("torque_saturation", False))
+    rng = np.random.default_rng(8)
+    q = d["q"].copy()
+    for c in range(cycles):
+        tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+        assert ctrl.kernelName() == "saip_cycle_oct"
+        ref, st = orc.step(q, d["dq"], d["goals"], nthreads=8)
+        assert np.array_equal(ctrl.status, st)
+        err = W.torque_error(tau, ref)
+        print("oct", variant, "cycle", c, "err", err)
+        assert err < TOL
+        q = q + 1e-3 * rng.standard_normal(q.shape)
+
+
+@pytest.mark.parametrize("cfg", [12, 14])
+def test_oct_flags_and_slow_path(cfg):
+    """near-singular instances: flagged by the oct kernel, recomputed by the general kernel behind it (truncated task / blended strategies)"""
+    from oracle import Oracle
+    B = 768
+    d = W.make_inputs(cfg, B)
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(OCT)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_oct"
+    assert np.array_equal(ctrl.status, st) and (st != 0).sum() > B // 4
+    assert W.torque_error(tau, ref) < TOL
+    # default handling: the same instances are flagged, the others are right
+    robot, ctrl, _ = _engine(d["model"].name, W.config_tasks(2), B)
+    ctrl.setKernel(OCT)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status == 1, st != 0) and np.isnan(tau[st != 0]).all()
+    assert W.torque_error(tau[st == 0], ref[st == 0]) < TOL
+
+
+def test_oct_uniform_postures_predicate_matches_oracle():
+    """uniformly random postures (more than half outside the non-singular branch): the certificate / exact fallback of the oct kernel
+    takes the same decisions as the oracle's SVD"""
+    from oracle import Oracle
+    B = 2048
+    d = W.make_inputs(2, B)
+    rng = np.random.default_rng(31)
+    q = rng.uniform(d["model"].q_lower, d["model"].q_upper, size=d["q"].shape)
+    ref, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(OCT)
+    tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status, st)
+    ok = st == 0
+    print("uniform postures: valid", int(ok.sum()), "of", B, "err", W.torque_error(tau[ok], ref[ok]))
+    assert W.torque_error(tau[ok], ref[ok]) < TOL
