@@ -22,6 +22,18 @@
 namespace saip {
 
 #define UNR _Pragma("unroll")
+#if defined(SAIP_STAMP_OCT)
+// diagnostic build only (never shipped): s_memtime of wavefront 0 at the phase boundaries
+__device__ unsigned long long saip_stamps_oct[64];
+#define STAMP(i)                                                                              \
+	do {                                                                                      \
+		__builtin_amdgcn_sched_barrier(0);                                                    \
+		if (blockIdx.x == 0 && threadIdx.x == 0) saip_stamps_oct[i] = __builtin_amdgcn_s_memtime(); \
+		__builtin_amdgcn_sched_barrier(0);                                                    \
+	} while (0)
+#else
+#define STAMP(i)
+#endif
 
 struct OctInst {
 	double X[2][8][12];  // forward-kinematics prefix product, ping-pong: per joint R (9, row-major) + o (3)
@@ -121,6 +133,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const TaskDev& mf = P.tasks[0];
 	const TaskDev& jt = P.tasks[1];
 
+	STAMP(0);
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
@@ -129,6 +142,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
 	if (act) sm.vec[0][r] = dq_r;
 
+	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
 	double Tw[12];
 	{
@@ -168,6 +182,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		UNR for (int e = 0; e < 12; e++) sm.X[cur ^ 1][r][e] = Tw[e];
 		__syncthreads();
 	}
+	STAMP(2);
 	// world frames of all bodies are now in X[1]; this lane's in Tw.  Padding lane 7 holds T_6 o T_6(local): unused.
 	double z[3], o[3];
 	{
@@ -209,12 +224,14 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
+	STAMP(3);
 	double Ic[10];  // composite inertia of the subtree of joint rr (serial chain: bodies rr..6)
 	UNR for (int e = 0; e < 10; e++) Ic[e] = 0.0;
 	UNR for (int l = 0; l < N; l++) {
 		const bool in = l >= rr;
 		UNR for (int e = 0; e < 10; e++) Ic[e] += in ? sm.body[l][e] : 0.0;
 	}
+	STAMP(4);
 	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
 	{
 		double w[3], v[3];
@@ -241,6 +258,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
+	STAMP(5);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
 	double mi[N], mb[N], mdiag[N];
 	{
@@ -251,6 +269,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		oct_cholesky<N>(L, dinv);
 		oct_solve_unit<N>(L, dinv, rr, mi);
 	}
+	STAMP(6);
 	UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
 	if (P.any_bie) {
 		// M_BIE = M + sum_e c_e e e^T (diagonal clamped from below, SingularityHandler.cpp:176-182): one Sherman-Morrison update of the
@@ -277,6 +296,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.MB[r][j] = mb[j];
 		}
 	}
+	STAMP(7);
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
 	double pw[3], Rc[9];
 	{
@@ -300,6 +320,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
+	STAMP(8);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
@@ -313,6 +334,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			vw[a] = s;
 		}
 	}
+	STAMP(9);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false;
 	{
@@ -389,6 +411,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 	}
+	STAMP(10);
 	// ---- operationalSpaceMatrices(J): row a of T1 = J M^-1 and of A = T1 J^T (and the M_BIE variants) per lane
 	const int ra = r < 6 ? r : 5;
 	{
@@ -415,6 +438,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
+	STAMP(11);
 	double lam[6], lmod[6];
 	{
 		double L[6][6], dinv[6];
@@ -436,6 +460,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (r < 6) {
 		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
 	}
+	STAMP(12);
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
 	{
@@ -479,6 +504,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		if (r < 6) sm.vec[2][r] = s;
 	}
 	__syncthreads();
+	STAMP(13);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J, row rr:  N1[i][j] = d_ij - sum_a (Lambda T1[:, i])_a J[a][j]
 	double tau_r;
 	double n1[N];
@@ -507,6 +533,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
+	STAMP(14);
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
 	double cj[N];  // column rr of N_1
 	double cn = 0.0;
@@ -526,6 +553,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			jb = j;
 		}
 	}
+	STAMP(15);
 	bool empty = false, need_exact = false;
 	if (frob2 < 1e-6) empty = true;  // ||Jp||_F < 1e-3: empty range (matrixRangeBasis)
 	else if (best < 1e-5) need_exact = true;
@@ -594,6 +622,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	if (act) sm.vec[8][r] = d_r;
 	__syncthreads();
+	STAMP(16);
 	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
 	double g_jt = 0.0;
 	{
@@ -640,6 +669,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
 	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
+	STAMP(17);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {
 		const double lim = md.effort[rr];
@@ -656,6 +686,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (singular) tv = __builtin_nan("");
 	if (live && act) P.tau[(size_t)r * ld + b] = tv;
 	if (live && r == 0) P.status[b] = singular ? 1 : 0;
+	STAMP(18);
 }
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
@@ -664,4 +695,9 @@ hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	return hipGetLastError();
 }
 
+#if defined(SAIP_STAMP_OCT)
+extern "C" int saip_debug_stamps_oct(unsigned long long* out, int n) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_oct), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#endif
 }  // namespace saip
