@@ -274,7 +274,7 @@ saip_status saip_batch_get_torques_host(saip_batch*, double* tau_host, uint8_t* 
 saip_status saip_batch_get_task_nullspace_host(saip_batch*, int task, double* N /*[dof*dof][B]*/);
 
 /* kernel selection: 0 = auto, 1 = general workgroup-per-instance kernel, 2 = lane-per-instance register kernel (dof <= 8),
- * 3 = eight-lanes-per-instance kernel (7-dof chain, full MotionForceTask + full JointTask; the auto choice for batches <= 4096) */
+ * 3 = eight-lanes-per-instance kernel (7-dof chain, full MotionForceTask + full JointTask; the auto choice for batches <= 8192) */
 saip_status saip_batch_set_kernel(saip_batch*, int which);
 const char* saip_batch_kernel_name(saip_batch*);
 /* HIP-event timing of `steps` back-to-back cycles on the engine stream (after `warmup` untimed ones):

@@ -1286,7 +1286,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
 		// small batches of the headline stack: eight lanes per instance (the lane kernel would leave most of the chip idle)
 		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
-		const int oct_max = oct_env ? atoi(oct_env) : 4096;  // two wavefronts per CU (57 KB of LDS each): beyond that the lane kernel wins (measured)
+		const int oct_max = oct_env ? atoi(oct_env) : 8192;  // four wavefronts per CU (35 KB of LDS each): beyond that the lane kernel wins (measured)
 		const bool oct = oct_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
 		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
 		if (oct) lane_ok = true;

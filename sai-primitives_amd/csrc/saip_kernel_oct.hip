@@ -36,15 +36,39 @@ __device__ unsigned long long saip_stamps_oct[64];
 #endif
 
 struct OctInst {
-	double X[2][8][12];  // forward-kinematics prefix product, ping-pong: per joint R (9, row-major) + o (3)
+	union {  // the kinematics / inertia scratch is dead before the task matrices are written
+		struct {
+			double X[2][8][12];  // forward-kinematics prefix product, ping-pong: per joint R (9, row-major) + o (3)
+			double body[8][10];  // spatial inertia about the world origin: m, h(3), Io(6: xx yy zz xy xz yz)
+			double M[8][8];
+		};
+		struct {
+			double T1[6][8], A[6][8], Am[6][8], Lam[6][8];  // Lam also carries J M_BIE^-1 until Lambda exists
+			double N1[8][8];
+			double Gx[8][8];     // Gram matrix of the exact range-basis path (its eigenvectors go to T1.., dead by then)
+		};
+	};
 	double zo[8][6];     // world joint axis z (3), joint origin o (3)
-	double body[8][10];  // spatial inertia about the world origin: m, h(3), Io(6: xx yy zz xy xz yz)
-	double M[8][8], Minv[8][8], MB[8][8];
-	double J[6][8], T1[6][8], A[6][8], Am[6][8], Lam[6][8];
-	double N1[8][8];
-	double vec[10][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions, 7 u, 8 d, 9 flags
-	double pad_[2];      // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+	double J[6][8];
+	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions / row exchange, 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
+	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
 };
+static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
+static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
+
+// 1/x and 1/sqrt(x) from the hardware estimates plus two Newton steps: full double accuracy for the normal-range, positive arguments met
+// here (pivots of SPD factorisations), without the scaling / fix-up sequences of the IEEE division and the library rsqrt
+__device__ __forceinline__ double oct_rcp(const double x) {
+	double y = __builtin_amdgcn_rcp(x);
+	y = fma(fma(-x, y, 1.0), y, y);
+	return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ double oct_rsqrt(const double x) {
+	double y = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+	y = fma(y, fma(-h * y, y, 0.5), y);
+	return fma(y, fma(-h * y, y, 0.5), y);
+}
 
 __device__ __forceinline__ void oct_mat3_vec(const double* R, const double* v, double* out) {
 	UNR for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
@@ -94,7 +118,7 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 template <int R>
 __device__ __forceinline__ void oct_cholesky(double (&L)[R][R], double (&dinv)[R]) {
 	UNR for (int k = 0; k < R; k++) {
-		const double rs = rsqrt(L[k][k]);
+		const double rs = oct_rsqrt(L[k][k]);
 		dinv[k] = rs;
 		UNR for (int i = k + 1; i < R; i++) L[i][k] *= rs;
 		UNR for (int j = k + 1; j < R; j++)
@@ -137,10 +161,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
-	double G24[24];
-	UNR for (int e = 0; e < 24; e++) G24[e] = mf.goal[(size_t)e * ld + b];
+	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
 	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
-	if (act) sm.vec[0][r] = dq_r;
 
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -168,6 +190,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	UNR for (int e = 0; e < 12; e++) sm.X[0][r][e] = Tw[e];
 	__syncthreads();
+	if (act) sm.vec[0][r] = dq_r;
+	sm.vec[10][r] = gl0;
+	sm.vec[11][r] = gl1;
+	sm.vec[12][r] = gl2;
 	UNR for (int step = 0; step < 3; step++) {
 		const int d = 1 << step, cur = step & 1;
 		if (r >= d) {  // T_r <- T_{r-d} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
@@ -278,22 +304,16 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			const double ce = fmax(P.bie_thr - mdiag[e], 0.0);
 			if (__any(ce > 0.0)) {
 				if (r == e) {
-					UNR for (int j = 0; j < N; j++) sm.MB[e][j] = mb[j];
+					UNR for (int j = 0; j < N; j++) sm.vec[3][j] = mb[j];
 				}
 				__syncthreads();
 				double re[N];
-				UNR for (int j = 0; j < N; j++) re[j] = sm.MB[e][j];
-				const double gamma = ce / fma(ce, re[e], 1.0);
+				UNR for (int j = 0; j < N; j++) re[j] = sm.vec[3][j];
+				const double gamma = ce * oct_rcp(fma(ce, re[e], 1.0));
 				const double mbe = mb[e];
 				UNR for (int j = 0; j < N; j++) mb[j] = fma(-gamma * mbe, re[j], mb[j]);
 				__syncthreads();
 			}
-		}
-	}
-	if (act) {
-		UNR for (int j = 0; j < N; j++) {
-			sm.Minv[r][j] = mi[j];
-			sm.MB[r][j] = mb[j];
 		}
 	}
 	STAMP(7);
@@ -347,7 +367,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				G[c][a] = s;
 				if (a == c) tr += s;
 			}
-		const double itr = 1.0 / tr;
+		const double itr = oct_rcp(tr);
 		const double smax2 = mf.s_max * mf.s_max, tol2 = mf.s_abs_tol * mf.s_abs_tol;
 		auto ldl_positive = [&](const double shift) {
 			double Gs[6][6];
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int kk = 0; kk < 6; kk++) {
 				const double d = Gs[kk][kk];
 				pos = pos && (d > 1e-13);
-				const double id = 1.0 / d;
+				const double id = oct_rcp(d);
 				UNR for (int i = kk + 1; i < 6; i++) {
 					const double lik = Gs[i][kk] * id;
 					UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
@@ -412,20 +432,34 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	STAMP(10);
-	// ---- operationalSpaceMatrices(J): row a of T1 = J M^-1 and of A = T1 J^T (and the M_BIE variants) per lane
+	// ---- operationalSpaceMatrices(J): this lane's COLUMN of T1 = J M^-1 (M^-1 symmetric: its column rr is the row this lane solved for),
+	// then its ROW of A = T1 J^T; the same with M_BIE^-1
 	const int ra = r < 6 ? r : 5;
+	double t1c[6];
 	{
-		double t1[N], tb[N];
-		UNR for (int j = 0; j < N; j++) t1[j] = tb[j] = 0.0;
-		UNR for (int l = 0; l < N; l++) {
-			const double jal = sm.J[ra][l];
-			UNR for (int j = 0; j < N; j++) {
-				t1[j] = fma(jal, sm.Minv[l][j], t1[j]);
-				tb[j] = fma(jal, sm.MB[l][j], tb[j]);
+		double tbc[6];
+		UNR for (int a = 0; a < 6; a++) {
+			double s1 = 0.0, s2 = 0.0;
+			UNR for (int l = 0; l < N; l++) {
+				s1 = fma(Jf[a][l], mi[l], s1);
+				s2 = fma(Jf[a][l], mb[l], s2);
+			}
+			t1c[a] = s1;
+			tbc[a] = s2;
+		}
+		if (act) {
+			UNR for (int a = 0; a < 6; a++) {
+				sm.T1[a][r] = t1c[a];
+				sm.Lam[a][r] = tbc[a];
 			}
 		}
+		__syncthreads();
+		double t1[N], tb[N];
+		UNR for (int j = 0; j < N; j++) {
+			t1[j] = sm.T1[ra][j];
+			tb[j] = sm.Lam[ra][j];
+		}
 		if (r < 6) {
-			UNR for (int j = 0; j < N; j++) sm.T1[r][j] = t1[j];
 			UNR for (int c = 0; c < 6; c++) {
 				double s = 0.0, s2 = 0.0;
 				UNR for (int j = 0; j < N; j++) {
@@ -464,7 +498,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
 	{
-		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6];
+		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6], G24[24];
+		UNR for (int e = 0; e < 24; e++) G24[e] = sm.vec[10 + (e >> 3)][e & 7];
 		if (track_mf) {
 			UNR for (int i = 0; i < 3; i++) {
 				ip[i] = mf.integ[(size_t)i * ld + b];
@@ -509,11 +544,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	double tau_r;
 	double n1[N];
 	{
-		double g[6], t2[6], t1c[6];
-		UNR for (int a = 0; a < 6; a++) {
-			g[a] = sm.vec[2][a];
-			t1c[a] = sm.T1[a][rr];
-		}
+		double g[6], t2[6];
+		UNR for (int a = 0; a < 6; a++) g[a] = sm.vec[2][a];
 		double s = 0.0;
 		UNR for (int a = 0; a < 6; a++) s = fma(sm.J[a][rr], g[a], s);
 		tau_r = s;
@@ -559,7 +591,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	else if (best < 1e-5) need_exact = true;
 	double u[N], d_r, u_own;
 	{
-		const double inv = rsqrt(best);
+		const double inv = oct_rsqrt(best);
 		u_own = sm.N1[rr][jb] * inv;
 		double dd = 0.0;
 		UNR for (int i = 0; i < N; i++) {
@@ -582,8 +614,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	if (__any(need_exact)) {  // exact path (rare): Gram eigen-decomposition with the reference's tolerances, one lane per instance
 		if (need_exact && r == 0) {
-			double* Gm = &sm.M[0][0];   // M and the kinematics scratch are dead by now
-			double* Vm = &sm.X[0][0][0];
+			double* Gm = &sm.Gx[0][0];
+			double* Vm = &sm.T1[0][0];  // 64 doubles over T1 / A: dead by now
 			double trc = 0.0;
 			for (int a = 0; a < N; a++)
 				for (int c = 0; c < N; c++) {
@@ -664,8 +696,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			a1 += sm.vec[5][j];
 			b1 += sm.vec[6][j];
 		}
-		const double Lam1 = 1.0 / A1;
-		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : 1.0 / Ab);
+		const double Lam1 = oct_rcp(A1);
+		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : oct_rcp(Ab));
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
 	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
