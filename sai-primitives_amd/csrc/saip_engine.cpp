@@ -1269,6 +1269,10 @@ static bool oct_eligible(const saip_batch* b, const CycleParams& P) {
 	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;
 	if (mf.k != 6 || !mf.bm_identity || mf.general_law || mf.cl_force || mf.cl_moment) return false;
 	if (jt.m != 7 || !jt.s_identity) return false;
+	for (int i = 0; i < 9; i++) {  // full task: projections and sigma matrices are identities (the kernel's control law relies on it)
+		const double id = (i % 4 == 0) ? 1.0 : 0.0;
+		if (mf.Ppos[i] != id || mf.Pori[i] != id || mf.sig_p[i] != id || mf.sig_o[i] != id) return false;
+	}
 	return lane_eligible(b);
 }
 static saip_status launch_cycle(saip_batch* b, bool diag) {

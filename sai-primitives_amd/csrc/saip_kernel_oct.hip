@@ -18,6 +18,7 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_fk.h"
 
 namespace saip {
 
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double ax = md.axis[rr][0], ay = md.axis[rr][1], az = md.axis[rr][2];
 		if (md.jtype[rr] == 1) {
 			double s, c;
-			sincos(q_r, &s, &c);
+			sincos_joint(q_r, &s, &c);
 			const double v = 1.0 - c;
 			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
 								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
@@ -254,8 +255,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	double Ic[10];  // composite inertia of the subtree of joint rr (serial chain: bodies rr..6)
 	UNR for (int e = 0; e < 10; e++) Ic[e] = 0.0;
 	UNR for (int l = 0; l < N; l++) {
-		const bool in = l >= rr;
-		UNR for (int e = 0; e < 10; e++) Ic[e] += in ? sm.body[l][e] : 0.0;
+		const double in = (l >= rr) ? 1.0 : 0.0;
+		UNR for (int e = 0; e < 10; e++) Ic[e] = fma(sm.body[l][e], in, Ic[e]);
 	}
 	STAMP(4);
 	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
@@ -506,15 +507,11 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
 			}
 		}
-		double v[3], w[3], e3[3], tmp[3];
-		UNR for (int i = 0; i < 3; i++) {
-			v[i] = mf.Ppos[3 * i] * vw[0] + mf.Ppos[3 * i + 1] * vw[1] + mf.Ppos[3 * i + 2] * vw[2];
-			w[i] = mf.Pori[3 * i] * vw[3] + mf.Pori[3 * i + 1] * vw[4] + mf.Pori[3 * i + 2] * vw[5];
-		}
+		// full 6-dof task without force space: the task projections and sigma_position / sigma_orientation are identities (oct_eligible)
+		double e3[3];
 		UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G24[i];
-		UNR for (int i = 0; i < 3; i++) ip[i] += (mf.sig_p[3 * i] * e3[0] + mf.sig_p[3 * i + 1] * e3[1] + mf.sig_p[3 * i + 2] * e3[2]) * mf.dt;
-		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - mf.kp_pos[i] * e3[i] - mf.kv_pos[i] * (v[i] - G24[12 + i]) - mf.ki_pos[i] * ip[i];
-		UNR for (int i = 0; i < 3; i++) Fum[i] = mf.sig_p[3 * i] * tmp[0] + mf.sig_p[3 * i + 1] * tmp[1] + mf.sig_p[3 * i + 2] * tmp[2];
+		UNR for (int i = 0; i < 3; i++) ip[i] = fma(e3[i], mf.dt, ip[i]);
+		UNR for (int i = 0; i < 3; i++) Fum[i] = G24[18 + i] - mf.kp_pos[i] * e3[i] - mf.kv_pos[i] * (vw[i] - G24[12 + i]) - mf.ki_pos[i] * ip[i];
 		double oe[3] = {0, 0, 0};  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
 		UNR for (int c = 0; c < 3; c++) {
 			const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
@@ -522,11 +519,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
 			oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
 		}
-		double dphi[3];
-		UNR for (int i = 0; i < 3; i++) dphi[i] = mf.sig_o[3 * i] * oe[0] + mf.sig_o[3 * i + 1] * oe[1] + mf.sig_o[3 * i + 2] * oe[2];
-		UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * mf.dt;
-		UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - mf.kp_ori[i] * dphi[i] - mf.kv_ori[i] * (w[i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
-		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = mf.sig_o[3 * i] * tmp[0] + mf.sig_o[3 * i + 1] * tmp[1] + mf.sig_o[3 * i + 2] * tmp[2];
+		UNR for (int i = 0; i < 3; i++) io[i] = fma(oe[i], mf.dt, io[i]);
+		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = G24[21 + i] - mf.kp_ori[i] * oe[i] - mf.kv_ori[i] * (vw[3 + i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
 		if (track_mf && live && !singular && r == 0) {
 			UNR for (int i = 0; i < 3; i++) {
 				mf.integ[(size_t)i * ld + b] = ip[i];
@@ -540,39 +534,38 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	__syncthreads();
 	STAMP(13);
-	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J, row rr:  N1[i][j] = d_ij - sum_a (Lambda T1[:, i])_a J[a][j]
+	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
+	// basis works on), N1[i][rr] = d_i,rr - sum_a T1[a][i] (Lambda J[:, rr])_a, and parks it as a row of the transposed matrix
 	double tau_r;
-	double n1[N];
+	double cj[N];  // column rr of N_1
+	double cn = 0.0;
 	{
-		double g[6], t2[6];
-		UNR for (int a = 0; a < 6; a++) g[a] = sm.vec[2][a];
+		double g[6], t3[6], jc[6];
+		UNR for (int a = 0; a < 6; a++) {
+			g[a] = sm.vec[2][a];
+			jc[a] = sm.J[a][rr];
+		}
 		double s = 0.0;
-		UNR for (int a = 0; a < 6; a++) s = fma(sm.J[a][rr], g[a], s);
+		UNR for (int a = 0; a < 6; a++) s = fma(jc[a], g[a], s);
 		tau_r = s;
 		UNR for (int a = 0; a < 6; a++) {
 			double acc = 0.0;
-			UNR for (int c = 0; c < 6; c++) acc = fma(sm.Lam[a][c], t1c[c], acc);
-			t2[a] = acc;
+			UNR for (int c = 0; c < 6; c++) acc = fma(sm.Lam[a][c], jc[c], acc);
+			t3[a] = acc;
 		}
-		UNR for (int j = 0; j < N; j++) {
-			double acc = (j == rr) ? 1.0 : 0.0;
-			UNR for (int a = 0; a < 6; a++) acc = fma(-t2[a], Jf[a][j], acc);
-			n1[j] = acc;
+		UNR for (int i = 0; i < N; i++) {
+			double acc = (i == rr) ? 1.0 : 0.0;
+			UNR for (int a = 0; a < 6; a++) acc = fma(-sm.T1[a][i], t3[a], acc);
+			cj[i] = acc;
+			cn = fma(acc, acc, cn);
 		}
 		if (act) {
-			UNR for (int j = 0; j < N; j++) sm.N1[r][j] = n1[j];
+			UNR for (int i = 0; i < N; i++) sm.N1[r][i] = cj[i];  // transposed storage: row r = column r of N_1
 			sm.vec[1][r] = tau_r;
 		}
 	}
-	__syncthreads();
 	STAMP(14);
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
-	double cj[N];  // column rr of N_1
-	double cn = 0.0;
-	UNR for (int i = 0; i < N; i++) {
-		cj[i] = sm.N1[i][rr];
-		cn = fma(cj[i], cj[i], cn);
-	}
 	sm.vec[3][r] = act ? cn : -1.0;
 	__syncthreads();
 	double best = -1.0, frob2 = 0.0;
@@ -592,10 +585,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	double u[N], d_r, u_own;
 	{
 		const double inv = oct_rsqrt(best);
-		u_own = sm.N1[rr][jb] * inv;
+		u_own = sm.N1[jb][rr] * inv;
 		double dd = 0.0;
 		UNR for (int i = 0; i < N; i++) {
-			u[i] = sm.N1[i][jb] * inv;
+			u[i] = sm.N1[jb][i] * inv;
 			dd = fma(u[i], cj[i], dd);
 		}
 		d_r = dd;  // (u^T Jp)_rr: the row of Jh = U^T Jp
@@ -620,7 +613,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			for (int a = 0; a < N; a++)
 				for (int c = 0; c < N; c++) {
 					double s = 0.0;
-					for (int j = 0; j < N; j++) s = fma(sm.N1[a][j], sm.N1[c][j], s);
+					for (int j = 0; j < N; j++) s = fma(sm.N1[j][a], sm.N1[j][c], s);  // (Jp Jp^T)_ac from the transposed storage
 					Gm[a * 8 + c] = s;
 					if (a == c) trc += s;
 				}
