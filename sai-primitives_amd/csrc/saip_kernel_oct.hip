@@ -39,8 +39,7 @@ __device__ unsigned long long saip_stamps_oct[64];
 struct OctInst {
 	union {  // the kinematics / inertia scratch is dead before the task matrices are written
 		struct {
-			double X[2][8][12];  // forward-kinematics prefix product, ping-pong: per joint R (9, row-major) + o (3)
-			double body[8][10];  // spatial inertia about the world origin: m, h(3), Io(6: xx yy zz xy xz yz)
+			double X[8][12];     // world frame per joint: R (9, row-major) + o (3)
 			double M[8][8];
 		};
 		struct {
@@ -52,7 +51,7 @@ struct OctInst {
 	double zo[8][6];     // world joint axis z (3), joint origin o (3)
 	double J[6][8];
 	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions / row exchange, 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
-	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+	double pad_[26];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
@@ -70,6 +69,16 @@ __device__ __forceinline__ double oct_rsqrt(const double x) {
 	y = fma(y, fma(-h * y, y, 0.5), y);
 	return fma(y, fma(-h * y, y, 0.5), y);
 }
+
+// value of the lane `n` positions up (row_shl) / down (row_shr) inside the 16-lane DPP row, 0 beyond it: a VALU move, no LDS round trip.
+// Callers mask the lanes whose source sits in the neighbouring instance (two instances share a row).
+template <int CTRL>
+__device__ __forceinline__ double oct_dpp(const double x) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110 };
 
 __device__ __forceinline__ void oct_mat3_vec(const double* R, const double* v, double* out) {
 	UNR for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
@@ -189,28 +198,27 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
 		}
 	}
-	UNR for (int e = 0; e < 12; e++) sm.X[0][r][e] = Tw[e];
-	__syncthreads();
 	if (act) sm.vec[0][r] = dq_r;
 	sm.vec[10][r] = gl0;
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
-	UNR for (int step = 0; step < 3; step++) {
-		const int d = 1 << step, cur = step & 1;
-		if (r >= d) {  // T_r <- T_{r-d} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
-			double Xa[12], Tn[12];
-			UNR for (int e = 0; e < 12; e++) Xa[e] = sm.X[cur][r - d][e];
-			UNR for (int i = 0; i < 3; i++) {
-				UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j];
-				Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];
-			}
-			UNR for (int e = 0; e < 12; e++) Tw[e] = Tn[e];
-		}
-		UNR for (int e = 0; e < 12; e++) sm.X[cur ^ 1][r][e] = Tw[e];
-		__syncthreads();
+#define OCT_PREFIX_STEP(D)                                                                                                          \
+	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
+		double Xa[12], Tn[12];                                                                                                      \
+		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
+		UNR for (int i = 0; i < 3; i++) {                                                                                           \
+			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
+			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
+		}                                                                                                                           \
+		const bool take = r >= D;                                                                                                   \
+		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
 	}
-	STAMP(2);
-	// world frames of all bodies are now in X[1]; this lane's in Tw.  Padding lane 7 holds T_6 o T_6(local): unused.
+	OCT_PREFIX_STEP(1)
+	OCT_PREFIX_STEP(2)
+	OCT_PREFIX_STEP(4)
+#undef OCT_PREFIX_STEP
+	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];  // the motion-force task reads its body's frame from here
+	// this lane's world frame is in Tw (padding lane 7: unused)
 	double z[3], o[3];
 	{
 		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
@@ -219,6 +227,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	const bool rev = md.jtype[rr] == 1;
 	// per-body spatial inertia about the world origin
+	double Ic[10];
 	{
 		double c[3], Bd[10];
 		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
@@ -242,23 +251,32 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		Bd[7] = Iw[1] - m * c[0] * c[1];
 		Bd[8] = Iw[2] - m * c[0] * c[2];
 		Bd[9] = Iw[5] - m * c[1] * c[2];
+		UNR for (int e = 0; e < 10; e++) Ic[e] = act ? Bd[e] : 0.0;
 		if (act) {
-			UNR for (int e = 0; e < 10; e++) sm.body[r][e] = Bd[e];
 			UNR for (int e = 0; e < 3; e++) {
 				sm.zo[r][e] = z[e];
 				sm.zo[r][3 + e] = o[e];
 			}
 		}
 	}
-	__syncthreads();
-	STAMP(3);
-	double Ic[10];  // composite inertia of the subtree of joint rr (serial chain: bodies rr..6)
-	UNR for (int e = 0; e < 10; e++) Ic[e] = 0.0;
-	UNR for (int l = 0; l < N; l++) {
-		const double in = (l >= rr) ? 1.0 : 0.0;
-		UNR for (int e = 0; e < 10; e++) Ic[e] = fma(sm.body[l][e], in, Ic[e]);
+	// composite inertia of the subtree of joint r (serial chain: bodies r..6): suffix sums over the instance's lanes by DPP row_shl
+	{
+		// (selects, not multiplications by 0: a neighbouring instance with non-finite state must not leak in)
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
+			Ic[e] += (r + 1 < 8) ? up : 0.0;
+		}
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
+			Ic[e] += (r + 2 < 8) ? up : 0.0;
+		}
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
+			Ic[e] += (r + 4 < 8) ? up : 0.0;
+		}
 	}
-	STAMP(4);
+	__syncthreads();
+	STAMP(2);
 	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
 	{
 		double w[3], v[3];
@@ -285,7 +303,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
-	STAMP(5);
+	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
 	double mi[N], mb[N], mdiag[N];
 	{
@@ -296,7 +314,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		oct_cholesky<N>(L, dinv);
 		oct_solve_unit<N>(L, dinv, rr, mi);
 	}
-	STAMP(6);
+	STAMP(4);
 	UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
 	if (P.any_bie) {
 		// M_BIE = M + sum_e c_e e e^T (diagonal clamped from below, SingularityHandler.cpp:176-182): one Sherman-Morrison update of the
@@ -317,13 +335,13 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 	}
-	STAMP(7);
+	STAMP(5);
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
 	double pw[3], Rc[9];
 	{
 		const int bd = mf.body;
 		double Rb[12];
-		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[1][bd][e];
+		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[bd][e];
 		oct_mat3_vec(Rb, mf.pos, pw);
 		UNR for (int e = 0; e < 3; e++) pw[e] += Rb[9 + e];
 		UNR for (int i = 0; i < 3; i++)
@@ -341,7 +359,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
-	STAMP(8);
+	STAMP(6);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
@@ -355,7 +373,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			vw[a] = s;
 		}
 	}
-	STAMP(9);
+	STAMP(7);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false;
 	{
@@ -432,7 +450,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 	}
-	STAMP(10);
+	STAMP(8);
 	// ---- operationalSpaceMatrices(J): this lane's COLUMN of T1 = J M^-1 (M^-1 symmetric: its column rr is the row this lane solved for),
 	// then its ROW of A = T1 J^T; the same with M_BIE^-1
 	const int ra = r < 6 ? r : 5;
@@ -473,7 +491,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
-	STAMP(11);
+	STAMP(9);
 	double lam[6], lmod[6];
 	{
 		double L[6][6], dinv[6];
@@ -495,7 +513,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (r < 6) {
 		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
 	}
-	STAMP(12);
+	STAMP(10);
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
 	{
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		if (r < 6) sm.vec[2][r] = s;
 	}
 	__syncthreads();
-	STAMP(13);
+	STAMP(11);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
 	// basis works on), N1[i][rr] = d_i,rr - sum_a T1[a][i] (Lambda J[:, rr])_a, and parks it as a row of the transposed matrix
 	double tau_r;
@@ -564,7 +582,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.vec[1][r] = tau_r;
 		}
 	}
-	STAMP(14);
+	STAMP(12);
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
 	sm.vec[3][r] = act ? cn : -1.0;
 	__syncthreads();
@@ -578,7 +596,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			jb = j;
 		}
 	}
-	STAMP(15);
+	STAMP(13);
 	bool empty = false, need_exact = false;
 	if (frob2 < 1e-6) empty = true;  // ||Jp||_F < 1e-3: empty range (matrixRangeBasis)
 	else if (best < 1e-5) need_exact = true;
@@ -647,7 +665,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	if (act) sm.vec[8][r] = d_r;
 	__syncthreads();
-	STAMP(16);
+	STAMP(14);
 	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
 	double g_jt = 0.0;
 	{
@@ -694,7 +712,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
 	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
-	STAMP(17);
+	STAMP(15);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {
 		const double lim = md.effort[rr];
@@ -711,7 +729,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (singular) tv = __builtin_nan("");
 	if (live && act) P.tau[(size_t)r * ld + b] = tv;
 	if (live && r == 0) P.status[b] = singular ? 1 : 0;
-	STAMP(18);
+	STAMP(16);
 }
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
