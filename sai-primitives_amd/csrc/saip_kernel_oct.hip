@@ -289,53 +289,46 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double nO[3] = {Ic[4] * w[0] + Ic[7] * w[1] + Ic[8] * w[2] + (hy * v[2] - hz * v[1]),
 							  Ic[7] * w[0] + Ic[5] * w[1] + Ic[9] * w[2] + (hz * v[0] - hx * v[2]),
 							  Ic[8] * w[0] + Ic[9] * w[1] + Ic[6] * w[2] + (hx * v[1] - hy * v[0])};
+		// row r of the lower triangle, M[r][i] for i <= r (M_ir = S_i . (Ic_r S_r)); entries beyond the diagonal are written too but never read
+		double mrow[N];
 		UNR for (int i = 0; i < N; i++) {
 			const double zi[3] = {sm.zo[i][0], sm.zo[i][1], sm.zo[i][2]}, oi[3] = {sm.zo[i][3], sm.zo[i][4], sm.zo[i][5]};
 			const bool revi = md.jtype[i] == 1;
 			const double vi[3] = {oi[1] * zi[2] - oi[2] * zi[1], oi[2] * zi[0] - oi[0] * zi[2], oi[0] * zi[1] - oi[1] * zi[0]};
 			const double vr = zi[0] * nO[0] + zi[1] * nO[1] + zi[2] * nO[2] + vi[0] * f[0] + vi[1] * f[1] + vi[2] * f[2];
 			const double vp = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
-			const double val = revi ? vr : vp;
-			if (act && i <= r) {
-				sm.M[i][r] = val;
-				sm.M[r][i] = val;
-			}
+			mrow[i] = revi ? vr : vp;
+		}
+		if (act) {
+			UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 		}
 	}
 	__syncthreads();
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
-	double mi[N], mb[N], mdiag[N];
+	// M_BIE = M with its diagonal clamped from below (SingularityHandler.cpp:176-182) is factored alongside: the two Cholesky chains are
+	// independent and latency bound, so the second one rides in the first one's issue gaps (a Sherman-Morrison update of the
+	// row-distributed inverse per clamped entry, two LDS exchanges each, measured the same)
+	double mi[N], mb[N];
 	{
 		double L[N][N], dinv[N];
 		UNR for (int i = 0; i < N; i++)
 			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.M[i][j];
-		UNR for (int i = 0; i < N; i++) mdiag[i] = L[i][i];
-		oct_cholesky<N>(L, dinv);
-		oct_solve_unit<N>(L, dinv, rr, mi);
-	}
-	STAMP(4);
-	UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
-	if (P.any_bie) {
-		// M_BIE = M + sum_e c_e e e^T (diagonal clamped from below, SingularityHandler.cpp:176-182): one Sherman-Morrison update of the
-		// row-distributed inverse per clamped entry
-		UNR for (int e = 0; e < N; e++) {
-			const double ce = fmax(P.bie_thr - mdiag[e], 0.0);
-			if (__any(ce > 0.0)) {
-				if (r == e) {
-					UNR for (int j = 0; j < N; j++) sm.vec[3][j] = mb[j];
-				}
-				__syncthreads();
-				double re[N];
-				UNR for (int j = 0; j < N; j++) re[j] = sm.vec[3][j];
-				const double gamma = ce * oct_rcp(fma(ce, re[e], 1.0));
-				const double mbe = mb[e];
-				UNR for (int j = 0; j < N; j++) mb[j] = fma(-gamma * mbe, re[j], mb[j]);
-				__syncthreads();
-			}
+		if (P.any_bie) {
+			double Lb[N][N], dinvb[N];
+			UNR for (int i = 0; i < N; i++)
+				UNR for (int j = 0; j <= i; j++) Lb[i][j] = (i == j) ? fmax(L[i][j], P.bie_thr) : L[i][j];
+			oct_cholesky<N>(L, dinv);
+			oct_cholesky<N>(Lb, dinvb);
+			oct_solve_unit<N>(L, dinv, rr, mi);
+			oct_solve_unit<N>(Lb, dinvb, rr, mb);
+		} else {
+			oct_cholesky<N>(L, dinv);
+			oct_solve_unit<N>(L, dinv, rr, mi);
+			UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
 		}
 	}
-	STAMP(5);
+	STAMP(4);
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
 	double pw[3], Rc[9];
 	{
@@ -359,7 +352,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
-	STAMP(6);
+	STAMP(5);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
@@ -373,7 +366,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			vw[a] = s;
 		}
 	}
-	STAMP(7);
+	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false;
 	{
@@ -450,7 +443,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 	}
-	STAMP(8);
+	STAMP(7);
 	// ---- operationalSpaceMatrices(J): this lane's COLUMN of T1 = J M^-1 (M^-1 symmetric: its column rr is the row this lane solved for),
 	// then its ROW of A = T1 J^T; the same with M_BIE^-1
 	const int ra = r < 6 ? r : 5;
@@ -491,7 +484,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	__syncthreads();
-	STAMP(9);
+	STAMP(8);
 	double lam[6], lmod[6];
 	{
 		double L[6][6], dinv[6];
@@ -513,7 +506,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (r < 6) {
 		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
 	}
-	STAMP(10);
+	STAMP(9);
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
 	{
@@ -551,7 +544,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		if (r < 6) sm.vec[2][r] = s;
 	}
 	__syncthreads();
-	STAMP(11);
+	STAMP(10);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
 	// basis works on), N1[i][rr] = d_i,rr - sum_a T1[a][i] (Lambda J[:, rr])_a, and parks it as a row of the transposed matrix
 	double tau_r;
@@ -582,7 +575,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.vec[1][r] = tau_r;
 		}
 	}
-	STAMP(12);
+	STAMP(11);
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
 	sm.vec[3][r] = act ? cn : -1.0;
 	__syncthreads();
@@ -596,7 +589,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			jb = j;
 		}
 	}
-	STAMP(13);
+	STAMP(12);
 	bool empty = false, need_exact = false;
 	if (frob2 < 1e-6) empty = true;  // ||Jp||_F < 1e-3: empty range (matrixRangeBasis)
 	else if (best < 1e-5) need_exact = true;
@@ -665,7 +658,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	if (act) sm.vec[8][r] = d_r;
 	__syncthreads();
-	STAMP(14);
+	STAMP(13);
 	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
 	double g_jt = 0.0;
 	{
@@ -712,7 +705,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
 	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
-	STAMP(15);
+	STAMP(14);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {
 		const double lim = md.effort[rr];
@@ -729,7 +722,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (singular) tv = __builtin_nan("");
 	if (live && act) P.tau[(size_t)r * ld + b] = tv;
 	if (live && r == 0) P.status[b] = singular ? 1 : 0;
-	STAMP(16);
+	STAMP(15);
 }
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {

@@ -14,9 +14,9 @@ for rep in range(20):
     ctrl.updateControllerTaskModels(); ctrl.computeControlTorques()
     buf = (C.c_ulonglong * 64)()
     capi.lib().saip_debug_stamps_oct(buf, 64)
-    s = np.array(buf[:19], dtype=np.float64)
+    s = np.array(buf[:16], dtype=np.float64)
     dlt = np.diff(s)
     acc = dlt if acc is None else np.minimum(acc, dlt)
-names = ["inputs", "fk local", "fk prefix", "inertia", "Ic", "M col", "chol7+solve", "bie", "J write", "Jf/vw", "cert", "T1/A", "chol6 x2", "law", "tau/N1", "gs norms", "gs exact/d", "jt law", "post"]
+names = ["inputs", "kinematics+inertia+Ic", "M column", "chol7 x2 + solves", "J column", "Jf/vw", "G + certificate", "T1/A", "chol6 x2", "law + g", "tau / N1 column", "range: norms", "range: pivot/deflate", "joint law + Lambda", "post"]
 for n_, c in zip(names, acc): print(f"{n_:14s} {c:8.0f}")
 print("total", acc.sum(), "clocks (100 MHz s_memtime ticks x ?)")
