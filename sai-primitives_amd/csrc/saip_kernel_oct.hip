@@ -43,7 +43,7 @@ struct OctInst {
 			double M[8][8];
 		};
 		struct {
-			double T1[6][8], A[6][8], Am[6][8], Lam[6][8];  // Lam also carries J M_BIE^-1 until Lambda exists
+			double T1[6][8], A[8][8], Am[8][8], Lam[8][8];  // Lam also carries J M_BIE^-1 until Lambda exists; rows 6, 7: padding lanes' scratch
 			double N1[8][8];
 			double Gx[8][8];     // Gram matrix of the exact range-basis path (its eigenvectors go to T1.., dead by then)
 		};
@@ -51,7 +51,7 @@ struct OctInst {
 	double zo[8][6];     // world joint axis z (3), joint origin o (3)
 	double J[6][8];
 	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions / row exchange, 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
-	double pad_[26];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
 		}
 	}
-	if (act) sm.vec[0][r] = dq_r;
+	sm.vec[0][r] = dq_r;
 	sm.vec[10][r] = gl0;
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
@@ -252,11 +252,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		Bd[8] = Iw[2] - m * c[0] * c[2];
 		Bd[9] = Iw[5] - m * c[1] * c[2];
 		UNR for (int e = 0; e < 10; e++) Ic[e] = act ? Bd[e] : 0.0;
-		if (act) {
-			UNR for (int e = 0; e < 3; e++) {
-				sm.zo[r][e] = z[e];
-				sm.zo[r][3 + e] = o[e];
-			}
+		UNR for (int e = 0; e < 3; e++) {  // (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
+			sm.zo[r][e] = z[e];
+			sm.zo[r][3 + e] = o[e];
 		}
 	}
 	// composite inertia of the subtree of joint r (serial chain: bodies r..6): suffix sums over the instance's lanes by DPP row_shl
@@ -299,9 +297,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			const double vp = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
 			mrow[i] = revi ? vr : vp;
 		}
-		if (act) {
-			UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
-		}
+		UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 	}
 	__syncthreads();
 	STAMP(3);
@@ -342,7 +338,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const bool on = rr <= bd;
 		const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
 		const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
-		if (act) {
+		{
 			sm.J[0][r] = on ? (rev ? c0 : z[0]) : 0.0;
 			sm.J[1][r] = on ? (rev ? c1 : z[1]) : 0.0;
 			sm.J[2][r] = on ? (rev ? c2 : z[2]) : 0.0;
@@ -459,11 +455,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			t1c[a] = s1;
 			tbc[a] = s2;
 		}
-		if (act) {
-			UNR for (int a = 0; a < 6; a++) {
-				sm.T1[a][r] = t1c[a];
-				sm.Lam[a][r] = tbc[a];
-			}
+		UNR for (int a = 0; a < 6; a++) {
+			sm.T1[a][r] = t1c[a];
+			sm.Lam[a][r] = tbc[a];
 		}
 		__syncthreads();
 		double t1[N], tb[N];
@@ -471,7 +465,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			t1[j] = sm.T1[ra][j];
 			tb[j] = sm.Lam[ra][j];
 		}
-		if (r < 6) {
+		{
 			UNR for (int c = 0; c < 6; c++) {
 				double s = 0.0, s2 = 0.0;
 				UNR for (int j = 0; j < N; j++) {
@@ -503,9 +497,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			oct_solve_unit<6>(L, dinv, ra, lmod);
 		}
 	}
-	if (r < 6) {
-		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
-	}
+	UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
 	STAMP(9);
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
@@ -541,7 +533,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		// g_a = (Lambda_mod F_um)_a  (SingularityHandler.cpp:307-309; F_f = 0 without a force space); Bm = I for the full task
 		double s = 0.0;
 		UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
-		if (r < 6) sm.vec[2][r] = s;
+		sm.vec[2][r] = s;
 	}
 	__syncthreads();
 	STAMP(10);
@@ -570,10 +562,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			cj[i] = acc;
 			cn = fma(acc, acc, cn);
 		}
-		if (act) {
-			UNR for (int i = 0; i < N; i++) sm.N1[r][i] = cj[i];  // transposed storage: row r = column r of N_1
-			sm.vec[1][r] = tau_r;
-		}
+		UNR for (int i = 0; i < N; i++) sm.N1[r][i] = cj[i];  // transposed storage: row r = column r of N_1
+		sm.vec[1][r] = tau_r;
 	}
 	STAMP(11);
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
@@ -656,7 +646,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 		__syncthreads();
 	}
-	if (act) sm.vec[8][r] = d_r;
+	sm.vec[8][r] = d_r;
 	__syncthreads();
 	STAMP(13);
 	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
