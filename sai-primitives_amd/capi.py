@@ -45,7 +45,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # -2.4 % cfg2 / -3.8 % cfg3 against the default); the OTG and dynamics kernels are faster with the default strategy (integrate
     # 33.6 vs 40.0 us).
     sched = {"csrc/saip_kernel_lane.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-             "csrc/saip_kernel_wg.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+             "csrc/saip_kernel_wg.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+             "csrc/saip_kernel_oct.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     objs = []
     procs = []
     for rel in SOURCES:
