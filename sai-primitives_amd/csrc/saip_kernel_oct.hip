@@ -302,15 +302,32 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	__syncthreads();
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
-	// M_BIE = M with its diagonal clamped from below (SingularityHandler.cpp:176-182) is factored alongside: the two Cholesky chains are
-	// independent and latency bound, so the second one rides in the first one's issue gaps (a Sherman-Morrison update of the
-	// row-distributed inverse per clamped entry, two LDS exchanges each, measured the same)
+	// M_BIE = M + sum_e c_e e e^T, the diagonal clamped from below (SingularityHandler.cpp:176-182).  Usual case (at most one clamped
+	// entry per instance, e.g. the last link of an arm): nothing is factored twice -- with m = column e of M^-1 and
+	// beta = c / (1 + c m_e), M_BIE^-1 = M^-1 - beta m m^T, hence J M_BIE^-1 J^T = A - beta t t^T (t = J m) and, by Sherman-Morrison,
+	// Lambda_mod = Lambda + gamma (Lambda t)(Lambda t)^T with gamma = beta / (1 - beta t^T Lambda t).  Several clamped entries in some
+	// instance of the wavefront (wave-uniform): M_BIE is factored alongside M and everything is formed twice.
 	double mi[N], mb[N];
+	int eclamp = 0;
+	double cclamp = 0.0;
+	bool general_bie = false;
 	{
 		double L[N][N], dinv[N];
 		UNR for (int i = 0; i < N; i++)
 			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.M[i][j];
 		if (P.any_bie) {
+			int nclamp = 0;
+			UNR for (int e = 0; e < N; e++) {
+				const double ce = P.bie_thr - L[e][e];
+				if (ce > 0.0) {
+					nclamp++;
+					eclamp = e;
+					cclamp = ce;
+				}
+			}
+			general_bie = __any(nclamp > 1);
+		}
+		if (general_bie) {
 			double Lb[N][N], dinvb[N];
 			UNR for (int i = 0; i < N; i++)
 				UNR for (int j = 0; j <= i; j++) Lb[i][j] = (i == j) ? fmax(L[i][j], P.bie_thr) : L[i][j];
@@ -323,6 +340,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			oct_solve_unit<N>(L, dinv, rr, mi);
 			UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
 		}
+	}
+	const bool rank1_bie = P.any_bie && !general_bie;
+	if (rank1_bie && r == eclamp) {
+		UNR for (int j = 0; j < N; j++) sm.vec[3][j] = mi[j];  // column e of M^-1 for the whole instance (read after the next barrier)
 	}
 	STAMP(4);
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
@@ -352,6 +373,16 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
+	double mcol[N], beta = 0.0;
+	UNR for (int j = 0; j < N; j++) mcol[j] = 0.0;
+	if (rank1_bie) {
+		double mee = 0.0;
+		UNR for (int j = 0; j < N; j++) {
+			mcol[j] = sm.vec[3][j];
+			mee = (j == eclamp) ? mcol[j] : mee;
+		}
+		beta = cclamp * oct_rcp(fma(cclamp, mee, 1.0));
+	}
 	double vw[6];
 	{
 		double dqa[N];
@@ -450,31 +481,29 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			double s1 = 0.0, s2 = 0.0;
 			UNR for (int l = 0; l < N; l++) {
 				s1 = fma(Jf[a][l], mi[l], s1);
-				s2 = fma(Jf[a][l], mb[l], s2);
+				if (general_bie) s2 = fma(Jf[a][l], mb[l], s2);
 			}
 			t1c[a] = s1;
 			tbc[a] = s2;
 		}
 		UNR for (int a = 0; a < 6; a++) {
 			sm.T1[a][r] = t1c[a];
-			sm.Lam[a][r] = tbc[a];
+			if (general_bie) sm.Lam[a][r] = tbc[a];
 		}
 		__syncthreads();
 		double t1[N], tb[N];
 		UNR for (int j = 0; j < N; j++) {
 			t1[j] = sm.T1[ra][j];
-			tb[j] = sm.Lam[ra][j];
+			tb[j] = general_bie ? sm.Lam[ra][j] : 0.0;
 		}
-		{
-			UNR for (int c = 0; c < 6; c++) {
-				double s = 0.0, s2 = 0.0;
-				UNR for (int j = 0; j < N; j++) {
-					s = fma(t1[j], Jf[c][j], s);
-					s2 = fma(tb[j], Jf[c][j], s2);
-				}
-				sm.A[r][c] = s;
-				sm.Am[r][c] = s2;
+		UNR for (int c = 0; c < 6; c++) {
+			double s = 0.0, s2 = 0.0;
+			UNR for (int j = 0; j < N; j++) {
+				s = fma(t1[j], Jf[c][j], s);
+				if (general_bie) s2 = fma(tb[j], Jf[c][j], s2);
 			}
+			sm.A[r][c] = s;
+			if (general_bie) sm.Am[r][c] = s2;
 		}
 	}
 	__syncthreads();
@@ -490,11 +519,28 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int c = 0; c < 6; c++) lmod[c] = lam[c];
 		} else if (mf.decoupling == DEC_IMPEDANCE) {
 			UNR for (int c = 0; c < 6; c++) lmod[c] = (c == ra) ? 1.0 : 0.0;
-		} else {
+		} else if (general_bie) {
 			UNR for (int i = 0; i < 6; i++)
 				UNR for (int j = 0; j <= i; j++) L[i][j] = sm.Am[i][j];
 			oct_cholesky<6>(L, dinv);
 			oct_solve_unit<6>(L, dinv, ra, lmod);
+		} else {  // rank-one form (beta = 0 when nothing is clamped: Lambda_mod = Lambda)
+			double t[6], lt_own = 0.0;
+			UNR for (int a = 0; a < 6; a++) {
+				double sacc = 0.0;
+				UNR for (int l = 0; l < N; l++) sacc = fma(Jf[a][l], mcol[l], sacc);
+				t[a] = sacc;
+				lt_own = fma(lam[a], sacc, lt_own);  // (Lambda t)_ra: Lambda symmetric, lam = its row ra
+			}
+			sm.vec[4][r] = lt_own;
+			__syncthreads();
+			double lt[6], q = 0.0;
+			UNR for (int a = 0; a < 6; a++) {
+				lt[a] = sm.vec[4][a];
+				q = fma(t[a], lt[a], q);
+			}
+			const double gamma = beta * oct_rcp(fma(-beta, q, 1.0));
+			UNR for (int c = 0; c < 6; c++) lmod[c] = fma(gamma * lt_own, lt[c], lam[c]);
 		}
 	}
 	UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
@@ -657,10 +703,11 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			dv[j] = sm.vec[8][j];
 			tauv[j] = sm.vec[1][j];
 		}
-		double t1 = 0.0, tb = 0.0, wr = 0.0;
+		double t1 = 0.0, tb = 0.0, wr = 0.0, dm = 0.0;
 		UNR for (int l = 0; l < N; l++) {
 			t1 = fma(dv[l], mi[l], t1);   // (Jh M^-1)_rr  (M^-1 symmetric: row rr = column rr)
-			tb = fma(dv[l], mb[l], tb);
+			tb = fma(dv[l], mb[l], tb);   // general M_BIE path only (mb = mi otherwise)
+			dm = fma(dv[l], mcol[l], dm); // Jh m, rank-one M_BIE path
 			wr = fma(mi[l], tauv[l], wr); // (M^-1 tau_prec)_rr
 		}
 		const bool track = (jt.has_ki || P.integ_always);
@@ -691,6 +738,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			b1 += sm.vec[6][j];
 		}
 		const double Lam1 = oct_rcp(A1);
+		if (!general_bie) Ab = fma(-beta * dm, dm, A1);  // Jh M_BIE^-1 Jh^T = Jh M^-1 Jh^T - beta (Jh m)^2
 		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : oct_rcp(Ab));
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
