@@ -78,7 +78,19 @@ __device__ __forceinline__ double oct_dpp(const double x) {
 	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
 	return __hiloint2double(hi, lo);
 }
-enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110 };
+enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141 };
+// sum / maximum over the eight lanes of an instance, every lane gets the same result: pairs and quads by quad permutes, then the
+// other quad of the 8-lane half-row by row_half_mirror (lane i <-> 7 - i)
+__device__ __forceinline__ double oct_group_sum(double x) {
+	x += oct_dpp<DPP_QUAD_XOR1>(x);
+	x += oct_dpp<DPP_QUAD_XOR2>(x);
+	return x + oct_dpp<DPP_HALF_MIRROR>(x);
+}
+__device__ __forceinline__ double oct_group_max(double x) {
+	x = fmax(x, oct_dpp<DPP_QUAD_XOR1>(x));
+	x = fmax(x, oct_dpp<DPP_QUAD_XOR2>(x));
+	return fmax(x, oct_dpp<DPP_HALF_MIRROR>(x));
+}
 
 __device__ __forceinline__ void oct_mat3_vec(const double* R, const double* v, double* out) {
 	UNR for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
@@ -644,13 +656,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			const double wv = fma(-u[i], d_r, cj[i]);
 			c2 = fma(wv, wv, c2);
 		}
-		sm.vec[4][r] = act ? c2 : -1.0;
-	}
-	__syncthreads();
-	{
-		double best2 = -1.0;
-		UNR for (int j = 0; j < N; j++) best2 = fmax(best2, sm.vec[4][j]);
-		if (!empty && !need_exact && !(best2 / best < 1e-20)) need_exact = true;  // not numerically rank one: the exact path decides
+		const double best2 = oct_group_max(act ? c2 : -1.0);
+		if (!empty && !need_exact && !(best2 < 1e-20 * best)) need_exact = true;  // not numerically rank one: the exact path decides
 	}
 	if (__any(need_exact)) {  // exact path (rare): Gram eigen-decomposition with the reference's tolerances, one lane per instance
 		if (need_exact && r == 0) {
@@ -725,18 +732,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
 		}
 		const double ai = jg_ddq - wr;
-		sm.vec[3][r] = act ? t1 * d_r : 0.0;
-		sm.vec[4][r] = act ? tb * d_r : 0.0;
-		sm.vec[5][r] = act ? u_own * ai : 0.0;
-		sm.vec[6][r] = act ? u_own * fi : 0.0;
-		__syncthreads();
-		double A1 = 0.0, Ab = 0.0, a1 = 0.0, b1 = 0.0;
-		UNR for (int j = 0; j < N; j++) {
-			A1 += sm.vec[3][j];
-			Ab += sm.vec[4][j];
-			a1 += sm.vec[5][j];
-			b1 += sm.vec[6][j];
-		}
+		const double A1 = oct_group_sum(act ? t1 * d_r : 0.0);
+		double Ab = general_bie ? oct_group_sum(act ? tb * d_r : 0.0) : 0.0;
+		const double a1 = oct_group_sum(act ? u_own * ai : 0.0);
+		const double b1 = oct_group_sum(act ? u_own * fi : 0.0);
 		const double Lam1 = oct_rcp(A1);
 		if (!general_bie) Ab = fma(-beta * dm, dm, A1);  // Jh M_BIE^-1 Jh^T = Jh M^-1 Jh^T - beta (Jh m)^2
 		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : oct_rcp(Ab));
