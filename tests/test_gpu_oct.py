@@ -144,3 +144,26 @@ def test_lane_kernel_on_the_same_stack(cfg, B, kernel):
     assert ctrl.kernelName() == "saip_cycle_lane"
     assert np.array_equal(ctrl.status, st)
     assert W.torque_error(tau, ref) < TOL
+
+
+def test_oct_instances_are_isolated():
+    """eight instances share a wavefront and two share a DPP row: a non-finite state in one instance must not reach its neighbours
+    (their torques stay bit-identical to a clean run), and the bad instance itself is reported, not silently wrong"""
+    B = 64
+    d = W.make_inputs(2, B)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(OCT)
+    clean = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"]).copy()
+    for bad, how in ((9, np.nan), (14, np.inf), (16, np.nan)):
+        q = d["q"].copy()
+        q[bad, 3] = how
+        tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+        others = np.arange(B) != bad
+        assert np.array_equal(tau[others], clean[others])
+        assert not np.isfinite(tau[bad]).all() and ctrl.status[bad] == 1
+        assert (ctrl.status[others] == 0).all()
+    dq = d["dq"].copy()
+    dq[23, :] = np.nan
+    tau = _cycle(robot, ctrl, d["q"], dq, d["goals"])
+    others = np.arange(B) != 23
+    assert np.array_equal(tau[others], clean[others]) and not np.isfinite(tau[23]).any()
