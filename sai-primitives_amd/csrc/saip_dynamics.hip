@@ -13,6 +13,7 @@
 // benchmarked path.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "saip_device.h"
 
@@ -250,7 +251,12 @@ __global__ void __launch_bounds__(64) saip_integrate_kernel(const SimParams S) {
 	}
 }
 
+hipError_t launch_integrate_oct(const SimParams& S, hipStream_t stream);  // saip_dynamics_oct.hip: eight lanes per instance, 7-dof chains
+
 hipError_t launch_integrate(const SimParams& S, hipStream_t stream) {
+	static const char* oct_env = getenv("SAIP_OCT_DYN_MAX_BATCH");
+	const int oct_max = oct_env ? atoi(oct_env) : 16384;
+	if (S.n == 7 && S.B <= oct_max) return launch_integrate_oct(S, stream);
 	const int grid = (S.B + 63) / 64;
 	if (S.n == 7) hipLaunchKernelGGL((saip_integrate_kernel<7, true>), dim3(grid), dim3(64), 0, stream, S);   // Panda-class arms: unrolled
 	else if (S.n <= 8) hipLaunchKernelGGL((saip_integrate_kernel<8, false>), dim3(grid), dim3(64), 0, stream, S);

@@ -19,10 +19,10 @@
 
 #include "saip_device.h"
 #include "saip_fk.h"
+#include "saip_oct_common.h"
 
 namespace saip {
 
-#define UNR _Pragma("unroll")
 #if defined(SAIP_STAMP_OCT)
 // diagnostic build only (never shipped): s_memtime of wavefront 0 at the phase boundaries
 __device__ unsigned long long saip_stamps_oct[64];
@@ -55,46 +55,6 @@ struct OctInst {
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
-
-// 1/x and 1/sqrt(x) from the hardware estimates plus two Newton steps: full double accuracy for the normal-range, positive arguments met
-// here (pivots of SPD factorisations), without the scaling / fix-up sequences of the IEEE division and the library rsqrt
-__device__ __forceinline__ double oct_rcp(const double x) {
-	double y = __builtin_amdgcn_rcp(x);
-	y = fma(fma(-x, y, 1.0), y, y);
-	return fma(fma(-x, y, 1.0), y, y);
-}
-__device__ __forceinline__ double oct_rsqrt(const double x) {
-	double y = __builtin_amdgcn_rsq(x);
-	const double h = 0.5 * x;
-	y = fma(y, fma(-h * y, y, 0.5), y);
-	return fma(y, fma(-h * y, y, 0.5), y);
-}
-
-// value of the lane `n` positions up (row_shl) / down (row_shr) inside the 16-lane DPP row, 0 beyond it: a VALU move, no LDS round trip.
-// Callers mask the lanes whose source sits in the neighbouring instance (two instances share a row).
-template <int CTRL>
-__device__ __forceinline__ double oct_dpp(const double x) {
-	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
-	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
-	return __hiloint2double(hi, lo);
-}
-enum { DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141 };
-// sum / maximum over the eight lanes of an instance, every lane gets the same result: pairs and quads by quad permutes, then the
-// other quad of the 8-lane half-row by row_half_mirror (lane i <-> 7 - i)
-__device__ __forceinline__ double oct_group_sum(double x) {
-	x += oct_dpp<DPP_QUAD_XOR1>(x);
-	x += oct_dpp<DPP_QUAD_XOR2>(x);
-	return x + oct_dpp<DPP_HALF_MIRROR>(x);
-}
-__device__ __forceinline__ double oct_group_max(double x) {
-	x = fmax(x, oct_dpp<DPP_QUAD_XOR1>(x));
-	x = fmax(x, oct_dpp<DPP_QUAD_XOR2>(x));
-	return fmax(x, oct_dpp<DPP_HALF_MIRROR>(x));
-}
-
-__device__ __forceinline__ void oct_mat3_vec(const double* R, const double* v, double* out) {
-	UNR for (int i = 0; i < 3; i++) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
-}
 
 // cyclic Jacobi eigen-solve of a symmetric n x n matrix in LDS by ONE lane (rare exact path): eigenvalues on the diagonal of A,
 // eigenvectors in the columns of V (optional)
@@ -133,33 +93,6 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 						V[k * ld + q] = s * vkp + c * vkq;
 					}
 			}
-	}
-}
-
-// Cholesky factor of an SPD R x R matrix given by its lower triangle; L overwrites A's lower triangle, dinv = 1 / L_kk
-template <int R>
-__device__ __forceinline__ void oct_cholesky(double (&L)[R][R], double (&dinv)[R]) {
-	UNR for (int k = 0; k < R; k++) {
-		const double rs = oct_rsqrt(L[k][k]);
-		dinv[k] = rs;
-		UNR for (int i = k + 1; i < R; i++) L[i][k] *= rs;
-		UNR for (int j = k + 1; j < R; j++)
-			UNR for (int i = j; i < R; i++) L[i][j] = fma(-L[i][k], L[j][k], L[i][j]);
-	}
-}
-// x = (L L^T)^-1 e_col, i.e. column (= row) `col` of the inverse; col is a lane variable
-template <int R>
-__device__ __forceinline__ void oct_solve_unit(const double (&L)[R][R], const double (&dinv)[R], const int col, double (&x)[R]) {
-	double y[R];
-	UNR for (int i = 0; i < R; i++) {
-		double s = (i == col) ? 1.0 : 0.0;
-		UNR for (int k = 0; k < i; k++) s = fma(-L[i][k], y[k], s);
-		y[i] = s * dinv[i];
-	}
-	UNR for (int i = R - 1; i >= 0; i--) {
-		double s = y[i];
-		UNR for (int k = i + 1; k < R; k++) s = fma(-L[k][i], x[k], s);
-		x[i] = s * dinv[i];
 	}
 }
 
