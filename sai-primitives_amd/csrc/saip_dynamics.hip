@@ -7,7 +7,7 @@
 //   M(q) qdd + b(q, dq) + g(q) = tau        b: Coriolis / centrifugal, g: gravity
 //   dq <- dq + dt qdd ;  q <- q + dt dq     (semi-implicit Euler, `substeps` times per call with the torque held)
 //
-// One lane per instance.  Bias forces by one recursive Newton-Euler pass in world coordinates, M(q) from composite rigid bodies
+// One lane per instance (7-dof chains run saip_dynamics_oct.hip instead: eight lanes per instance).  Bias forces by one recursive Newton-Euler pass in world coordinates, M(q) from composite rigid bodies
 // (spatial inertias about the world origin, suffix sums along the chain), Cholesky solve; fully unrolled for 7-dof arms.  Per-body arrays are lane-private
 // (scratch for NMAX = 32, mostly registers for NMAX = 8); the kernel is FP64-latency bound like the cycle kernels and is not on the
 // benchmarked path.
@@ -254,9 +254,10 @@ __global__ void __launch_bounds__(64) saip_integrate_kernel(const SimParams S) {
 hipError_t launch_integrate_oct(const SimParams& S, hipStream_t stream);  // saip_dynamics_oct.hip: eight lanes per instance, 7-dof chains
 
 hipError_t launch_integrate(const SimParams& S, hipStream_t stream) {
+	// 7-dof chains: the eight-lanes-per-instance kernel is faster at every batch size measured (8.7 vs 33.4 us at 4096, 46.8 vs 81.1 us at
+	// 65 536, 166 vs 218 us at 262 144 per two substeps); SAIP_OCT_DYN_MAX_BATCH=0 selects the lane-per-instance kernel for comparisons
 	static const char* oct_env = getenv("SAIP_OCT_DYN_MAX_BATCH");
-	const int oct_max = oct_env ? atoi(oct_env) : 16384;
-	if (S.n == 7 && S.B <= oct_max) return launch_integrate_oct(S, stream);
+	if (S.n == 7 && (!oct_env || S.B <= atoi(oct_env))) return launch_integrate_oct(S, stream);
 	const int grid = (S.B + 63) / 64;
 	if (S.n == 7) hipLaunchKernelGGL((saip_integrate_kernel<7, true>), dim3(grid), dim3(64), 0, stream, S);   // Panda-class arms: unrolled
 	else if (S.n <= 8) hipLaunchKernelGGL((saip_integrate_kernel<8, false>), dim3(grid), dim3(64), 0, stream, S);
