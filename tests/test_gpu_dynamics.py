@@ -105,3 +105,47 @@ def test_on_device_closed_loop_rollout_tracks_otg_trajectory():
     assert gr.all()
     assert err.max() < 2e-3 and np.abs(dq1).max() < 0.05
     assert np.linalg.norm(x0 - goal, axis=1).min() > 0.06
+
+
+def test_eight_lane_dynamics_substeps_ragged_batch_and_coasting():
+    """saip_integrate_oct (7-dof chains): a batch that is not a multiple of the eight instances per wavefront, three substeps with the
+    torque held against the same scheme stepped with the Lagrangian oracle, NaN torques coast as zero torque, one instance with a
+    non-finite state does not disturb the instances that share its wavefront"""
+    B = 1001
+    d = W.make_inputs(2, B)
+    model = d["model"]
+    rng = np.random.default_rng(12)
+    robot, ctrl, _ = _engine(model.name, d["tasks"], B)
+    tau = rng.uniform(-5, 5, (B, 7))
+    tau[5] = np.nan
+    dq = rng.uniform(-1.0, 1.0, (B, 7))
+    dt, damping, grav = 2e-4, 0.2, (0.0, 0.0, -9.81)
+    ctrl.setTorques(tau)
+    robot.setQ(d["q"])
+    robot.setDq(dq)
+    robot.updateModel()
+    ctrl.integrate(dt, 3, gravity=grav, damping=damping)
+    ctrl.synchronize()
+    q1, dq1 = ctrl.pullState()
+    tz = np.where(np.isnan(tau), 0.0, tau)
+    q_ref, dq_ref = d["q"].copy(), dq.copy()
+    for _ in range(3):
+        qdd = W.forward_dynamics(model, q_ref, dq_ref, tz, g=grav, damping=damping)
+        dq_ref = dq_ref + dt * qdd
+        q_ref = q_ref + dt * dq_ref
+    err = np.abs(dq1 - dq_ref).max() / np.abs(dq_ref - dq).max()
+    print("three substeps, B = 1001: velocity increment error", err)
+    assert err < 1e-6 and np.abs(q1 - q_ref).max() < 1e-9
+    # isolation
+    qb = d["q"].copy()
+    qb[42, 2] = np.nan
+    robot.setQ(qb)
+    robot.setDq(dq)
+    robot.updateModel()
+    ctrl.setTorques(tau)
+    ctrl.integrate(dt, 3, gravity=grav, damping=damping)
+    ctrl.synchronize()
+    q2, dq2 = ctrl.pullState()
+    others = np.arange(B) != 42
+    assert np.array_equal(dq2[others], dq1[others]) and np.array_equal(q2[others], q1[others])
+    assert not np.isfinite(dq2[42]).all()
