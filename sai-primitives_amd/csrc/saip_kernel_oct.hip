@@ -244,6 +244,28 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 		UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 	}
+	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
+	double pw[3], Rc[9];
+	{
+		const int bd = mf.body;
+		double Rb[12];
+		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[bd][e];
+		oct_mat3_vec(Rb, mf.pos, pw);
+		UNR for (int e = 0; e < 3; e++) pw[e] += Rb[9 + e];
+		UNR for (int i = 0; i < 3; i++)
+			UNR for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
+		const bool on = rr <= bd;
+		const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
+		const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
+		{
+			sm.J[0][r] = on ? (rev ? c0 : z[0]) : 0.0;
+			sm.J[1][r] = on ? (rev ? c1 : z[1]) : 0.0;
+			sm.J[2][r] = on ? (rev ? c2 : z[2]) : 0.0;
+			sm.J[3][r] = (on && rev) ? z[0] : 0.0;
+			sm.J[4][r] = (on && rev) ? z[1] : 0.0;
+			sm.J[5][r] = (on && rev) ? z[2] : 0.0;
+		}
+	}
 	__syncthreads();
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
@@ -291,43 +313,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		UNR for (int j = 0; j < N; j++) sm.vec[3][j] = mi[j];  // column e of M^-1 for the whole instance (read after the next barrier)
 	}
 	STAMP(4);
-	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
-	double pw[3], Rc[9];
-	{
-		const int bd = mf.body;
-		double Rb[12];
-		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[bd][e];
-		oct_mat3_vec(Rb, mf.pos, pw);
-		UNR for (int e = 0; e < 3; e++) pw[e] += Rb[9 + e];
-		UNR for (int i = 0; i < 3; i++)
-			UNR for (int j = 0; j < 3; j++) Rc[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
-		const bool on = rr <= bd;
-		const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
-		const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
-		{
-			sm.J[0][r] = on ? (rev ? c0 : z[0]) : 0.0;
-			sm.J[1][r] = on ? (rev ? c1 : z[1]) : 0.0;
-			sm.J[2][r] = on ? (rev ? c2 : z[2]) : 0.0;
-			sm.J[3][r] = (on && rev) ? z[0] : 0.0;
-			sm.J[4][r] = (on && rev) ? z[1] : 0.0;
-			sm.J[5][r] = (on && rev) ? z[2] : 0.0;
-		}
-	}
-	__syncthreads();
-	STAMP(5);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
-	double mcol[N], beta = 0.0;
-	UNR for (int j = 0; j < N; j++) mcol[j] = 0.0;
-	if (rank1_bie) {
-		double mee = 0.0;
-		UNR for (int j = 0; j < N; j++) {
-			mcol[j] = sm.vec[3][j];
-			mee = (j == eclamp) ? mcol[j] : mee;
-		}
-		beta = cclamp * oct_rcp(fma(cclamp, mee, 1.0));
-	}
 	double vw[6];
 	{
 		double dqa[N];
@@ -338,6 +326,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			vw[a] = s;
 		}
 	}
+	STAMP(5);
 	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false;
@@ -418,6 +407,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	STAMP(7);
 	// ---- operationalSpaceMatrices(J): this lane's COLUMN of T1 = J M^-1 (M^-1 symmetric: its column rr is the row this lane solved for),
 	// then its ROW of A = T1 J^T; the same with M_BIE^-1
+	double mcol[N], beta = 0.0;
+	UNR for (int j = 0; j < N; j++) mcol[j] = 0.0;
 	const int ra = r < 6 ? r : 5;
 	double t1c[6];
 	{
@@ -436,6 +427,14 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			if (general_bie) sm.Lam[a][r] = tbc[a];
 		}
 		__syncthreads();
+		if (rank1_bie) {
+			double mee = 0.0;
+			UNR for (int j = 0; j < N; j++) {
+				mcol[j] = sm.vec[3][j];
+				mee = (j == eclamp) ? mcol[j] : mee;
+			}
+			beta = cclamp * oct_rcp(fma(cclamp, mee, 1.0));
+		}
 		double t1[N], tb[N];
 		UNR for (int j = 0; j < N; j++) {
 			t1[j] = sm.T1[ra][j];
