@@ -17,6 +17,6 @@ for rep in range(20):
     s = np.array(buf[:16], dtype=np.float64)
     dlt = np.diff(s)
     acc = dlt if acc is None else np.minimum(acc, dlt)
-names = ["inputs", "kinematics+inertia+Ic", "M column", "chol7 x2 + solves", "J column", "Jf/vw", "G + certificate", "T1/A", "chol6 x2", "law + g", "tau / N1 column", "range: norms", "range: pivot/deflate", "joint law + Lambda", "post"]
+names = ["inputs", "kinematics+inertia+Ic", "M row + J column", "chol7 + solve", "Jf/vw", "-", "G + certificate", "T1/A", "chol6 + Lambda_mod", "law + g", "tau / N1 column", "range: norms", "range: pivot/deflate", "joint law + Lambda", "post"]
 for n_, c in zip(names, acc): print(f"{n_:14s} {c:8.0f}")
 print("total", acc.sum(), "clocks (100 MHz s_memtime ticks x ?)")
