@@ -20,6 +20,7 @@ hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* sup
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
+hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream);
 int otg_state_fields();
 hipError_t launch_integrate(const SimParams& S, hipStream_t stream);
 }  // namespace saip
@@ -1281,8 +1282,25 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	if (st) return st;
 	for (size_t t = 0; t < b->tasks.size(); t++) {
 		TaskHost& T = b->tasks[t];
+		if (T.otg_enabled && !T.otg_inited && (st = run_otg(b, (int)t, 1))) return st;
+	}
+	// { MotionForceTask, JointTask } with both OTGs on: one launch for the two cycle-mode kernels
+	bool paired = false;
+	if (!diag && b->tasks.size() == 2 && b->tasks[0].otg_enabled && b->tasks[1].otg_enabled && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE &&
+		b->tasks[1].dev.type == saip::TASK_JOINT && b->tasks[1].otg.gs == 8 && !b->tasks[0].otg_limits_dirty && !b->tasks[1].otg_limits_dirty) {
+		for (int t = 0; t < 2; t++) {
+			TaskHost& T = b->tasks[t];
+			T.otg.goal_comps = T.dev.goal_comps;
+			T.otg.task = b->tasks_dev + t;
+			T.otg.dt = T.dev.dt;
+		}
+		hipError_t e = saip::launch_otg_pair(b->tasks[0].otg, b->tasks[1].otg, b->B, b->ld, b->stream);
+		if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "OTG kernel launch failed: %s", hipGetErrorString(e));
+		paired = true;
+	}
+	for (size_t t = 0; t < b->tasks.size() && !paired; t++) {
+		TaskHost& T = b->tasks[t];
 		if (!T.otg_enabled) continue;
-		if (!T.otg_inited && (st = run_otg(b, (int)t, 1))) return st;
 		if (!diag && (st = run_otg(b, (int)t, 0))) return st;  // a diagnostic re-launch must not advance the trajectory
 	}
 	bool lane_ok = false;

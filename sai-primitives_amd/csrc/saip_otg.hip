@@ -616,9 +616,9 @@ __device__ __forceinline__ int ruckig_update(const Grp<GS>& g, bool act, bool ru
 // One control cycle of the internal OTG of one joint task for the whole batch.  mode 0: cycle (JointTask.cpp:313-319);
 // mode 1: OTG_joints::reInitialize(S q) (JointTask.cpp:95-106, OTG_joints.cpp:28-42).
 template <int GS>
-__global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, int ld, int mode) {
+__device__ __forceinline__ void otg_joints_body(const OtgDev& O, const int B, const int ld, const int mode, const int block) {
 	const Grp<GS> g;
-	const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int gtid = block * blockDim.x + threadIdx.x;
 	const int inst = gtid / GS;
 	const int dof = g.dof;
 	const int m = O.m;
@@ -934,10 +934,10 @@ __device__ __forceinline__ void cart_set_goal_position(const Grp<GS>& g, Lane& L
 
 // mode 0: one control cycle (MotionForceTask.cpp:394-406).  mode 1 | (mask << 4): reInitialize (mask 3), reInitializeLinear
 // (mask 1), reInitializeAngular (mask 2) at the current pose of the control frame (OTG_6dof_cartesian.cpp:46-84).
-__global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B, int ld, int mode) {
+__device__ __forceinline__ void otg_cartesian_body(const OtgDev& O, const int B, const int ld, const int mode, const int block) {
 	constexpr int GS = 8;
 	const Grp<GS> g;
-	const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const int gtid = block * blockDim.x + threadIdx.x;
 	const int inst = gtid / GS;
 	const int dof = g.dof;
 	const bool inst_ok = inst < B;
@@ -1067,6 +1067,28 @@ __global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B,
 			O.result[inst] = run ? result : 1;
 		}
 	}
+}
+
+template <int GS>
+__global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, int ld, int mode) {
+	otg_joints_body<GS>(O, B, ld, mode, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B, int ld, int mode) {
+	otg_cartesian_body(O, B, ld, mode, blockIdx.x);
+}
+// One launch for the two OTGs of a { MotionForceTask, JointTask } stack in their cycle mode: they are independent and each is a few
+// latency-bound wavefronts, so the second launch only added its latency.  Workgroups [0, grid_c) run the Cartesian OTG, the rest the
+// joint OTG (8-lane groups).
+__global__ void __launch_bounds__(256) saip_otg_pair(const OtgDev Oc, const OtgDev Oj, int B, int ld, int grid_c) {
+	if ((int)blockIdx.x < grid_c) otg_cartesian_body(Oc, B, ld, 0, blockIdx.x);
+	else otg_joints_body<8>(Oj, B, ld, 0, blockIdx.x - grid_c);
+}
+
+hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream) {
+	const int block = 256;
+	const int grid_c = (int)(((long long)Oc.lanes + block - 1) / block), grid_j = (int)(((long long)Oj.lanes + block - 1) / block);
+	hipLaunchKernelGGL(saip_otg_pair, dim3(grid_c + grid_j), dim3(block), 0, stream, Oc, Oj, B, ld, grid_c);
+	return hipGetLastError();
 }
 
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream) {
