@@ -37,7 +37,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc cross-compiles for gfx950 (works without a GPU). Output stays in-tree: sai-primitives_amd/libsaip.so"""
     srcs = [os.path.join(_DIR, s) for s in SOURCES]
     deps = srcs + [os.path.join(_DIR, h) for h in HEADERS]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    exact_lib = os.path.join(_DIR, "libsaip_octexact.so")
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(exact_lib) and all(min(os.path.getmtime(LIB_PATH), os.path.getmtime(exact_lib)) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     extra = os.environ.get("SAIP_EXTRA_HIPCC_FLAGS", "").split()  # diagnostic builds only (e.g. -DSAIP_STAMP)
     # One object per source, then one link.  The cycle kernels run at one wavefront per SIMD (512 registers per lane), so instruction
@@ -49,6 +50,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
              "csrc/saip_kernel_oct.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     objs = []
     procs = []
+    # test-only variant of the eight-lane cycle kernel in which EVERY instance takes the exact eigen fallbacks (they are rare on real
+    # data): linked into libsaip_octexact.so next to the product library, loaded by tests/test_gpu_oct.py through SAIP_LIB
+    oct_rel = "csrc/saip_kernel_oct.hip"
+    oct_exact_obj = os.path.join(_DIR, "build", "saip_kernel_oct_exact.o")
+    os.makedirs(os.path.dirname(oct_exact_obj), exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", "-DSAIP_OCT_FORCE_EXACT", "-o", oct_exact_obj] + sched[oct_rel] + extra + [os.path.join(_DIR, oct_rel)]
+    procs.append((cmd, subprocess.Popen(cmd)))
     for rel in SOURCES:
         obj = os.path.join(_DIR, "build", os.path.basename(rel) + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
@@ -61,6 +69,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
+    exact_objs = [oct_exact_obj if os.path.basename(o) == "saip_kernel_oct.hip.o" else o for o in objs]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", exact_lib] + exact_objs)
     return LIB_PATH
 
 

@@ -361,6 +361,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		};
 		// stage 1: lambda_max(Gs) <= trace(Gs) = 1, lambda_max(G) >= trace(G)/6; stage 2: trace-power bound (see saip_kernel_lane.hip)
 		bool need_exact = !((tr > 0.0) && (tr >= 6.0 * tol2) && ldl_positive(smax2));
+#if defined(SAIP_OCT_FORCE_EXACT)  // diagnostic build only: every instance takes the exact fallbacks (validated against the oracle once per change)
+		need_exact = true;
+#endif
 		if (__any(need_exact)) {
 			double G2[6][6], Gt[6][6];
 			UNR for (int a = 0; a < 6; a++)
@@ -385,6 +388,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			const bool ok_s0 = (u * mf.cert_kroot * tr >= tol2);
 			const bool pos = ldl_positive(smax2 * u);
 			need_exact = need_exact && !(ok_s0 && pos && tr > 0.0);
+#if defined(SAIP_OCT_FORCE_EXACT)
+			need_exact = true;
+#endif
 			if (__any(need_exact)) {  // exact path (rare): singular values from the Gram eigenvalues, one lane per instance (SingularityHandler.cpp:78-121)
 				if (need_exact && r == 0) {
 					for (int a = 0; a < 6; a++)
@@ -591,6 +597,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double best2 = oct_group_max(act ? c2 : -1.0);
 		if (!empty && !need_exact && !(best2 < 1e-20 * best)) need_exact = true;  // not numerically rank one: the exact path decides
 	}
+#if defined(SAIP_OCT_FORCE_EXACT)
+	need_exact = !empty;
+#endif
 	if (__any(need_exact)) {  // exact path (rare): Gram eigen-decomposition with the reference's tolerances, one lane per instance
 		if (need_exact && r == 0) {
 			double* Gm = &sm.Gx[0][0];

@@ -167,3 +167,41 @@ def test_oct_instances_are_isolated():
     tau = _cycle(robot, ctrl, d["q"], dq, d["goals"])
     others = np.arange(B) != 23
     assert np.array_equal(tau[others], clean[others]) and not np.isfinite(tau[23]).any()
+
+
+def test_oct_exact_fallbacks_when_forced():
+    """the Gram-eigenvalue fallbacks of the oct kernel (singular-value predicate, range basis) are rare on real data; a test-only build
+    of the same source sends EVERY instance through them (libsaip_octexact.so, -DSAIP_OCT_FORCE_EXACT) and must give the oracle's
+    answers too.  Runs in a child process because the library is chosen at load time (SAIP_LIB)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "sai-primitives_amd", "libsaip_octexact.so")
+    assert os.path.exists(lib), "build() links the test-only variant next to libsaip.so"
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import workloads as W
+from oracle import Oracle
+from sai_primitives_amd.controller import controller_from_specs
+rng = np.random.default_rng(31)
+for uniform in (False, True):
+    B = 768
+    d = W.make_inputs(2, B)
+    q = rng.uniform(d["model"].q_lower, d["model"].q_upper, size=d["q"].shape) if uniform else d["q"]
+    ref, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
+    ctrl.setKernel(3)
+    robot.setQ(q); robot.setDq(d["dq"]); robot.updateModel(); ctrl.updateControllerTaskModels(); ctrl.setGoals(d["goals"])
+    tau = ctrl.computeControlTorques()
+    assert ctrl.kernelName() == "saip_cycle_oct" and np.array_equal(ctrl.status, st)
+    ok = st == 0
+    err = W.torque_error(tau[ok], ref[ok])
+    print("forced exact paths, uniform postures" if uniform else "forced exact paths, config 2", int(ok.sum()), "valid, err", err)
+    assert err < 1e-5
+''' % (root, os.path.join(root, "oracle"))
+    env = dict(os.environ, SAIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr[-2000:])
+    assert out.returncode == 0
