@@ -125,9 +125,41 @@ public:
 		check(saip_batch_get_task_nullspace_host(_batch, _id, N.data()));
 		return N;
 	}
+	// N_prec this task was updated with = N_{t-1} ... N_0 of the tasks above it (identity for the first), TemplateTask.h:79-83; same layout
+	std::vector<double> getPreviousTasksNullspace() {
+		need();
+		const int n = _robot->dof();
+		const size_t B = _robot->batchSize();
+		std::vector<double> Np((size_t)n * n * B, 0.0), Ns(Np.size()), T(Np.size());
+		for (int i = 0; i < n; i++)
+			for (size_t b = 0; b < B; b++) Np[((size_t)i * n + i) * B + b] = 1.0;
+		for (int s = 0; s < _id; s++) {
+			check(saip_batch_get_task_nullspace_host(_batch, s, Ns.data()));
+			matmulBatched(Ns, Np, T, n, B);
+			Np.swap(T);
+		}
+		return Np;
+	}
+	// N N_prec, what the next task of the hierarchy is updated with, TemplateTask.h:85-89
+	std::vector<double> getTaskAndPreviousNullspace() {
+		const int n = _robot->dof();
+		const size_t B = _robot->batchSize();
+		std::vector<double> N = getTaskNullspace(), Np = getPreviousTasksNullspace(), T(N.size());
+		matmulBatched(N, Np, T, n, B);
+		return T;
+	}
 
 protected:
 	friend class RobotController;
+	static void matmulBatched(const std::vector<double>& A, const std::vector<double>& Bm, std::vector<double>& C, int n, size_t B) {  // [n*n][B] layout
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < n; j++)
+				for (size_t b = 0; b < B; b++) {
+					double s = 0.0;
+					for (int l = 0; l < n; l++) s += A[((size_t)i * n + l) * B + b] * Bm[((size_t)l * n + j) * B + b];
+					C[((size_t)i * n + j) * B + b] = s;
+				}
+	}
 	template <typename F>
 	void cfg(F f) {
 		if (_batch) check(f(_batch, _id));

@@ -252,6 +252,22 @@ class _Task:
         capi.check(capi.lib().saip_batch_get_task_nullspace_host(ctrl._h, self._id, _dptr(out)))
         return out.T.reshape(ctrl._robot.batch_size, n, n).copy()
 
+    def getPreviousTasksNullspace(self):
+        """(B, dof, dof) N_prec this task was updated with: the product N_{t-1} ... N_0 of the tasks above it (TemplateTask.h:79-83,
+        RobotController.cpp:68-77); the identity for the first task"""
+        ctrl = self._need_ctrl()
+        n, B = self._robot.dof(), ctrl._robot.batch_size
+        Np = np.broadcast_to(np.eye(n), (B, n, n)).copy()
+        for s in range(self._id):
+            out = np.empty((n * n, B))
+            capi.check(capi.lib().saip_batch_get_task_nullspace_host(ctrl._h, s, _dptr(out)))
+            Np = out.T.reshape(B, n, n) @ Np
+        return Np
+
+    def getTaskAndPreviousNullspace(self):
+        """(B, dof, dof) N N_prec, what the next task in the hierarchy is updated with (TemplateTask.h:85-89)"""
+        return self.getTaskNullspace() @ self.getPreviousTasksNullspace()
+
 
 class MotionForceTask(_Task):
     """MotionForceTask.h:96-110.  controlled_directions_* = None -> full 6-dof task."""

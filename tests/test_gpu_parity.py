@@ -401,6 +401,10 @@ def test_task_nullspaces_match_oracle():
         det = o.details(d["q"][b], d["dq"][b], [g[b] for g in d["goals"]])
         assert np.abs(N0[b] - det["N"][0]).max() < 1e-8
         assert np.abs(N1[b] - det["N"][1]).max() < 1e-7
+    # TemplateTask.h:79-89: the nullspace a task was updated with and the one it hands on
+    assert np.array_equal(tasks[0].getPreviousTasksNullspace(), np.broadcast_to(np.eye(N0.shape[1]), N0.shape))
+    assert np.allclose(tasks[1].getPreviousTasksNullspace(), N0, atol=0, rtol=0)
+    assert np.allclose(tasks[1].getTaskAndPreviousNullspace(), N1 @ N0, atol=1e-15)
 
 
 def test_integrators_and_repeated_cycles():
