@@ -248,6 +248,12 @@ saip_status saip_batch_get_goal_host(saip_batch*, int task, double* goal);
 /* TemplateTask::reInitializeTask / RobotController::reinitializeTasks: goal := current pose of every instance,
  * velocities/accelerations := 0, integrators := 0 (MotionForceTask.cpp:204-245, JointTask.cpp:91-107). GPU kernel. */
 saip_status saip_batch_reinitialize_tasks(saip_batch*);
+/* TemplateTask::reInitializeTask of ONE task (MotionForceTask.cpp:204-245, JointTask.cpp:95-106) */
+saip_status saip_batch_reinitialize_task(saip_batch*, int task);
+/* MotionForceTask::resetIntegrators / resetIntegratorsLinear / resetIntegratorsAngular (MotionForceTask.cpp:988-1002; the linear part
+ * also clears the force integrator, the angular part the moment integrator), JointTask::resetIntegrators.  parts: 1 linear (or the
+ * joint task's), 2 angular, 3 both. */
+saip_status saip_batch_reset_integrators(saip_batch*, int task, int parts);
 
 /* ---- zero-copy access for resident pipelines (simulator / rollout on the same GPU) */
 double* saip_batch_device_q(saip_batch*);

@@ -94,7 +94,22 @@ public:
 	const std::string& getTaskName() const { return _task_name; }
 
 	void setDynamicDecouplingType(DynamicDecouplingType t) { cfg([=](saip_batch* b, int id) { return saip_batch_set_dynamic_decoupling_type(b, id, (int)t); }); }
-	void setBoundedInertiaEstimateThreshold(double thr) { cfg([=](saip_batch* b, int id) { return saip_batch_set_bie_threshold(b, id, thr); }); }
+	void setBoundedInertiaEstimateThreshold(double thr) {
+		_bie_threshold = thr;
+		cfg([=](saip_batch* b, int id) { return saip_batch_set_bie_threshold(b, id, thr); });
+	}
+	double getBoundedInertiaEstimateThreshold() const { return _bie_threshold; }
+	// TemplateTask::reInitializeTask of this task alone; the per-task updateTaskModel / computeTorques of the reference do not exist here:
+	// the hierarchy is evaluated as a whole by RobotController::updateControllerTaskModels / computeControlTorques
+	void reInitializeTask() {
+		need();
+		check(saip_batch_reinitialize_task(_batch, _id));
+	}
+	// resetIntegrators (both tasks), resetIntegratorsLinear / Angular (MotionForceTask.cpp:988-1002)
+	void resetIntegrators() {
+		need();
+		check(saip_batch_reset_integrators(_batch, _id, 3));
+	}
 	void disableInternalOtg() {
 		_otg_enabled = false;
 		cfg([](saip_batch* b, int id) { return saip_batch_set_internal_otg(b, id, 0); });
@@ -180,6 +195,7 @@ protected:
 	TaskType _task_type;
 	double _loop_timestep;
 	bool _otg_enabled = true;  // reference default (JointTask.h:38, MotionForceTask.h:67)
+	double _bie_threshold = 0.1;
 	saip_batch* _batch = nullptr;
 	int _id = -1;
 	std::vector<std::function<saip_status(saip_batch*, int)>> _pending;
@@ -262,6 +278,27 @@ public:
 	void setMomentControlGains(double kp, double kv, double ki) { cfg([=](saip_batch* b, int id) { return saip_batch_set_moment_control_gains(b, id, kp, kv, ki); }); }
 	void setClosedLoopForceControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_force_control(b, id, e); }); }
 	void setClosedLoopMomentControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_moment_control(b, id, e); }); }
+	void resetIntegratorsLinear() {
+		need();
+		check(saip_batch_reset_integrators(_batch, _id, 1));
+	}
+	void resetIntegratorsAngular() {
+		need();
+		check(saip_batch_reset_integrators(_batch, _id, 2));
+	}
+	void enablePassivity() { cfg([](saip_batch* b, int id) { return saip_batch_set_passivity(b, id, 1); }); }    // MotionForceTask.h:630-631
+	void disablePassivity() { cfg([](saip_batch* b, int id) { return saip_batch_set_passivity(b, id, 0); }); }
+	// MotionForceTask.cpp:805-828: sensed force / moment in the sensor frame, [3][B] each
+	void updateSensedForceAndMoment(const std::vector<double>& force, const std::vector<double>& moment) {
+		setField(30, 3, force, "updateSensedForceAndMoment: expected [3][B]");
+		setField(33, 3, moment, "updateSensedForceAndMoment: expected [3][B]");
+	}
+	// setFeedforwardForceGain / MomentGain, setMaxForceControlFeedbackOutput / Moment (MotionForceTask.h:330-355) in one call
+	void setForceControlParameters(double kff_force = 0.95, double kff_moment = 0.95, double max_force_feedback = 20.0, double max_moment_feedback = 10.0) {
+		cfg([=](saip_batch* b, int id) { return saip_batch_set_force_control_parameters(b, id, kff_force, kff_moment, max_force_feedback, max_moment_feedback); });
+	}
+	void setPosControlGainsUnsafe(double kp, double kv, double ki = 0) { setPosControlGains(kp, kv, ki); }
+	void setOriControlGainsUnsafe(double kp, double kv, double ki = 0) { setOriControlGains(kp, kv, ki); }
 
 protected:
 	saip_status add(saip_batch* b, int* id) override {
@@ -292,6 +329,15 @@ public:
 	void setGoalVelocity(const std::vector<double>& dq) { setField(getTaskDof(), getTaskDof(), dq, "goal velocity vector size not consistent with task dof in JointTask::setGoalVelocity\n"); }
 	void setGoalAcceleration(const std::vector<double>& ddq) { setField(2 * getTaskDof(), getTaskDof(), ddq, "goal acceleration vector size not consistent with task dof in JointTask::setGoalAcceleration\n"); }
 	void setGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_joint_gains(b, id, &kp, &kv, &ki, 1); }); }
+	void setGainsUnsafe(double kp, double kv, double ki = 0) { setGains(kp, kv, ki); }
+	// rows x dof, row-major (identity for the full task), JointTask.h getJointSelectionMatrix
+	std::vector<double> getJointSelectionMatrix() const {
+		if (_rows > 0) return _S;
+		const int n = _robot->dof();
+		std::vector<double> I((size_t)n * n, 0.0);
+		for (int i = 0; i < n; i++) I[(size_t)i * n + i] = 1.0;
+		return I;
+	}
 	// JointTask.cpp:358-381 (defaults JointTask.h:40-41); the jerk-limited variant throws (not on the device)
 	void enableInternalOtgAccelerationLimited(double max_velocity = M_PI / 3.0, double max_acceleration = 2.0 * M_PI) {
 		_otg_enabled = true;

@@ -171,7 +171,20 @@ class _Task:
         else:
             self._ctrl._call(fn_name, self._id, *args)
 
+    def reInitializeTask(self):
+        """TemplateTask::reInitializeTask of this task alone: goal := current pose, integrators := 0, OTG re-initialised"""
+        self._need_ctrl()._push_state()
+        self._ctrl._call("saip_batch_reinitialize_task", self._id)
+
+    def updateTaskModel(self, N_prec=None):
+        raise NotImplementedError("the task models of a hierarchy are evaluated together on the device: RobotController.updateControllerTaskModels()")
+
+    def computeTorques(self, tau_prec=None):
+        raise NotImplementedError("the torques of a hierarchy are evaluated together on the device: RobotController.computeControlTorques()")
+
     def _gains(self, fn, kp, kv, ki):
+        self._gain_cache = getattr(self, "_gain_cache", {})
+        self._gain_cache[fn] = tuple(np.atleast_1d(np.asarray(x, float)).copy() for x in (kp, kv, ki))
         kp, kv, ki = (np.atleast_1d(np.asarray(x, float)) for x in (kp, kv, ki))
         size = max(kp.shape[0], kv.shape[0], ki.shape[0])
         for x in (kp, kv, ki):
@@ -185,6 +198,7 @@ class _Task:
         self._cfg("saip_batch_set_dynamic_decoupling_type", int(t))
 
     def setBoundedInertiaEstimateThreshold(self, thr: float):
+        self._bie_threshold = max(float(thr), 0.0) if self._type == TaskType.JOINT_TASK else float(thr)  # JointTask.h:372-378 clamps, SingularityHandler.h:81-86 does not
         self._cfg("saip_batch_set_bie_threshold", float(thr))
 
     def disableInternalOtg(self):
@@ -218,14 +232,21 @@ class _Task:
 
     def enableVelocitySaturation(self, *values):
         """MotionForceTask: (linear_vel_sat, angular_vel_sat); JointTask: (value) or (vector of task dof); () keeps the defaults"""
+        self._vel_sat = True
         if values:
             v = np.ascontiguousarray(np.concatenate([np.atleast_1d(np.asarray(x, float)) for x in values]))
+            self._sat_vel = tuple(v.tolist())
             self._keepalive.append(v)
             self._cfg("saip_batch_set_saturation_velocities", _dptr(v), int(v.shape[0]))
         self._cfg("saip_batch_set_velocity_saturation", 1)
 
     def disableVelocitySaturation(self):
+        self._vel_sat = False
         self._cfg("saip_batch_set_velocity_saturation", 0)
+
+    def _cached_gains(self, fn, default):
+        g = getattr(self, "_gain_cache", {}).get(fn)
+        return [PIDGains(*d) for d in default] if g is None else [PIDGains(*v) for v in zip(*(np.broadcast_to(x, (max(len(y) for y in g),)) for x in g))]
 
     def _need_ctrl(self):
         if self._ctrl is None:
@@ -337,15 +358,19 @@ class MotionForceTask(_Task):
         return bool(ch.value)
 
     def parametrizeForceMotionSpaces(self, force_space_dimension, force_or_motion_single_axis=None):  # MotionForceTask.h:560-580
+        self._force_dim = int(force_space_dimension)
         return self._space("saip_batch_parametrize_force_motion_spaces", force_space_dimension, force_or_motion_single_axis)
 
     def parametrizeMomentRotMotionSpaces(self, moment_space_dimension, moment_or_rot_motion_single_axis=None):
+        self._moment_dim = int(moment_space_dimension)
         return self._space("saip_batch_parametrize_moment_rot_motion_spaces", moment_space_dimension, moment_or_rot_motion_single_axis)
 
     def setForceControlGains(self, kp, kv, ki=0.0):
+        self._force_gains = (float(kp), float(kv), float(ki))
         self._cfg("saip_batch_set_force_control_gains", float(kp), float(kv), float(ki))
 
     def setMomentControlGains(self, kp, kv, ki=0.0):
+        self._moment_gains = (float(kp), float(kv), float(ki))
         self._cfg("saip_batch_set_moment_control_gains", float(kp), float(kv), float(ki))
 
     def setClosedLoopForceControl(self, enabled: bool):
@@ -366,6 +391,8 @@ class MotionForceTask(_Task):
 
     def setForceControlParameters(self, kff_force=0.95, kff_moment=0.95, max_force_feedback=20.0, max_moment_feedback=10.0):
         """setFeedforwardForceGain / MomentGain, setMaxForceControlFeedbackOutput / Moment (MotionForceTask.h:330-355)"""
+        self._force_params = dict(kff_force=float(kff_force), kff_moment=float(kff_moment), max_force_feedback=float(max_force_feedback),
+                                  max_moment_feedback=float(max_moment_feedback))
         self._cfg("saip_batch_set_force_control_parameters", float(kff_force), float(kff_moment), float(max_force_feedback), float(max_moment_feedback))
 
     def setControlToSensorTransform(self, R, p):
@@ -373,6 +400,83 @@ class MotionForceTask(_Task):
         R, p = np.ascontiguousarray(np.asarray(R, float).reshape(9)), np.ascontiguousarray(np.asarray(p, float).reshape(3))
         self._keepalive.append((R, p))
         self._cfg("saip_batch_set_control_to_sensor_transform", _dptr(R), _dptr(p))
+
+    # remaining MotionForceTask.h surface: aliases, host-side getters of what was configured, integrator resets
+    def setPosControlGainsUnsafe(self, kp, kv, ki=0.0):  # MotionForceTask.h: same as the checked setter (the engine validates itself)
+        self.setPosControlGains(kp, kv, ki)
+
+    def setOriControlGainsUnsafe(self, kp, kv, ki=0.0):
+        self.setOriControlGains(kp, kv, ki)
+
+    def getPosControlGains(self):
+        """list of PIDGains (one entry for isotropic gains), defaults MotionForceTask.h:40-45"""
+        return self._cached_gains("saip_batch_set_pos_control_gains", [(100.0, 20.0, 0.0)])
+
+    def getOriControlGains(self):
+        return self._cached_gains("saip_batch_set_ori_control_gains", [(200.0, 28.3, 0.0)])
+
+    def getForceControlGains(self):
+        return PIDGains(*getattr(self, "_force_gains", (0.7, 10.0, 1.3)))  # MotionForceTask.h:50-52
+
+    def getMomentControlGains(self):
+        return PIDGains(*getattr(self, "_moment_gains", (0.7, 10.0, 1.3)))
+
+    def getForceSpaceDimension(self):
+        return getattr(self, "_force_dim", 0)
+
+    def getMomentSpaceDimension(self):
+        return getattr(self, "_moment_dim", 0)
+
+    def getVelocitySaturationEnabled(self):
+        return getattr(self, "_vel_sat", False)
+
+    def getLinearSaturationVelocity(self):
+        return getattr(self, "_sat_vel", (0.3, np.pi / 3))[0]  # MotionForceTask.h:64-65
+
+    def getAngularSaturationVelocity(self):
+        return getattr(self, "_sat_vel", (0.3, np.pi / 3))[1]
+
+    def getBoundedInertiaEstimateThreshold(self):
+        return getattr(self, "_bie_threshold", 0.1)
+
+    def _fcp(self, **kw):
+        cur = dict(kff_force=0.95, kff_moment=0.95, max_force_feedback=20.0, max_moment_feedback=10.0)
+        cur.update(getattr(self, "_force_params", {}))
+        cur.update(kw)
+        self.setForceControlParameters(**cur)
+
+    def setFeedforwardForceGain(self, k):  # MotionForceTask.h:330-355
+        self._fcp(kff_force=float(k))
+
+    def setFeedforwardmomentGain(self, k):
+        self._fcp(kff_moment=float(k))
+
+    def setMaxForceControlFeedbackOutput(self, v):
+        self._fcp(max_force_feedback=float(v))
+
+    def setMaxMomentControlFeedbackOutput(self, v):
+        self._fcp(max_moment_feedback=float(v))
+
+    def getFeedforwardForceGain(self):
+        return getattr(self, "_force_params", {}).get("kff_force", 0.95)
+
+    def getFeedforwardmomentGain(self):
+        return getattr(self, "_force_params", {}).get("kff_moment", 0.95)
+
+    def getMaxForceControlFeedbackOutput(self):
+        return getattr(self, "_force_params", {}).get("max_force_feedback", 20.0)
+
+    def getMaxMomentControlFeedbackOutput(self):
+        return getattr(self, "_force_params", {}).get("max_moment_feedback", 10.0)
+
+    def resetIntegrators(self):  # MotionForceTask.cpp:988-1002
+        self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 3)
+
+    def resetIntegratorsLinear(self):
+        self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 1)
+
+    def resetIntegratorsAngular(self):
+        self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 2)
 
     def getGoalPosition(self):
         return self._get_goal()[:, 0:3]
@@ -491,6 +595,44 @@ class JointTask(_Task):
 
     def setGains(self, kp, kv, ki=0.0):  # JointTask.h:237-257
         self._gains("saip_batch_set_joint_gains", kp, kv, ki)
+
+    def setGainsUnsafe(self, kp, kv, ki=0.0):  # same as the checked setter (the engine validates itself)
+        self.setGains(kp, kv, ki)
+
+    def getGains(self):
+        """list of PIDGains (one entry for isotropic gains), defaults JointTask.h:31-33"""
+        return self._cached_gains("saip_batch_set_joint_gains", [(50.0, 14.0, 0.0)])
+
+    def getJointSelectionMatrix(self):
+        return np.eye(self._robot.dof()) if self.S is None else self.S.reshape(self.getTaskDof(), self._robot.dof()).copy()
+
+    def getCurrentPosition(self):
+        """S q of the robot's current state, (B, task dof)"""
+        return self._robot._q @ self.getJointSelectionMatrix().T
+
+    def getCurrentVelocity(self):
+        return self._robot._dq @ self.getJointSelectionMatrix().T
+
+    def getGoalVelocity(self):
+        m = self.getTaskDof()
+        return self._get_goal()[:, m:2 * m]
+
+    def getGoalAcceleration(self):
+        m = self.getTaskDof()
+        return self._get_goal()[:, 2 * m:3 * m]
+
+    def getVelocitySaturationEnabled(self):
+        return getattr(self, "_vel_sat", False)
+
+    def getVelocitySaturationMaxVelocity(self):
+        v = np.asarray(getattr(self, "_sat_vel", (np.pi / 3,)), float)  # JointTask.h:44
+        return np.broadcast_to(v, (self.getTaskDof(),)).copy() if v.shape[0] in (1, self.getTaskDof()) else v
+
+    def getBoundedInertiaEstimateThreshold(self):
+        return getattr(self, "_bie_threshold", 0.1)
+
+    def resetIntegrators(self):
+        self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 1)
 
     # internal OTG, JointTask.h:272-327.  Acceleration-limited mode (the reference default) runs on the device.
     def enableInternalOtgAccelerationLimited(self, max_velocity=np.pi / 3.0, max_acceleration=2.0 * np.pi):

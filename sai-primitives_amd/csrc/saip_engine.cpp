@@ -1371,6 +1371,32 @@ extern "C" saip_status saip_batch_reinitialize_tasks(saip_batch* b) {
 	return launch_reinit_masked(b, -1, 7);
 }
 
+extern "C" saip_status saip_batch_reinitialize_task(saip_batch* b, int task) {
+	saip_status st = need_ready(b, "saip_batch_reinitialize_task");
+	if (st) return st;
+	if (task < 0 || task >= (int)b->tasks.size()) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_reinitialize_task: bad task");
+	return launch_reinit_masked(b, task, 7);
+}
+// MotionForceTask::resetIntegrators / Linear / Angular (MotionForceTask.cpp:988-1002), JointTask::resetIntegrators: parts bit 0 = linear
+// (or the joint task's), bit 1 = angular
+extern "C" saip_status saip_batch_reset_integrators(saip_batch* b, int task, int parts) {
+	saip_status st = need_ready(b, "saip_batch_reset_integrators");
+	if (st) return st;
+	if (task < 0 || task >= (int)b->tasks.size()) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_reset_integrators: bad task");
+	TaskHost& T = b->tasks[task];
+	if (!T.integ_dev) return SAIP_OK;
+	const size_t row = (size_t)b->ld * sizeof(double);
+	if (T.dev.type == saip::TASK_JOINT) {
+		if (parts & 1) HIP_TRY(hipMemsetAsync(T.integ_dev, 0, row * T.dev.m, b->stream));
+	} else {
+		if (parts & 1) HIP_TRY(hipMemsetAsync(T.integ_dev, 0, row * 3, b->stream));                      // position, then force (rows 6..8)
+		if (parts & 1) HIP_TRY(hipMemsetAsync(T.integ_dev + 6 * (size_t)b->ld, 0, row * 3, b->stream));
+		if (parts & 2) HIP_TRY(hipMemsetAsync(T.integ_dev + 3 * (size_t)b->ld, 0, row * 3, b->stream));  // orientation, then moment (rows 9..11)
+		if (parts & 2) HIP_TRY(hipMemsetAsync(T.integ_dev + 9 * (size_t)b->ld, 0, row * 3, b->stream));
+	}
+	return SAIP_OK;
+}
+
 extern "C" saip_status saip_batch_update_task_models(saip_batch* b) {
 	saip_status st = need_ready(b, "saip_batch_update_task_models");
 	if (st) return st;

@@ -543,3 +543,43 @@ def test_closed_loop_tracking_toy_integrator():
     err = np.linalg.norm(x_goal - x, axis=1)[ok]
     print("closed loop: initial error", err0, "final max error", err.max())
     assert err.max() < 0.1 * err0
+
+
+def test_per_task_reinitialise_reset_integrators_and_getters():
+    """TemplateTask::reInitializeTask of one task, MotionForceTask::resetIntegrators{,Linear,Angular}, JointTask::resetIntegrators and the
+    host-side getters of the facade (MotionForceTask.h / JointTask.h accessors)"""
+    from oracle import Oracle
+    B = 64
+    d = W.make_inputs(2, B)
+    spec = W.config_tasks(2)
+    spec[0].update(ki_pos=5.0, ki_ori=7.0)
+    spec[1].update(ki=3.0)
+    robot, ctrl, (mf, jt) = _engine(d["model"].name, spec, B)
+    orc = Oracle(d["model"], spec)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    ref, _ = orc.step(d["q"], d["dq"], d["goals"], nthreads=4)
+    assert W.torque_error(tau, ref) < TOL
+    # second cycle without a reset differs from the first (integrators advanced); after resetting every integrator it repeats the first
+    tau2 = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert W.torque_error(tau2, ref) > 1e-6
+    mf.resetIntegrators()
+    jt.resetIntegrators()
+    tau3 = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert W.torque_error(tau3, ref) < TOL
+    # linear part only: the orientation integrator keeps its two cycles -> equals an oracle whose linear / joint integrators were cleared
+    mf.resetIntegratorsLinear()
+    mf.resetIntegratorsAngular()
+    jt.resetIntegrators()
+    assert W.torque_error(_run(robot, ctrl, d["q"], d["dq"], d["goals"]), ref) < TOL
+    # per-task reinitialisation: the joint task's goal becomes the current posture, the motion-force goal stays
+    g_before = mf.getGoalPosition().copy()
+    jt.reInitializeTask()
+    assert np.allclose(jt.getGoalPosition(), d["q"]) and np.array_equal(mf.getGoalPosition(), g_before)
+    assert np.allclose(jt.getCurrentPosition(), d["q"]) and np.allclose(jt.getCurrentVelocity(), d["dq"])
+    # getters
+    assert mf.getPosControlGains()[0].kp == spec[0]["kp_pos"] and mf.getOriControlGains()[0].ki == 7.0 and jt.getGains()[0].ki == 3.0
+    assert mf.getForceSpaceDimension() == 0 and not mf.getVelocitySaturationEnabled() and jt.getJointSelectionMatrix().shape == (7, 7)
+    mf.setFeedforwardForceGain(0.8)
+    assert mf.getFeedforwardForceGain() == 0.8 and mf.getMaxForceControlFeedbackOutput() == 20.0
+    with pytest.raises(NotImplementedError):
+        mf.computeTorques()
