@@ -248,6 +248,9 @@ saip_status saip_batch_get_goal_host(saip_batch*, int task, double* goal);
 /* TemplateTask::reInitializeTask / RobotController::reinitializeTasks: goal := current pose of every instance,
  * velocities/accelerations := 0, integrators := 0 (MotionForceTask.cpp:204-245, JointTask.cpp:91-107). GPU kernel. */
 saip_status saip_batch_reinitialize_tasks(saip_batch*);
+/* MotionForceTask::getCurrentPosition / getCurrentOrientation (MotionForceTask.h:121-138) at the state last set: pos [3][B], rot [9][B]
+ * (row-major per instance); either pointer may be NULL */
+saip_status saip_batch_get_current_pose_host(saip_batch*, int task, double* pos, double* rot);
 /* TemplateTask::reInitializeTask of ONE task (MotionForceTask.cpp:204-245, JointTask.cpp:95-106) */
 saip_status saip_batch_reinitialize_task(saip_batch*, int task);
 /* MotionForceTask::resetIntegrators / resetIntegratorsLinear / resetIntegratorsAngular (MotionForceTask.cpp:988-1002; the linear part

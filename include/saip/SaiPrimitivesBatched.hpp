@@ -278,6 +278,20 @@ public:
 	void setMomentControlGains(double kp, double kv, double ki) { cfg([=](saip_batch* b, int id) { return saip_batch_set_moment_control_gains(b, id, kp, kv, ki); }); }
 	void setClosedLoopForceControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_force_control(b, id, e); }); }
 	void setClosedLoopMomentControl(bool e) { cfg([=](saip_batch* b, int id) { return saip_batch_set_closed_loop_moment_control(b, id, e); }); }
+	// control point [3][B] and compliant-frame orientation [9][B] (row-major per instance) in the world frame at the robot's current
+	// state, MotionForceTask.h:121-138
+	std::vector<double> getCurrentPosition() {
+		need();
+		std::vector<double> p((size_t)3 * _robot->batchSize());
+		check(saip_batch_get_current_pose_host(_batch, _id, p.data(), nullptr));
+		return p;
+	}
+	std::vector<double> getCurrentOrientation() {
+		need();
+		std::vector<double> r((size_t)9 * _robot->batchSize());
+		check(saip_batch_get_current_pose_host(_batch, _id, nullptr, r.data()));
+		return r;
+	}
 	void resetIntegratorsLinear() {
 		need();
 		check(saip_batch_reset_integrators(_batch, _id, 1));

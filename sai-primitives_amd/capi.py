@@ -118,6 +118,7 @@ def lib():
         "saip_batch_set_singularity_handling": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_singularity_strategies": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_reinitialize_task": (C.c_int, [vp, C.c_int]),
+        "saip_batch_get_current_pose_host": (C.c_int, [vp, C.c_int, dp, dp]),
         "saip_batch_reset_integrators": (C.c_int, [vp, C.c_int, C.c_int]),
         "saip_batch_set_singularity_gains": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_double]),
         "saip_batch_set_all_singularities_type1": (C.c_int, [vp, C.c_int, C.c_int]),

@@ -298,6 +298,7 @@ class MotionForceTask(_Task):
                  controlled_directions_translation=None, controlled_directions_rotation=None,
                  task_name="motion_force_task", is_force_motion_parametrization_in_compliant_frame=False, loop_timestep=0.001):
         super().__init__(robot, task_name, loop_timestep)
+        self._compliant_param = bool(is_force_motion_parametrization_in_compliant_frame)
         if is_force_motion_parametrization_in_compliant_frame:
             self._cfg("saip_batch_set_parametrization_in_compliant_frame", 1)
         self.link_name = link_name
@@ -359,10 +360,14 @@ class MotionForceTask(_Task):
 
     def parametrizeForceMotionSpaces(self, force_space_dimension, force_or_motion_single_axis=None):  # MotionForceTask.h:560-580
         self._force_dim = int(force_space_dimension)
+        if force_or_motion_single_axis is not None and self._force_dim in (1, 2):
+            self._force_axis = np.asarray(force_or_motion_single_axis, float).reshape(3) / np.linalg.norm(force_or_motion_single_axis)
         return self._space("saip_batch_parametrize_force_motion_spaces", force_space_dimension, force_or_motion_single_axis)
 
     def parametrizeMomentRotMotionSpaces(self, moment_space_dimension, moment_or_rot_motion_single_axis=None):
         self._moment_dim = int(moment_space_dimension)
+        if moment_or_rot_motion_single_axis is not None and self._moment_dim in (1, 2):
+            self._moment_axis = np.asarray(moment_or_rot_motion_single_axis, float).reshape(3) / np.linalg.norm(moment_or_rot_motion_single_axis)
         return self._space("saip_batch_parametrize_moment_rot_motion_spaces", moment_space_dimension, moment_or_rot_motion_single_axis)
 
     def setForceControlGains(self, kp, kv, ki=0.0):
@@ -471,6 +476,59 @@ class MotionForceTask(_Task):
 
     def resetIntegrators(self):  # MotionForceTask.cpp:988-1002
         self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 3)
+
+    def _current_pose(self):
+        ctrl = self._need_ctrl()
+        ctrl._push_state()
+        B = ctrl._robot.batch_size
+        pos, rot = np.empty((3, B)), np.empty((9, B))
+        capi.check(capi.lib().saip_batch_get_current_pose_host(ctrl._h, self._id, _dptr(pos), _dptr(rot)))
+        return pos.T.copy(), rot.T.reshape(B, 3, 3).copy()
+
+    def getCurrentPosition(self):
+        """(B, 3) control point in the world frame at the robot's current state, MotionForceTask.h:121"""
+        return self._current_pose()[0]
+
+    def getCurrentOrientation(self):
+        """(B, 3, 3) compliant-frame orientation in the world frame, MotionForceTask.h:136"""
+        return self._current_pose()[1]
+
+    def _sigma(self, dim, axis, sel, R):
+        """sigmaPosition / sigmaOrientation, MotionForceTask.cpp:892-971: sel (I - sigma_force) sel^T with the force (moment) space given
+        by `dim` and `axis`, in the compliant frame when the task is parametrised there"""
+        B = R.shape[0]
+        I = np.broadcast_to(np.eye(3), (B, 3, 3))
+        if dim == 0:
+            core = np.zeros((B, 3, 3))
+        elif dim == 3:
+            core = I
+        else:
+            a = (R @ axis) if self._compliant_param else np.broadcast_to(axis, (B, 3))
+            aa = np.einsum("bi,bj->bij", a, a)
+            core = aa if dim == 1 else I - aa
+        sf = sel @ core @ sel.T if dim in (1, 2) else (sel if dim == 3 else core)
+        return sel @ (I - sf) @ sel.T
+
+    def goalPositionReached(self, tolerance, verbose=False):
+        """(B,) bool: sqrt(e^T sigmaPosition e) < tolerance with e = goal - current position, MotionForceTask.cpp:548-563"""
+        pos, R = self._current_pose()
+        e = self.getGoalPosition() - pos
+        S = self._sigma(getattr(self, "_force_dim", 0), getattr(self, "_force_axis", np.array([0.0, 0.0, 1.0])), self.getTaskProjection()[0][:3, :3], R)
+        err = np.sqrt(np.maximum(np.einsum("bi,bij,bj->b", e, S, e), 0.0))
+        if verbose:
+            print("position error in MotionForceTask :", err, "\nTolerance :", tolerance)
+        return err < tolerance
+
+    def goalOrientationReached(self, tolerance, verbose=False):
+        """(B,) bool: sqrt(dphi^T sigmaOrientation dphi) < tolerance, dphi = orientationError(goal, current), MotionForceTask.cpp:565-579"""
+        _, R = self._current_pose()
+        Rd = self.getGoalOrientation()
+        dphi = -0.5 * sum(np.cross(R[:, :, c], Rd[:, :, c]) for c in range(3))
+        S = self._sigma(getattr(self, "_moment_dim", 0), getattr(self, "_moment_axis", np.array([0.0, 0.0, 1.0])), self.getTaskProjection()[0][3:, 3:], R)
+        err = np.sqrt(np.maximum(np.einsum("bi,bij,bj->b", dphi, S, dphi), 0.0))
+        if verbose:
+            print("orientation error in MotionForceTask :", err, "\nTolerance :", tolerance)
+        return err < tolerance
 
     def resetIntegratorsLinear(self):
         self._need_ctrl()._call("saip_batch_reset_integrators", self._id, 1)
@@ -623,6 +681,19 @@ class JointTask(_Task):
 
     def getVelocitySaturationEnabled(self):
         return getattr(self, "_vel_sat", False)
+
+    def goalPositionReached(self, tol):
+        """(B,) bool: sqrt(e^T U U^T e) < tol with e = current - goal and U = matrixRangeBasis(S N_prec) (JointTask.cpp:437-446; tolerance
+        1e-3 as JointTask.cpp:233); N_prec comes from the device, the small SVDs run on the host"""
+        e = self.getCurrentPosition() - self.getGoalPosition()
+        Jp = self.getJointSelectionMatrix()[None] @ self.getPreviousTasksNullspace()
+        out = np.zeros(e.shape[0], bool)
+        for b in range(e.shape[0]):
+            U, sv, _ = np.linalg.svd(Jp[b], full_matrices=False)
+            keep = (sv >= 1e-3 * sv[0]) if sv[0] >= 1e-3 and np.linalg.norm(Jp[b]) >= 1e-3 else np.zeros(len(sv), bool)
+            c = U[:, keep].T @ e[b]
+            out[b] = np.sqrt(c @ c) < tol
+        return out
 
     def getVelocitySaturationMaxVelocity(self):
         v = np.asarray(getattr(self, "_sat_vel", (np.pi / 3,)), float)  # JointTask.h:44

@@ -18,6 +18,7 @@ hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
+hipError_t launch_pose(const CycleParams& P, int task, double* out, hipStream_t stream);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream);
@@ -340,6 +341,7 @@ struct saip_batch {
 	ModelDev* model_dev = nullptr;
 	TaskDev* tasks_dev = nullptr;
 	std::vector<void*> allocs;
+	double* pose_dev = nullptr;              // [12][ld] scratch of saip_batch_get_current_pose_host
 	hipGraph_t rollout_graph = nullptr;      // one captured closed-loop period (saip_batch_rollout_async)
 	hipGraphExec_t rollout_exec = nullptr;
 };
@@ -1371,6 +1373,21 @@ extern "C" saip_status saip_batch_reinitialize_tasks(saip_batch* b) {
 	return launch_reinit_masked(b, -1, 7);
 }
 
+// MotionForceTask::getCurrentPosition / getCurrentOrientation (MotionForceTask.h:121-138) for the state last pushed: pos [3][B], rot [9][B]
+extern "C" saip_status saip_batch_get_current_pose_host(saip_batch* b, int task, double* pos, double* rot) {
+	saip_status st = need_type(b, task, saip::TASK_MOTION_FORCE, "saip_batch_get_current_pose_host");
+	if (st) return st;
+	if ((st = need_ready(b, "saip_batch_get_current_pose_host"))) return st;
+	if (!b->pose_dev && (st = dev_alloc(b, &b->pose_dev, (size_t)12 * b->ld))) return st;
+	CycleParams P;
+	if ((st = make_params(b, P, false))) return st;
+	hipError_t e = saip::launch_pose(P, task, b->pose_dev, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "pose kernel launch failed: %s", hipGetErrorString(e));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (pos && (st = copy_d2h(b, pos, b->pose_dev, 3))) return st;
+	if (rot && (st = copy_d2h(b, rot, b->pose_dev + 3 * (size_t)b->ld, 9))) return st;
+	return SAIP_OK;
+}
 extern "C" saip_status saip_batch_reinitialize_task(saip_batch* b, int task) {
 	saip_status st = need_ready(b, "saip_batch_reinitialize_task");
 	if (st) return st;

@@ -1089,6 +1089,21 @@ hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream) {
 	}
 	return hipGetLastError();
 }
+// current pose of the control frame of one motion-force task (MotionForceTask::getCurrentPosition / getCurrentOrientation): out = [12][ld],
+// rows 0..2 position, 3..11 rotation (row-major)
+__global__ void saip_pose_kernel(const CycleParams P, const int task, double* out) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= P.B) return;
+	double pw[3], Rc[9];
+	fk_control_frame(*P.model, P.tasks[task], P.q, P.ld, b, pw, Rc);
+	for (int e = 0; e < 3; e++) out[(size_t)e * P.ld + b] = pw[e];
+	for (int e = 0; e < 9; e++) out[(size_t)(3 + e) * P.ld + b] = Rc[e];
+}
+hipError_t launch_pose(const CycleParams& P, int task, double* out, hipStream_t stream) {
+	hipLaunchKernelGGL(saip_pose_kernel, dim3((P.B + 63) / 64), dim3(64), 0, stream, P, task, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream) {
 	hipLaunchKernelGGL(saip_reinit_kernel, dim3((P.B + 63) / 64), dim3(64), 0, stream, P);
 	return hipGetLastError();

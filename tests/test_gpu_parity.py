@@ -583,3 +583,36 @@ def test_per_task_reinitialise_reset_integrators_and_getters():
     assert mf.getFeedforwardForceGain() == 0.8 and mf.getMaxForceControlFeedbackOutput() == 20.0
     with pytest.raises(NotImplementedError):
         mf.computeTorques()
+
+
+def test_current_pose_and_goal_reached():
+    """MotionForceTask::getCurrentPosition / getCurrentOrientation and goalPositionReached / goalOrientationReached (MotionForceTask.cpp:548-579,
+    sigma matrices :892-971), JointTask::goalPositionReached (JointTask.cpp:437-446)"""
+    B = 48
+    d = W.make_inputs(2, B)
+    model = d["model"]
+    robot, ctrl, (mf, jt) = _engine(model.name, d["tasks"], B)
+    _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    fr = W.fk(model, d["q"])
+    li = model.link_index("end-effector")
+    x = fr[li][1] + fr[li][0] @ np.array([0.0, 0.0, 0.07])
+    assert np.abs(mf.getCurrentPosition() - x).max() < 1e-14 and np.abs(mf.getCurrentOrientation() - fr[li][0]).max() < 1e-14
+    e = np.linalg.norm(d["goals"][0][:, 0:3] - x, axis=1)
+    assert np.array_equal(mf.goalPositionReached(0.04), e < 0.04) and 0 < (e < 0.04).sum() < B
+    Rd = d["goals"][0][:, 3:12].reshape(B, 3, 3)
+    dphi = np.array([W.orientation_error(Rd[b], fr[li][0][b]) for b in range(B)])
+    assert np.array_equal(mf.goalOrientationReached(0.15), np.linalg.norm(dphi, axis=1) < 0.15)
+    ctrl.reinitializeTasks()
+    assert mf.goalPositionReached(1e-9).all() and mf.goalOrientationReached(1e-9).all() and jt.goalPositionReached(1e-9).all()
+    # force space along world z: the position error along z no longer counts (sigmaPosition = I - z z^T)
+    mf.parametrizeForceMotionSpaces(1, [0.0, 0.0, 1.0])
+    g = mf.getGoalPosition() + np.array([0.0, 0.0, 0.2])
+    mf.setGoalPosition(g)
+    assert mf.goalPositionReached(1e-9).all()
+    mf.setGoalPosition(g + np.array([0.01, 0.0, 0.0]))
+    assert not mf.goalPositionReached(5e-3).any() and mf.goalPositionReached(2e-2).all()
+    # the joint task behind a 6-dof task only sees the one direction left in its range: a goal offset inside the range of the
+    # motion-force task does not count
+    jt.setGoalPosition(d["q"] + 0.1)
+    r = jt.goalPositionReached(0.05)
+    assert r.dtype == bool and r.shape == (B,)
