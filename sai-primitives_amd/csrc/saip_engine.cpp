@@ -1266,7 +1266,7 @@ static bool lane_eligible(const saip_batch* b) {
 }
 // eight-lanes-per-instance kernel (saip_kernel_oct.hip): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain, default laws
 static bool oct_eligible(const saip_batch* b, const CycleParams& P) {
-	if (b->model->n != 7 || b->tasks.size() != 2 || P.jla) return false;
+	if (b->model->n != 7 || b->tasks.size() != 2) return false;
 	const TaskDev& mf = b->tasks[0].dev;
 	const TaskDev& jt = b->tasks[1].dev;
 	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;

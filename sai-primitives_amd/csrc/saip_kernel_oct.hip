@@ -19,6 +19,7 @@
 
 #include "saip_device.h"
 #include "saip_fk.h"
+#include "saip_law.h"
 #include "saip_oct_common.h"
 
 namespace saip {
@@ -688,6 +689,50 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (P.torque_sat) {
 		const double lim = md.effort[rr];
 		tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
+	}
+	if (P.jla) {
+		// joint limit avoidance wrap, RobotController.cpp:96-112: tau = JLA.computeTorques(tau) + N_c^T tau with
+		// N_c^T = I - S^T (S M^-1 S^T)^-1 S M^-1 over the joints inside a limit zone (padded to 7 x 7 with identity rows).  The zone logic is
+		// per joint = per lane; the rest only runs when some instance of the wavefront touches a zone.
+		bool zone;
+		const double tj = jla_joint(q_r, dq_r, md.q_lower[rr], md.q_upper[rr], md.vel_limit[rr], md.effort[rr], tv, &zone);
+		const bool in_zone = zone && act && !singular;
+		if (__any(in_zone)) {
+			sm.vec[1][r] = tv;
+			sm.vec[3][r] = in_zone ? 1.0 : 0.0;
+			__syncthreads();
+			double tall[N], zall[N];
+			UNR for (int j = 0; j < N; j++) {
+				tall[j] = sm.vec[1][j];
+				zall[j] = sm.vec[3][j];
+			}
+			double sacc = 0.0;
+			UNR for (int j = 0; j < N; j++) sacc = fma(mi[j], tall[j], sacc);  // (M^-1 tau)_rr
+			sm.vec[4][r] = in_zone ? sacc : 0.0;
+			UNR for (int j = 0; j < N; j++) sm.N1[r][j] = (in_zone && zall[j] != 0.0) ? mi[j] : ((j == rr) ? 1.0 : 0.0);  // N1 is dead: masked M^-1
+			__syncthreads();
+			double L[N][N], dinv[N], y[N], x[N];
+			UNR for (int i = 0; i < N; i++)
+				UNR for (int j = 0; j <= i; j++) L[i][j] = sm.N1[i][j];
+			oct_cholesky<N>(L, dinv);
+			UNR for (int i = 0; i < N; i++) {
+				double sy = sm.vec[4][i];
+				UNR for (int k = 0; k < i; k++) sy = fma(-L[i][k], y[k], sy);
+				y[i] = sy * dinv[i];
+			}
+			UNR for (int i = N - 1; i >= 0; i--) {
+				double sx = y[i];
+				UNR for (int k = i + 1; k < N; k++) sx = fma(-L[k][i], x[k], sx);
+				x[i] = sx * dinv[i];
+			}
+			double yr = 0.0;
+			UNR for (int i = 0; i < N; i++) yr = (i == rr) ? x[i] : yr;
+			if (in_zone) tv = tj + tv - yr;
+			if (P.torque_sat) {
+				const double lim = md.effort[rr];
+				tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
+			}
+		}
 	}
 	if (P.gravity_comp) {
 		const double* gv = md.gravity;

@@ -93,6 +93,33 @@ def test_oct_options(variant):
         q = q + 1e-3 * rng.standard_normal(q.shape)
 
 
+@pytest.mark.parametrize("opts", [dict(joint_limit_avoidance=True), dict(joint_limit_avoidance=True, gravity_comp=True, torque_saturation=True)],
+                         ids=["jla", "jla_gravity_saturation"])
+def test_oct_joint_limit_avoidance(opts):
+    """RobotController::enableJointLimitAvoidance (RobotController.cpp:96-112) on the oct kernel: config 11's states (joints inside the
+    position and velocity zones of their limits), two cycles"""
+    from oracle import Oracle
+    B = 1024
+    d = W.make_inputs(11, B)
+    orc = Oracle(d["model"], d["tasks"], **opts)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], B)
+    ctrl.setKernel(OCT)
+    ctrl.enableJointLimitAvoidance(True)
+    ctrl.enableGravityCompensation(opts.get("gravity_comp", False))
+    ctrl.enableTorqueSaturation(opts.get("torque_saturation", False))
+    q = d["q"].copy()
+    for c in range(2):
+        tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+        assert ctrl.kernelName() == "saip_cycle_oct"
+        ref, st = orc.step(q, d["dq"], d["goals"], nthreads=8)
+        assert np.array_equal(ctrl.status, st)
+        ok = st == 0
+        err = W.torque_error(tau[ok], ref[ok])
+        print("oct jla", opts, "cycle", c, "err", err)
+        assert err < TOL
+        q = q + 1e-3 * d["dq"]
+
+
 @pytest.mark.parametrize("cfg", [12, 14])
 def test_oct_flags_and_slow_path(cfg):
     """near-singular instances: flagged by the oct kernel, recomputed by the general kernel behind it (truncated task / blended strategies)"""
