@@ -1270,11 +1270,12 @@ static bool oct_eligible(const saip_batch* b, const CycleParams& P) {
 	const TaskDev& mf = b->tasks[0].dev;
 	const TaskDev& jt = b->tasks[1].dev;
 	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;
-	if (mf.k != 6 || !mf.bm_identity || mf.general_law || mf.cl_force || mf.cl_moment) return false;
+	if (mf.k != 6 || !mf.bm_identity || mf.cl_force || mf.cl_moment) return false;
 	if (jt.m != 7 || !jt.s_identity) return false;
 	for (int i = 0; i < 9; i++) {  // full task: projections and sigma matrices are identities (the kernel's control law relies on it)
 		const double id = (i % 4 == 0) ? 1.0 : 0.0;
-		if (mf.Ppos[i] != id || mf.Pori[i] != id || mf.sig_p[i] != id || mf.sig_o[i] != id) return false;
+		if (mf.Ppos[i] != id || mf.Pori[i] != id) return false;
+		if (!mf.general_law && (mf.sig_p[i] != id || mf.sig_o[i] != id)) return false;  // the short law assumes them; the general law forms its own
 	}
 	return lane_eligible(b);
 }

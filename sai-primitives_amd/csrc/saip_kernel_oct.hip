@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
 	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
+	const double gl3 = (mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
 	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
 
 	STAMP(1);
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	sm.vec[10][r] = gl0;
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
+	sm.vec[5][r] = gl3;
 #define OCT_PREFIX_STEP(D)                                                                                                          \
 	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
 		double Xa[12], Tn[12];                                                                                                      \
@@ -507,6 +509,15 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
 			}
 		}
+		double Ffa = 0.0;
+		if (mf.general_law) {
+			// velocity saturation and / or force & moment spaces (open-loop force control): the shared general law, MotionForceTask.cpp:306-487
+			double G30[30], Ff[6] = {0, 0, 0, 0, 0, 0};
+			UNR for (int e = 0; e < 24; e++) G30[e] = G24[e];
+			UNR for (int e = 0; e < 6; e++) G30[24 + e] = sm.vec[5][e];
+			law_motion_force_general<false>(&mf, vw, pw, Rc, G30, ip, io, (double*)nullptr, Fum, Ff);
+			UNR for (int a = 0; a < 6; a++) Ffa = (a == ra) ? Ff[a] : Ffa;
+		} else {
 		// full 6-dof task without force space: the task projections and sigma_position / sigma_orientation are identities (oct_eligible)
 		double e3[3];
 		UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G24[i];
@@ -521,14 +532,15 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 		UNR for (int i = 0; i < 3; i++) io[i] = fma(oe[i], mf.dt, io[i]);
 		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = G24[21 + i] - mf.kp_ori[i] * oe[i] - mf.kv_ori[i] * (vw[3 + i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
+		}
 		if (track_mf && live && !singular && r == 0) {
 			UNR for (int i = 0; i < 3; i++) {
 				mf.integ[(size_t)i * ld + b] = ip[i];
 				mf.integ[(size_t)(3 + i) * ld + b] = io[i];
 			}
 		}
-		// g_a = (Lambda_mod F_um)_a  (SingularityHandler.cpp:307-309; F_f = 0 without a force space); Bm = I for the full task
-		double s = 0.0;
+		// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
+		double s = Ffa;
 		UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
 		sm.vec[2][r] = s;
 	}

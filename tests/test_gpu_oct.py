@@ -120,6 +120,33 @@ def test_oct_joint_limit_avoidance(opts):
         q = q + 1e-3 * d["dq"]
 
 
+@pytest.mark.parametrize("cfg", [9, 10])
+def test_oct_general_control_laws(cfg):
+    """velocity saturation + hybrid force / motion control (9) and a full force space (10), MotionForceTask.cpp:306-487, on the oct kernel;
+    integrators on, three cycles"""
+    from oracle import Oracle
+    B = 512
+    d = W.make_inputs(cfg, B)
+    spec = W.config_tasks(cfg)
+    for t in spec:
+        if t["type"] == "motion_force":
+            t.update(ki_pos=4.0, ki_ori=6.0)
+    orc = Oracle(d["model"], spec)
+    robot, ctrl, _ = _engine(d["model"].name, spec, B)
+    ctrl.setKernel(OCT)
+    rng = np.random.default_rng(cfg)
+    q = d["q"].copy()
+    for c in range(3):
+        tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+        assert ctrl.kernelName() == "saip_cycle_oct"
+        ref, st = orc.step(q, d["dq"], d["goals"], nthreads=8)
+        assert np.array_equal(ctrl.status, st)
+        err = W.torque_error(tau, ref)
+        print("oct general laws cfg", cfg, "cycle", c, "err", err)
+        assert err < TOL
+        q = q + 1e-3 * rng.standard_normal(q.shape)
+
+
 @pytest.mark.parametrize("cfg", [12, 14])
 def test_oct_flags_and_slow_path(cfg):
     """near-singular instances: flagged by the oct kernel, recomputed by the general kernel behind it (truncated task / blended strategies)"""
