@@ -97,6 +97,9 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 	}
 }
 
+// FULL: general control laws and the joint-limit-avoidance wrap compiled in; the lean instantiation is the benchmarked default stack
+// (their mere presence costs it 1.7 % through register allocation)
+template <bool FULL>
 __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	constexpr int N = 7;
 	__shared__ OctInst smem[8];
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
 	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
-	const double gl3 = (mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
+	const double gl3 = (FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
 	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
 
 	STAMP(1);
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 		double Ffa = 0.0;
-		if (mf.general_law) {
+		if (FULL && mf.general_law) {
 			// velocity saturation and / or force & moment spaces (open-loop force control): the shared general law, MotionForceTask.cpp:306-487
 			double G30[30], Ff[6] = {0, 0, 0, 0, 0, 0};
 			UNR for (int e = 0; e < 24; e++) G30[e] = G24[e];
@@ -702,7 +705,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double lim = md.effort[rr];
 		tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
 	}
-	if (P.jla) {
+	if (FULL && P.jla) {
 		// joint limit avoidance wrap, RobotController.cpp:96-112: tau = JLA.computeTorques(tau) + N_c^T tau with
 		// N_c^T = I - S^T (S M^-1 S^T)^-1 S M^-1 over the joints inside a limit zone (padded to 7 x 7 with identity rows).  The zone logic is
 		// per joint = per lane; the rest only runs when some instance of the wavefront touches a zone.
@@ -762,7 +765,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
-	hipLaunchKernelGGL(saip_cycle_oct, grid, block, 0, stream, P);
+	if (P.jla || P.lane_general) hipLaunchKernelGGL(saip_cycle_oct<true>, grid, block, 0, stream, P);
+	else hipLaunchKernelGGL(saip_cycle_oct<false>, grid, block, 0, stream, P);
 	return hipGetLastError();
 }
 
