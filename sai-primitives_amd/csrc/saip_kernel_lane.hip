@@ -421,6 +421,32 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 			const bool ok_s0 = (u * tk->cert_kroot * tr >= tol2);
 			const bool pos = ldl_positive(smax2 * u);
 			need_exact = need_exact && !(ok_s0 && pos && tr > 0.0);
+			if (__any(need_exact)) {
+				// stage 3, the opposite certificate: with l = max_i Gs_ii <= lambda_max(Gs), a NEGATIVE LDL^T pivot of Gs - s_max^2 l I (all earlier
+				// pivots positive: Sylvester) proves lambda_min < s_max^2 lambda_max -- outside the non-singular branch for sure; so does
+				// trace(G) < s_abs_tol^2.  Without it every near-singular lane sent its whole wavefront through the eigen-solve just to confirm.
+				double lmx = 0.0;
+				UNR for (int a = 0; a < 6; a++) lmx = (a < k) ? fmax(lmx, G[a][a] * itr) : lmx;
+				double Gs[6][6];
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
+				UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < k) ? Gs[a][a] - smax2 * lmx : 1.0;
+				bool neg = false, clean = true;
+				UNR for (int kk = 0; kk < 6; kk++) {
+					const double dpv = Gs[kk][kk];
+					neg = neg || (clean && dpv < -1e-12);
+					clean = clean && (dpv > 1e-13);
+					const double id = 1.0 / dpv;
+					UNR for (int i = kk + 1; i < 6; i++) {
+						const double lik = Gs[i][kk] * id;
+						UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
+					}
+				}
+				if (need_exact && ((tr > 0.0 && neg) || tr < tol2)) {
+					singular = true;
+					need_exact = false;
+				}
+			}
 		}
 	}
 	// exact path (rare): wave-cooperative Jacobi eigen-solve of this lane's Gram matrix
