@@ -1,14 +1,16 @@
 // Control-cycle kernel for SMALL batches of 7-dof arms: EIGHT LANES PER ROBOT INSTANCE (eight instances per wavefront).
 //
 // At the batch the headline metric is quoted on (4096 instances per GPU) the lane-per-instance kernel fills 64 of the 1024 SIMDs
-// of an MI355X and each of those wavefronts walks the whole ~5000-instruction cycle alone.  Here the rows of every matrix of
+// of an MI355X and each of those wavefronts walks the whole 6 300-instruction cycle alone.  Here the rows of every matrix of
 // an instance are spread over eight lanes (lane r owns joint r / row r; lane 7 is padding), operands the other lanes need travel
-// through a small LDS block per instance, and the inherently serial factorisations are done redundantly (a Cholesky factor per
-// lane, then each lane solves for its own column of the inverse).  4096 instances become 512 wavefronts with ~1/4 of the
-// instructions each.  One wavefront per workgroup: __syncthreads() is a wave-local ordering point.
+// by DPP (scans along the chain, reductions) or through a small LDS block per instance, and the inherently serial factorisations
+// are done redundantly (a Cholesky factor per lane, then each lane solves for its own column of the inverse).  4096 instances
+// become 512 wavefronts of 2 500 instructions each.  One wavefront per workgroup: __syncthreads() is a wave-local ordering point.
 //
-// Covers exactly the stack of BASELINE config 2 (and 12 / 14): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain with
-// the default control laws; everything else stays on saip_cycle_lane / saip_cycle_wg (engine: oct_eligible).
+// Covers the stack of BASELINE config 2 (and 9 - 14): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain, default or
+// general control laws (no closed-loop force control), joint limit avoidance, gravity compensation, torque saturation; everything
+// else stays on saip_cycle_lane / saip_cycle_wg (engine: oct_eligible).  Instances outside the non-singular branch are flagged and,
+// where a task can handle them (truncated task, blended strategies), recomputed by the general kernel launched behind.
 //   SaiModel::updateModel()                       -> prefix-product kinematics, composite inertias, M, M^-1, M_BIE^-1
 //   RobotController::updateControllerTaskModels() -> /root/reference/src/RobotController.cpp:68-77, tasks/MotionForceTask.cpp:247-268,
 //       tasks/SingularityHandler.cpp:75-228 (non-singular branch; others flagged -> slow path), tasks/JointTask.cpp:218-283
@@ -51,7 +53,7 @@ struct OctInst {
 	};
 	double zo[8][6];     // world joint axis z (3), joint origin o (3)
 	double J[6][8];
-	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3..6 reductions / row exchange, 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
+	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3 / 4 row and scalar exchanges, 5 goal force + moment (general laws), 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
 	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
