@@ -112,10 +112,10 @@ struct CycleParams {
 	int lane_prefetch_ok;         // stack is {motion-force, full joint task}: the prefetch layout of the latency variant applies
 	int lane_active;              // instances per wavefront in the lane kernel (64 = every lane)
 	int lane_general;             // some task needs the general control laws (velocity saturation / force or moment space)
-	int pad3_;
+	int oct_general_joint;        // eight-lane kernel: the joint task takes the general path (<= 4 rows, any selection matrix)
 	int reinit_task, reinit_mask; // reinit kernel: task (-1 = all) and parts (1 linear/joint, 2 angular, 4 goal force+moment)
 	int any_bie;
-	int pad1_;
+	int oct_partial_mf;           // eight-lane kernel: the motion-force task is partial (k < 6)
 	double bie_thr;
 };
 

@@ -1236,7 +1236,8 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.reinit_task = -1;
 	P.reinit_mask = 7;
 	P.lane_general = 0;
-	P.pad3_ = 0;
+	P.oct_general_joint = 0;
+	P.oct_partial_mf = 0;
 	for (auto& T : b->tasks)
 		if (T.dev.general_law) P.lane_general = 1;
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
@@ -1264,20 +1265,30 @@ static bool lane_eligible(const saip_batch* b) {
 	}
 	return nmf <= 2;
 }
-// eight-lanes-per-instance kernel (saip_kernel_oct.hip): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain, default laws
-static bool oct_eligible(const saip_batch* b, const CycleParams& P) {
+// eight-lanes-per-instance kernel (saip_kernel_oct.hip): 7-dof chain, { MotionForceTask, JointTask }.  Either the headline stack
+// (full 6-dof motion-force task + full joint task: the joint task has rank <= 1) or any motion-force task of rank >= 2 with a joint
+// task of at most four rows (general range basis); default or general control laws, no closed-loop force control.
+static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 	if (b->model->n != 7 || b->tasks.size() != 2) return false;
 	const TaskDev& mf = b->tasks[0].dev;
 	const TaskDev& jt = b->tasks[1].dev;
 	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;
-	if (mf.k != 6 || !mf.bm_identity || mf.cl_force || mf.cl_moment) return false;
-	if (jt.m != 7 || !jt.s_identity) return false;
-	for (int i = 0; i < 9; i++) {  // full task: projections and sigma matrices are identities (the kernel's control law relies on it)
-		const double id = (i % 4 == 0) ? 1.0 : 0.0;
-		if (mf.Ppos[i] != id || mf.Pori[i] != id) return false;
-		if (!mf.general_law && (mf.sig_p[i] != id || mf.sig_o[i] != id)) return false;  // the short law assumes them; the general law forms its own
+	if (mf.cl_force || mf.cl_moment || mf.k < 2) return false;
+	const bool full_mf = mf.k == 6 && mf.bm_identity;
+	const bool full_jt = jt.m == 7 && jt.s_identity;
+	if (!full_mf && mf.general_law) return false;  // the general laws are wired for the full task only
+	if (full_mf) {
+		for (int i = 0; i < 9; i++) {  // full task: the projections are identities; the short control law also relies on identity sigma matrices
+			const double id = (i % 4 == 0) ? 1.0 : 0.0;
+			if (mf.Ppos[i] != id || mf.Pori[i] != id) return false;
+			if (!mf.general_law && (mf.sig_p[i] != id || mf.sig_o[i] != id)) return false;
+		}
 	}
-	return lane_eligible(b);
+	if (!(full_mf && full_jt) && jt.m > 4) return false;
+	if (!lane_eligible(b)) return false;
+	P.oct_general_joint = (full_mf && full_jt) ? 0 : 1;
+	P.oct_partial_mf = full_mf ? 0 : 1;
+	return true;
 }
 static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;

@@ -99,9 +99,53 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 	}
 }
 
-// FULL: general control laws and the joint-limit-avoidance wrap compiled in; the lean instantiation is the benchmarked default stack
+// eigen-decomposition of a symmetric 4 x 4 matrix in registers: cyclic Jacobi, fixed sweep count, no branches (converged rotations
+// degenerate to the identity); eigenvalues on the diagonal of A, eigenvectors in the columns of V
+__device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]) {
+	UNR for (int i = 0; i < 4; i++)
+		UNR for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 8; sweep++) {
+		UNR for (int p = 0; p < 3; p++)
+			UNR for (int q = p + 1; q < 4; q++) {
+				const double apq = A[p][q];
+				const bool rot = fabs(apq) > 1e-300;
+				const double theta = (A[q][q] - A[p][p]) / (2.0 * (rot ? apq : 1.0));
+				const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+				const double t = rot ? tt : 0.0;
+				const double c = rsqrt(fma(t, t, 1.0)), s = t * c;
+				UNR for (int k = 0; k < 4; k++) {
+					const double akp = A[k][p], akq = A[k][q];
+					A[k][p] = c * akp - s * akq;
+					A[k][q] = s * akp + c * akq;
+				}
+				UNR for (int k = 0; k < 4; k++) {
+					const double apk = A[p][k], aqk = A[q][k];
+					A[p][k] = c * apk - s * aqk;
+					A[q][k] = s * apk + c * aqk;
+				}
+				UNR for (int k = 0; k < 4; k++) {
+					const double vkp = V[k][p], vkq = V[k][q];
+					V[k][p] = c * vkp - s * vkq;
+					V[k][q] = s * vkp + c * vkq;
+				}
+			}
+	}
+}
+// inverse of an SPD 4 x 4 matrix given by its lower triangle
+__device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) {
+	double L[4][4], dinv[4], x[4];
+	UNR for (int i = 0; i < 4; i++)
+		UNR for (int j = 0; j <= i; j++) L[i][j] = A[i][j];
+	oct_cholesky<4>(L, dinv);
+	UNR for (int col = 0; col < 4; col++) {
+		oct_solve_unit<4>(L, dinv, col, x);
+		UNR for (int i = 0; i < 4; i++) Ainv[i][col] = x[i];
+	}
+}
+
+// FULL: general control laws, partial motion-force tasks and the joint-limit-avoidance wrap compiled in; GJ: general joint task (<= 4 rows); the lean instantiation is the benchmarked default stack
 // (their mere presence costs it 1.7 % through register allocation)
-template <bool FULL>
+template <bool FULL, bool GJ>
 __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	constexpr int N = 7;
 	__shared__ OctInst smem[8];
@@ -117,6 +161,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const ModelDev& md = *P.model;
 	const TaskDev& mf = P.tasks[0];
 	const TaskDev& jt = P.tasks[1];
+	const int kmf = FULL ? mf.k : 6;  // rank of the motion-force task (partial tasks: rows >= k of its Jacobian are zero, diagonals padded with 1)
 
 	STAMP(0);
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
@@ -124,7 +169,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const double dq_r = P.dq[(size_t)rr * ld + b];
 	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
 	const double gl3 = (FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
-	const double jg_q = jt.goal[(size_t)rr * ld + b], jg_dq = jt.goal[(size_t)(N + rr) * ld + b], jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
+	const int mj = GJ ? jt.m : N;                 // rows of the joint task (general path: <= 4)
+	const int rj = GJ ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
+	const double jg_q = jt.goal[(size_t)rj * ld + b], jg_dq = jt.goal[(size_t)(mj + rj) * ld + b], jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
 
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -253,7 +300,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 	}
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
-	double pw[3], Rc[9];
+	double pw[3], Rc[9], jwc[6];  // control point, control frame, this joint's column of the world Jacobian [Jv; Jw]
 	{
 		const int bd = mf.body;
 		double Rb[12];
@@ -265,13 +312,17 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const bool on = rr <= bd;
 		const double rx = pw[0] - o[0], ry = pw[1] - o[1], rz = pw[2] - o[2];
 		const double c0 = z[1] * rz - z[2] * ry, c1 = z[2] * rx - z[0] * rz, c2 = z[0] * ry - z[1] * rx;
-		{
-			sm.J[0][r] = on ? (rev ? c0 : z[0]) : 0.0;
-			sm.J[1][r] = on ? (rev ? c1 : z[1]) : 0.0;
-			sm.J[2][r] = on ? (rev ? c2 : z[2]) : 0.0;
-			sm.J[3][r] = (on && rev) ? z[0] : 0.0;
-			sm.J[4][r] = (on && rev) ? z[1] : 0.0;
-			sm.J[5][r] = (on && rev) ? z[2] : 0.0;
+		const double jw[6] = {on ? (rev ? c0 : z[0]) : 0.0, on ? (rev ? c1 : z[1]) : 0.0, on ? (rev ? c2 : z[2]) : 0.0,
+							  (on && rev) ? z[0] : 0.0,    (on && rev) ? z[1] : 0.0,    (on && rev) ? z[2] : 0.0};
+		UNR for (int a = 0; a < 6; a++) jwc[a] = act ? jw[a] : 0.0;
+		if (FULL && !mf.bm_identity) {  // partial task: rows of the Jacobian in the basis of range(P), Jb = Bm^T Jw (columns >= k of Bm are zero)
+			UNR for (int a = 0; a < 6; a++) {
+				double sj = 0.0;
+				UNR for (int e = 0; e < 6; e++) sj = fma(mf.Bm[e * 6 + a], jw[e], sj);
+				sm.J[a][r] = sj;
+			}
+		} else {
+			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
 		}
 	}
 	__syncthreads();
@@ -333,6 +384,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int j = 0; j < N; j++) s = fma(Jf[a][j], dqa[j], s);
 			vw[a] = s;
 		}
+		if (FULL && !mf.bm_identity) {  // the task velocities use the UNprojected Jacobian (MotionForceTask.cpp:293-298): vw = Jw dq
+			UNR for (int a = 0; a < 6; a++) vw[a] = oct_group_sum(jwc[a] * dq_r);
+		}
 	}
 	STAMP(5);
 	STAMP(6);
@@ -355,7 +409,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int a = 0; a < 6; a++)
 				UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
 			bool pos = true;
-			UNR for (int a = 0; a < 6; a++) Gs[a][a] -= shift;
+			UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < kmf) ? Gs[a][a] - shift : 1.0;  // zero rows of a partial task: padded
 			UNR for (int kk = 0; kk < 6; kk++) {
 				const double d = Gs[kk][kk];
 				pos = pos && (d > 1e-13);
@@ -368,7 +422,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			return pos;
 		};
 		// stage 1: lambda_max(Gs) <= trace(Gs) = 1, lambda_max(G) >= trace(G)/6; stage 2: trace-power bound (see saip_kernel_lane.hip)
-		bool need_exact = !((tr > 0.0) && (tr >= 6.0 * tol2) && ldl_positive(smax2));
+		bool need_exact = !((tr > 0.0) && (tr >= (double)kmf * tol2) && ldl_positive(smax2));
 #if defined(SAIP_OCT_FORCE_EXACT)  // diagnostic build only: every instance takes the exact fallbacks (validated against the oracle once per change)
 		need_exact = true;
 #endif
@@ -402,11 +456,11 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				// sure; so does trace(G) < s_abs_tol^2.  Batches with many near-singular instances would otherwise send every one of them
 				// through the eigen-solve only to confirm it (measured: 70 us instead of 10 us per launch at a third of the batch).
 				double lmx = 0.0;
-				UNR for (int a = 0; a < 6; a++) lmx = fmax(lmx, G[a][a] * itr);
+				UNR for (int a = 0; a < 6; a++) lmx = (a < kmf) ? fmax(lmx, G[a][a] * itr) : lmx;
 				double Gs[6][6];
 				UNR for (int a = 0; a < 6; a++)
 					UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
-				UNR for (int a = 0; a < 6; a++) Gs[a][a] -= smax2 * lmx;
+				UNR for (int a = 0; a < 6; a++) Gs[a][a] = (a < kmf) ? Gs[a][a] - smax2 * lmx : 1.0;
 				bool neg = false, clean = true;
 				UNR for (int kk = 0; kk < 6; kk++) {
 					const double dpv = Gs[kk][kk];
@@ -430,12 +484,12 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				if (need_exact && r == 0) {
 					for (int a = 0; a < 6; a++)
 						for (int c = 0; c < 6; c++) sm.A[a][c] = G[a][c];
-					oct_serial_jacobi(&sm.A[0][0], nullptr, 6, 8);
+					oct_serial_jacobi(&sm.A[0][0], nullptr, kmf, 8);
 					double lmax = 0.0;
-					for (int i = 0; i < 6; i++) lmax = fmax(lmax, sm.A[i][i]);
+					for (int i = 0; i < kmf; i++) lmax = fmax(lmax, sm.A[i][i]);
 					const double s0 = sqrt(lmax);
 					bool sing = !(s0 >= mf.s_abs_tol);
-					for (int i = 0; i < 6; i++)
+					for (int i = 0; i < kmf; i++)
 						if (sqrt(fmax(sm.A[i][i], 0.0)) / s0 < mf.s_max) sing = true;
 					sm.vec[9][0] = sing ? 1.0 : 0.0;
 				}
@@ -487,8 +541,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				s = fma(t1[j], Jf[c][j], s);
 				if (general_bie) s2 = fma(tb[j], Jf[c][j], s2);
 			}
-			sm.A[r][c] = s;
-			if (general_bie) sm.Am[r][c] = s2;
+			const bool padrow = FULL && ra >= kmf && c == ra;  // zero row of a partial task: keep the factorisation regular
+			sm.A[r][c] = padrow ? 1.0 : s;
+			if (general_bie) sm.Am[r][c] = padrow ? 1.0 : s2;
 		}
 	}
 	__syncthreads();
@@ -549,6 +604,35 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int e = 0; e < 6; e++) G30[24 + e] = sm.vec[5][e];
 			law_motion_force_general<false>(&mf, vw, pw, Rc, G30, ip, io, (double*)nullptr, Fum, Ff);
 			UNR for (int a = 0; a < 6; a++) Ffa = (a == ra) ? Ff[a] : Ffa;
+		} else if (FULL && !mf.bm_identity) {
+			// partial task: the short law with its projections (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0), then
+			// F in the basis of range(P): fhat = Bm^T F_um
+			double v[3], w[3], e3[3], tmp[3], Fw[6];
+			UNR for (int i = 0; i < 3; i++) {
+				v[i] = mf.Ppos[3 * i] * vw[0] + mf.Ppos[3 * i + 1] * vw[1] + mf.Ppos[3 * i + 2] * vw[2];
+				w[i] = mf.Pori[3 * i] * vw[3] + mf.Pori[3 * i + 1] * vw[4] + mf.Pori[3 * i + 2] * vw[5];
+			}
+			UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G24[i];
+			UNR for (int i = 0; i < 3; i++) ip[i] += (mf.sig_p[3 * i] * e3[0] + mf.sig_p[3 * i + 1] * e3[1] + mf.sig_p[3 * i + 2] * e3[2]) * mf.dt;
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - mf.kp_pos[i] * e3[i] - mf.kv_pos[i] * (v[i] - G24[12 + i]) - mf.ki_pos[i] * ip[i];
+			UNR for (int i = 0; i < 3; i++) Fw[i] = mf.sig_p[3 * i] * tmp[0] + mf.sig_p[3 * i + 1] * tmp[1] + mf.sig_p[3 * i + 2] * tmp[2];
+			double oe[3] = {0, 0, 0};
+			UNR for (int c = 0; c < 3; c++) {
+				const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
+				oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+				oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+				oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+			}
+			double dphi[3];
+			UNR for (int i = 0; i < 3; i++) dphi[i] = mf.sig_o[3 * i] * oe[0] + mf.sig_o[3 * i + 1] * oe[1] + mf.sig_o[3 * i + 2] * oe[2];
+			UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * mf.dt;
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - mf.kp_ori[i] * dphi[i] - mf.kv_ori[i] * (w[i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
+			UNR for (int i = 0; i < 3; i++) Fw[3 + i] = mf.sig_o[3 * i] * tmp[0] + mf.sig_o[3 * i + 1] * tmp[1] + mf.sig_o[3 * i + 2] * tmp[2];
+			UNR for (int a = 0; a < 6; a++) {
+				double sf = 0.0;
+				UNR for (int e = 0; e < 6; e++) sf = fma(mf.Bm[e * 6 + a], Fw[e], sf);
+				Fum[a] = sf;
+			}
 		} else {
 		// full 6-dof task without force space: the task projections and sigma_position / sigma_orientation are identities (oct_eligible)
 		double e3[3];
@@ -607,6 +691,147 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		sm.vec[1][r] = tau_r;
 	}
 	STAMP(11);
+	// ---------------------------------------------------------------- JointTask, general path (GJ): any selection matrix with m <= 4 rows behind any
+	// motion-force task.  Lane j holds column j of Jp = S N_1 (m x 7).  Left singular vectors / squared singular values of Jp = eigen-pairs
+	// of its 4 x 4 Gram matrix (sums over the lanes by DPP), by an unrolled Jacobi solve in registers; matrixRangeBasis keeps the directions
+	// with sigma_i / sigma_0 >= 1e-3 (JointTask.cpp:233); the rest of the task algebra is r x r with dropped directions padded.
+	double tv;
+	if (GJ) {
+		double cp[4];
+		UNR for (int i = 0; i < 4; i++) {
+			double sc = 0.0;
+			UNR for (int l = 0; l < N; l++) sc = fma(jt.S[i * N + l], cj[l], sc);  // rows >= m of the stored S are zero
+			cp[i] = act ? sc : 0.0;
+		}
+		double Gp[4][4], V4[4][4], trp = 0.0;
+		UNR for (int i = 0; i < 4; i++)
+			UNR for (int k = 0; k <= i; k++) {
+				const double gs = oct_group_sum(cp[i] * cp[k]);
+				Gp[i][k] = gs;
+				Gp[k][i] = gs;
+				if (i == k) trp += gs;
+			}
+		oct_jacobi4(Gp, V4);
+		double lmaxp = 0.0;
+		UNR for (int c = 0; c < 4; c++) lmaxp = fmax(lmaxp, Gp[c][c]);
+		const bool any_range = (sqrt(fmax(trp, 0.0)) >= 1e-3) && (sqrt(lmaxp) >= 1e-3);
+		bool keep[4];
+		double jh[4];
+		UNR for (int c = 0; c < 4; c++) {
+			keep[c] = any_range && (sqrt(fmax(Gp[c][c], 0.0) / lmaxp) >= 1e-3);
+			double sj = 0.0;
+			UNR for (int i = 0; i < 4; i++) sj = fma(V4[i][c], cp[i], sj);
+			jh[c] = keep[c] ? sj : 0.0;  // own column of Jh = U^T Jp
+		}
+		// gather Jh, q, the joint-task goal rows and w = M^-1 tau_prec for the whole instance
+		double tauv[N];
+		UNR for (int j = 0; j < N; j++) tauv[j] = sm.vec[1][j];
+		double wr = 0.0;
+		UNR for (int l = 0; l < N; l++) wr = fma(mi[l], tauv[l], wr);
+		UNR for (int c = 0; c < 4; c++) sm.T1[c][r] = jh[c];
+		sm.vec[4][r] = wr;
+		sm.vec[6][r] = q_r;
+		sm.vec[7][r] = jg_q;
+		sm.vec[8][r] = jg_dq;
+		sm.vec[3][r] = jg_ddq;
+		__syncthreads();
+		double Jh[4][N];
+		UNR for (int c = 0; c < 4; c++)
+			UNR for (int j = 0; j < N; j++) Jh[c][j] = sm.T1[c][j];
+		double t1v[4], A4[4][4], Lam4[4][4], Lmod4[4][4];
+		UNR for (int c = 0; c < 4; c++) {
+			double st = 0.0;
+			UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mi[l], st);  // (Jh M^-1)[c][rr]: M^-1 symmetric
+			t1v[c] = act ? st : 0.0;
+		}
+		UNR for (int c = 0; c < 4; c++)
+			UNR for (int k = 0; k <= c; k++) {
+				const double gs = oct_group_sum(t1v[c] * jh[k]);
+				A4[c][k] = (c == k && !keep[c]) ? 1.0 : gs;
+			}
+		oct_spd_inverse4(A4, Lam4);
+		if (jt.decoupling == DEC_FULL) {
+			UNR for (int c = 0; c < 4; c++)
+				UNR for (int k = 0; k < 4; k++) Lmod4[c][k] = Lam4[c][k];
+		} else if (jt.decoupling == DEC_IMPEDANCE) {
+			UNR for (int c = 0; c < 4; c++)
+				UNR for (int k = 0; k < 4; k++) Lmod4[c][k] = (c == k) ? 1.0 : 0.0;
+		} else if (general_bie) {
+			double tbv[4];
+			UNR for (int c = 0; c < 4; c++) {
+				double st = 0.0;
+				UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mb[l], st);
+				tbv[c] = act ? st : 0.0;
+			}
+			UNR for (int c = 0; c < 4; c++)
+				UNR for (int k = 0; k <= c; k++) {
+					const double gs = oct_group_sum(tbv[c] * jh[k]);
+					A4[c][k] = (c == k && !keep[c]) ? 1.0 : gs;
+				}
+			oct_spd_inverse4(A4, Lmod4);
+		} else {  // rank-one bounded-inertia form: Lambda_mod = Lambda + gamma (Lambda t)(Lambda t)^T, t = Jh m
+			double t[4], lt[4], qq = 0.0;
+			UNR for (int c = 0; c < 4; c++) {
+				double st = 0.0;
+				UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mcol[l], st);
+				t[c] = st;
+			}
+			UNR for (int c = 0; c < 4; c++) {
+				double sl = 0.0;
+				UNR for (int k = 0; k < 4; k++) sl = fma(Lam4[c][k], t[k], sl);
+				lt[c] = sl;
+				qq = fma(t[c], sl, qq);
+			}
+			const double gamma = beta * oct_rcp(fma(-beta, qq, 1.0));
+			UNR for (int c = 0; c < 4; c++)
+				UNR for (int k = 0; k < 4; k++) Lmod4[c][k] = fma(gamma * lt[c], lt[k], Lam4[c][k]);
+		}
+		// control law of the (at most four) task rows, every lane alike (JointTask.cpp:285-356)
+		double qa[N], dqa[N], wa[N];
+		UNR for (int j = 0; j < N; j++) {
+			qa[j] = sm.vec[6][j];
+			dqa[j] = sm.vec[0][j];
+			wa[j] = sm.vec[4][j];
+		}
+		const bool track = (jt.has_ki || P.integ_always);
+		double a1[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+		UNR for (int i = 0; i < 4; i++) {
+			double cur = 0.0, vel = 0.0, sw = 0.0;
+			UNR for (int l = 0; l < N; l++) {
+				const double sil = jt.S[i * N + l];
+				cur = fma(sil, qa[l], cur);
+				vel = fma(sil, dqa[l], vel);
+				sw = fma(sil, wa[l], sw);
+			}
+			const bool row = i < mj;
+			const double gq = row ? sm.vec[7][i] : 0.0, gdq = row ? sm.vec[8][i] : 0.0, gddq = row ? sm.vec[3][i] : 0.0;
+			const double e = cur - gq;
+			double ie = 0.0;
+			if (track && row) ie = jt.integ[(size_t)i * ld + b];
+			ie += e * jt.dt;  // :323-324
+			if (track && row && live && !singular && r == 0) jt.integ[(size_t)i * ld + b] = ie;
+			double fi;
+			if (jt.vel_sat) {  // :327-341
+				double vdes = -jt.kp[i] * jt.kvinv[i] * e - jt.ki[i] * jt.kvinv[i] * ie;
+				vdes = fmin(fmax(vdes, -jt.sat[i]), jt.sat[i]);
+				fi = -jt.kv[i] * (vel - vdes);
+			} else {
+				fi = -jt.kp[i] * e - jt.kv[i] * (vel - gdq) - jt.ki[i] * ie;  // :342-345
+			}
+			const double ai = gddq - sw;
+			UNR for (int c = 0; c < 4; c++) {
+				a1[c] = fma(V4[i][c], row ? ai : 0.0, a1[c]);
+				b1[c] = fma(V4[i][c], row ? fi : 0.0, b1[c]);
+			}
+		}
+		double tj = tau_r;
+		UNR for (int c = 0; c < 4; c++) {
+			double gc = 0.0;
+			UNR for (int k = 0; k < 4; k++) gc = fma(Lam4[c][k], a1[k], fma(Lmod4[c][k], b1[k], gc));  // :348-351
+			tj = fma(jh[c], keep[c] ? gc : 0.0, tj);  // tau += Jh^T g
+		}
+		tv = tj;
+	} else {
 	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
 	sm.vec[3][r] = act ? cn : -1.0;
 	__syncthreads();
@@ -727,7 +952,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : oct_rcp(Ab));
 		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
 	}
-	double tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
+	tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
+	}
 	STAMP(14);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {
@@ -794,8 +1020,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
-	if (P.jla || P.lane_general) hipLaunchKernelGGL(saip_cycle_oct<true>, grid, block, 0, stream, P);
-	else hipLaunchKernelGGL(saip_cycle_oct<false>, grid, block, 0, stream, P);
+	if (P.oct_general_joint) hipLaunchKernelGGL((saip_cycle_oct<true, true>), grid, block, 0, stream, P);
+	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, false>), grid, block, 0, stream, P);
+	else hipLaunchKernelGGL((saip_cycle_oct<false, false>), grid, block, 0, stream, P);
 	return hipGetLastError();
 }
 
