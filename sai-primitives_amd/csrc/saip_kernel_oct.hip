@@ -99,34 +99,47 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 	}
 }
 
-// eigen-decomposition of a symmetric 4 x 4 matrix in registers: cyclic Jacobi, fixed sweep count, no branches (converged rotations
-// degenerate to the identity); eigenvalues on the diagonal of A, eigenvectors in the columns of V
+// eigen-decomposition of a symmetric 4 x 4 matrix in registers: cyclic Jacobi, wave-uniform convergence test per sweep (rotations of
+// an already diagonal matrix degenerate to the identity); eigenvalues on the diagonal of A, eigenvectors in the columns of V
 __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]) {
 	UNR for (int i = 0; i < 4; i++)
 		UNR for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 8; sweep++) {
+	for (int sweep = 0; sweep < 10; sweep++) {
+		double off = 0.0, dg = 0.0;
+		UNR for (int p = 0; p < 4; p++) {
+			dg = fma(A[p][p], A[p][p], dg);
+			UNR for (int q = p + 1; q < 4; q++) off = fma(A[p][q], A[p][q], off);
+		}
+		if (!__any(off > 1e-32 * dg)) break;  // every instance of the wavefront has converged (quadratic convergence: 3 - 5 sweeps)
 		UNR for (int p = 0; p < 3; p++)
 			UNR for (int q = p + 1; q < 4; q++) {
-				const double apq = A[p][q];
-				const bool rot = fabs(apq) > 1e-300;
-				const double theta = (A[q][q] - A[p][p]) / (2.0 * (rot ? apq : 1.0));
-				const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-				const double t = rot ? tt : 0.0;
-				const double c = rsqrt(fma(t, t, 1.0)), s = t * c;
+				// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
+				// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
+				const double apq = A[p][q], d = A[q][q] - A[p][p], b2 = 2.0 * apq;
+				const double x = fma(d, d, b2 * b2);
+				const bool rot = x > 1e-300;
+				const double h = rot ? x * oct_rsqrt(x) : 1.0;
+				const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
+				const double t = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
+				const double c = oct_rsqrt(fma(t, t, 1.0)), sn = t * c;
 				UNR for (int k = 0; k < 4; k++) {
-					const double akp = A[k][p], akq = A[k][q];
-					A[k][p] = c * akp - s * akq;
-					A[k][q] = s * akp + c * akq;
+					if (k != p && k != q) {
+						const double akp = A[k][p], akq = A[k][q];
+						const double np_ = c * akp - sn * akq, nq_ = sn * akp + c * akq;
+						A[k][p] = np_;
+						A[p][k] = np_;
+						A[k][q] = nq_;
+						A[q][k] = nq_;
+					}
 				}
-				UNR for (int k = 0; k < 4; k++) {
-					const double apk = A[p][k], aqk = A[q][k];
-					A[p][k] = c * apk - s * aqk;
-					A[q][k] = s * apk + c * aqk;
-				}
+				A[p][p] = fma(-t, apq, A[p][p]);
+				A[q][q] = fma(t, apq, A[q][q]);
+				A[p][q] = 0.0;
+				A[q][p] = 0.0;
 				UNR for (int k = 0; k < 4; k++) {
 					const double vkp = V[k][p], vkq = V[k][q];
-					V[k][p] = c * vkp - s * vkq;
-					V[k][q] = s * vkp + c * vkq;
+					V[k][p] = c * vkp - sn * vkq;
+					V[k][q] = sn * vkp + c * vkq;
 				}
 			}
 	}
