@@ -43,7 +43,11 @@ def test_oct_is_the_default_for_the_headline_batch():
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 4096)
     _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert ctrl.kernelName() == "saip_cycle_oct"
-    d = W.make_inputs(3, 64)   # partial tasks: not covered
+    d = W.make_inputs(3, 64)   # partial motion-force task + 4-row joint task: the general eight-lane path
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
+    _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_oct"
+    d = W.make_inputs(6, 64)   # 8-dof chain, joint task first: not covered
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
     _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert ctrl.kernelName() == "saip_cycle_lane"
