@@ -112,7 +112,7 @@ struct CycleParams {
 	int lane_prefetch_ok;         // stack is {motion-force, full joint task}: the prefetch layout of the latency variant applies
 	int lane_active;              // instances per wavefront in the lane kernel (64 = every lane)
 	int lane_general;             // some task needs the general control laws (velocity saturation / force or moment space)
-	int oct_general_joint;        // eight-lane kernel: the joint task takes the general path (<= 4 rows, any selection matrix)
+	int oct_general_joint;        // eight-lane kernel, joint task: 0 rank <= 1 behind a 6-dof task, 1 Gram path (<= 4 rows), 2 full task behind a partial one
 	int reinit_task, reinit_mask; // reinit kernel: task (-1 = all) and parts (1 linear/joint, 2 angular, 4 goal force+moment)
 	int any_bie;
 	int oct_partial_mf;           // eight-lane kernel: the motion-force task is partial (k < 6)

@@ -1284,9 +1284,10 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 			if (!mf.general_law && (mf.sig_p[i] != id || mf.sig_o[i] != id)) return false;
 		}
 	}
-	if (!(full_mf && full_jt) && jt.m > 4) return false;
+	const bool full_behind_partial = full_jt && !full_mf && mf.k <= 5;  // Jp = N_1 has rank 7 - k: multi-pivot Gram-Schmidt path
+	if (!(full_mf && full_jt) && !full_behind_partial && jt.m > 4) return false;
 	if (!lane_eligible(b)) return false;
-	P.oct_general_joint = (full_mf && full_jt) ? 0 : 1;
+	P.oct_general_joint = (full_mf && full_jt) ? 0 : (full_behind_partial ? 2 : 1);
 	P.oct_partial_mf = full_mf ? 0 : 1;
 	return true;
 }

@@ -144,21 +144,23 @@ __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]
 			}
 	}
 }
-// inverse of an SPD 4 x 4 matrix given by its lower triangle
-__device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) {
-	double L[4][4], dinv[4], x[4];
-	UNR for (int i = 0; i < 4; i++)
+// inverse of an SPD R x R matrix given by its lower triangle
+template <int R>
+__device__ __forceinline__ void oct_spd_inverse_n(const double (&A)[R][R], double (&Ainv)[R][R]) {
+	double L[R][R], dinv[R], x[R];
+	UNR for (int i = 0; i < R; i++)
 		UNR for (int j = 0; j <= i; j++) L[i][j] = A[i][j];
-	oct_cholesky<4>(L, dinv);
-	UNR for (int col = 0; col < 4; col++) {
-		oct_solve_unit<4>(L, dinv, col, x);
-		UNR for (int i = 0; i < 4; i++) Ainv[i][col] = x[i];
+	oct_cholesky<R>(L, dinv);
+	UNR for (int col = 0; col < R; col++) {
+		oct_solve_unit<R>(L, dinv, col, x);
+		UNR for (int i = 0; i < R; i++) Ainv[i][col] = x[i];
 	}
 }
+__device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) { oct_spd_inverse_n<4>(A, Ainv); }
 
 // FULL: general control laws, partial motion-force tasks and the joint-limit-avoidance wrap compiled in; GJ: general joint task (<= 4 rows); the lean instantiation is the benchmarked default stack
 // (their mere presence costs it 1.7 % through register allocation)
-template <bool FULL, bool GJ>
+template <bool FULL, int GJ>
 __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	constexpr int N = 7;
 	__shared__ OctInst smem[8];
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const double dq_r = P.dq[(size_t)rr * ld + b];
 	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
 	const double gl3 = (FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
-	const int mj = GJ ? jt.m : N;                 // rows of the joint task (general path: <= 4)
-	const int rj = GJ ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
+	const int mj = GJ == 1 ? jt.m : N;                 // rows of the joint task (Gram path: <= 4)
+	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	const double jg_q = jt.goal[(size_t)rj * ld + b], jg_dq = jt.goal[(size_t)(mj + rj) * ld + b], jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
 
 	STAMP(1);
@@ -709,7 +711,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// of its 4 x 4 Gram matrix (sums over the lanes by DPP), by an unrolled Jacobi solve in registers; matrixRangeBasis keeps the directions
 	// with sigma_i / sigma_0 >= 1e-3 (JointTask.cpp:233); the rest of the task algebra is r x r with dropped directions padded.
 	double tv;
-	if (GJ) {
+	if (GJ == 1) {
 		double cp[4];
 		UNR for (int i = 0; i < 4; i++) {
 			double sc = 0.0;
@@ -842,6 +844,149 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			double gc = 0.0;
 			UNR for (int k = 0; k < 4; k++) gc = fma(Lam4[c][k], a1[k], fma(Lmod4[c][k], b1[k], gc));  // :348-351
 			tj = fma(jh[c], keep[c] ? gc : 0.0, tj);  // tau += Jh^T g
+		}
+		tv = tj;
+	} else if (GJ == 2) {
+		// ------------------------------------------------------------ full joint task (S = I) behind a motion-force task of rank k < 6: Jp = N_1 has
+		// rank 7 - k (2..5).  Column-pivoted Gram-Schmidt over the instance's lanes (lane j owns column j): arg-max of the column norms by
+		// a DPP butterfly carrying the index, the pivot column travels by ds_bpermute, the deflation coefficients are the rows of
+		// Jh = U^T Jp (the same clean-gap rule as the lane kernel; an ambiguous gap is reported as status 1, never silently truncated).
+		const int rmax = N - kmf;  // wave-uniform
+		double Wc[N], jh[5], uown[5];
+		UNR for (int i = 0; i < N; i++) Wc[i] = act ? cj[i] : 0.0;
+		UNR for (int s5 = 0; s5 < 5; s5++) jh[s5] = uown[s5] = 0.0;
+		double c0 = 1.0;
+		bool going = true, bad = false;
+		int rank = 0;
+		UNR for (int s5 = 0; s5 <= 5; s5++) {
+			if (s5 <= rmax) {
+				double cnw = 0.0;
+				UNR for (int i = 0; i < N; i++) cnw = fma(Wc[i], Wc[i], cnw);
+				double bestw = act ? cnw : -1.0;
+				int jbw = r;
+#define OCT_ARGMAX_STEP(CTRL)                                                                                   \
+	{                                                                                                           \
+		const double ob = oct_dpp<CTRL>(bestw);                                                                 \
+		const int oj = __builtin_amdgcn_update_dpp(0, jbw, CTRL, 0xF, 0xF, true);                               \
+		const bool take = ob > bestw || (ob == bestw && oj < jbw);                                              \
+		bestw = take ? ob : bestw;                                                                              \
+		jbw = take ? oj : jbw;                                                                                  \
+	}
+				OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
+				OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
+				OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+#undef OCT_ARGMAX_STEP
+				if (s5 == 0) {
+					const double frob2 = oct_group_sum(act ? cnw : 0.0);
+					c0 = bestw;
+					if (frob2 < 1e-6) going = false;  // ||Jp||_F < 1e-3: empty range
+					else if (bestw < 1e-5) { going = false; bad = true; }
+				} else if (going) {
+					const double ratio = bestw / c0;
+					if (ratio < 1e-20) going = false;                         // numerically exact rank below the bound
+					else if (ratio < 1e-4 || s5 == rmax) { going = false; bad = true; }  // ambiguous gap, or more directions than 7 - k
+				}
+				if (s5 < rmax && s5 < 5) {
+					const int src = (lane & ~7) | jbw;
+					const double inv = going ? oct_rsqrt(bestw) : 0.0;
+					double u[N], dd = 0.0;
+					UNR for (int i = 0; i < N; i++) {
+						u[i] = __shfl(Wc[i], src) * inv;
+						dd = fma(u[i], Wc[i], dd);
+					}
+					UNR for (int i = 0; i < N; i++) Wc[i] = fma(-u[i], dd, Wc[i]);
+					double uo = 0.0;
+					UNR for (int i = 0; i < N; i++) uo = (i == rr) ? u[i] : uo;
+					jh[s5 < 5 ? s5 : 0] = act ? dd : 0.0;
+					uown[s5 < 5 ? s5 : 0] = act ? uo : 0.0;
+					if (going) rank = s5 + 1;
+				}
+			}
+		}
+		if (bad) singular = true;
+		// Lambda = (Jh M^-1 Jh^T)^-1 (rank x rank, padded to 5): gather Jh, own column of T1, sums over the lanes
+		double tauv[N];
+		UNR for (int j = 0; j < N; j++) tauv[j] = sm.vec[1][j];
+		UNR for (int c = 0; c < 5; c++) sm.T1[c][r] = jh[c];
+		__syncthreads();
+		double Jh[5][N];
+		UNR for (int c = 0; c < 5; c++)
+			UNR for (int j = 0; j < N; j++) Jh[c][j] = sm.T1[c][j];
+		double t1v[5], wr = 0.0, A5[5][5], Lam5[5][5], Lmod5[5][5];
+		UNR for (int l = 0; l < N; l++) wr = fma(mi[l], tauv[l], wr);  // (M^-1 tau_prec)_rr
+		UNR for (int c = 0; c < 5; c++) {
+			double st = 0.0;
+			UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mi[l], st);
+			t1v[c] = act ? st : 0.0;
+		}
+		UNR for (int c = 0; c < 5; c++)
+			UNR for (int k5 = 0; k5 <= c; k5++) {
+				const double gs = oct_group_sum(t1v[c] * jh[k5]);
+				A5[c][k5] = (c == k5 && c >= rank) ? 1.0 : gs;
+			}
+		oct_spd_inverse_n<5>(A5, Lam5);
+		if (jt.decoupling == DEC_FULL) {
+			UNR for (int c = 0; c < 5; c++)
+				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = Lam5[c][k5];
+		} else if (jt.decoupling == DEC_IMPEDANCE) {
+			UNR for (int c = 0; c < 5; c++)
+				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = (c == k5) ? 1.0 : 0.0;
+		} else if (general_bie) {
+			double tbv[5];
+			UNR for (int c = 0; c < 5; c++) {
+				double st = 0.0;
+				UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mb[l], st);
+				tbv[c] = act ? st : 0.0;
+			}
+			UNR for (int c = 0; c < 5; c++)
+				UNR for (int k5 = 0; k5 <= c; k5++) {
+					const double gs = oct_group_sum(tbv[c] * jh[k5]);
+					A5[c][k5] = (c == k5 && c >= rank) ? 1.0 : gs;
+				}
+			oct_spd_inverse_n<5>(A5, Lmod5);
+		} else {
+			double t[5], lt[5], qq = 0.0;
+			UNR for (int c = 0; c < 5; c++) {
+				double st = 0.0;
+				UNR for (int l = 0; l < N; l++) st = fma(Jh[c][l], mcol[l], st);
+				t[c] = st;
+			}
+			UNR for (int c = 0; c < 5; c++) {
+				double sl = 0.0;
+				UNR for (int k5 = 0; k5 < 5; k5++) sl = fma(Lam5[c][k5], t[k5], sl);
+				lt[c] = sl;
+				qq = fma(t[c], sl, qq);
+			}
+			const double gamma = beta * oct_rcp(fma(-beta, qq, 1.0));
+			UNR for (int c = 0; c < 5; c++)
+				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = fma(gamma * lt[c], lt[k5], Lam5[c][k5]);
+		}
+		// control law of this lane's joint (JointTask.cpp:285-356), its range coordinates by sums over the lanes
+		const bool track = (jt.has_ki || P.integ_always);
+		const double e = q_r - jg_q;
+		double ie = 0.0;
+		if (track) ie = jt.integ[(size_t)rr * ld + b];
+		ie += e * jt.dt;
+		if (track && live && !singular && act) jt.integ[(size_t)r * ld + b] = ie;
+		double fi;
+		if (jt.vel_sat) {
+			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
+			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
+			fi = -jt.kv[rr] * (dq_r - vdes);
+		} else {
+			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;
+		}
+		const double ai = jg_ddq - wr;
+		double a1[5], b1[5];
+		UNR for (int c = 0; c < 5; c++) {
+			a1[c] = oct_group_sum(uown[c] * ai);
+			b1[c] = oct_group_sum(uown[c] * fi);
+		}
+		double tj = tau_r;
+		UNR for (int c = 0; c < 5; c++) {
+			double gc = 0.0;
+			UNR for (int k5 = 0; k5 < 5; k5++) gc = fma(Lam5[c][k5], a1[k5], fma(Lmod5[c][k5], b1[k5], gc));
+			tj = fma(jh[c], (c < rank) ? gc : 0.0, tj);
 		}
 		tv = tj;
 	} else {
@@ -1033,9 +1178,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
-	if (P.oct_general_joint) hipLaunchKernelGGL((saip_cycle_oct<true, true>), grid, block, 0, stream, P);
-	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, false>), grid, block, 0, stream, P);
-	else hipLaunchKernelGGL((saip_cycle_oct<false, false>), grid, block, 0, stream, P);
+	if (P.oct_general_joint == 1) hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
+	else if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
+	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
+	else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
 	return hipGetLastError();
 }
 
