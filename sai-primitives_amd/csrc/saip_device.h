@@ -116,6 +116,7 @@ struct CycleParams {
 	int reinit_task, reinit_mask; // reinit kernel: task (-1 = all) and parts (1 linear/joint, 2 angular, 4 goal force+moment)
 	int any_bie;
 	int oct_partial_mf;           // eight-lane kernel: the motion-force task is partial (k < 6)
+	int oct_truncate;             // eight-lane kernel: singularity handling disabled -> near-singular instances are reduced in the kernel
 	double bie_thr;
 };
 

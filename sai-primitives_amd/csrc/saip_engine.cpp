@@ -1238,6 +1238,7 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.lane_general = 0;
 	P.oct_general_joint = 0;
 	P.oct_partial_mf = 0;
+	P.oct_truncate = 0;
 	for (auto& T : b->tasks)
 		if (T.dev.general_law) P.lane_general = 1;
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
@@ -1288,6 +1289,10 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 	if (!(full_mf && full_jt) && !full_behind_partial && jt.m > 4) return false;
 	if (!lane_eligible(b)) return false;
 	P.oct_general_joint = (full_mf && full_jt) ? 0 : (full_behind_partial ? 2 : 1);
+	if (full_mf && full_jt && !mf.sing_handling && !mf.general_law) {  // disableSingularityHandling(): reduced tasks need the multi-pivot joint-task path
+		P.oct_general_joint = 2;
+		P.oct_truncate = 1;
+	}
 	P.oct_partial_mf = full_mf ? 0 : 1;
 	return true;
 }

@@ -99,20 +99,21 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 	}
 }
 
-// eigen-decomposition of a symmetric 4 x 4 matrix in registers: cyclic Jacobi, wave-uniform convergence test per sweep (rotations of
+// eigen-decomposition of a symmetric R x R matrix in registers: cyclic Jacobi, wave-uniform convergence test per sweep (rotations of
 // an already diagonal matrix degenerate to the identity); eigenvalues on the diagonal of A, eigenvectors in the columns of V
-__device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]) {
-	UNR for (int i = 0; i < 4; i++)
-		UNR for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 10; sweep++) {
+template <int R>
+__device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R]) {
+	UNR for (int i = 0; i < R; i++)
+		UNR for (int j = 0; j < R; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 12; sweep++) {
 		double off = 0.0, dg = 0.0;
-		UNR for (int p = 0; p < 4; p++) {
+		UNR for (int p = 0; p < R; p++) {
 			dg = fma(A[p][p], A[p][p], dg);
-			UNR for (int q = p + 1; q < 4; q++) off = fma(A[p][q], A[p][q], off);
+			UNR for (int q = p + 1; q < R; q++) off = fma(A[p][q], A[p][q], off);
 		}
 		if (!__any(off > 1e-32 * dg)) break;  // every instance of the wavefront has converged (quadratic convergence: 3 - 5 sweeps)
-		UNR for (int p = 0; p < 3; p++)
-			UNR for (int q = p + 1; q < 4; q++) {
+		UNR for (int p = 0; p < R - 1; p++)
+			UNR for (int q = p + 1; q < R; q++) {
 				// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
 				// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
 				const double apq = A[p][q], d = A[q][q] - A[p][p], b2 = 2.0 * apq;
@@ -122,7 +123,7 @@ __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]
 				const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
 				const double t = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
 				const double c = oct_rsqrt(fma(t, t, 1.0)), sn = t * c;
-				UNR for (int k = 0; k < 4; k++) {
+				UNR for (int k = 0; k < R; k++) {
 					if (k != p && k != q) {
 						const double akp = A[k][p], akq = A[k][q];
 						const double np_ = c * akp - sn * akq, nq_ = sn * akp + c * akq;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]
 				A[q][q] = fma(t, apq, A[q][q]);
 				A[p][q] = 0.0;
 				A[q][p] = 0.0;
-				UNR for (int k = 0; k < 4; k++) {
+				UNR for (int k = 0; k < R; k++) {
 					const double vkp = V[k][p], vkq = V[k][q];
 					V[k][p] = c * vkp - sn * vkq;
 					V[k][q] = sn * vkp + c * vkq;
@@ -144,6 +145,7 @@ __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]
 			}
 	}
 }
+__device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]) { oct_jacobi_n<4>(A, V); }
 // inverse of an SPD R x R matrix given by its lower triangle
 template <int R>
 __device__ __forceinline__ void oct_spd_inverse_n(const double (&A)[R][R], double (&Ainv)[R][R]) {
@@ -406,9 +408,12 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	STAMP(5);
 	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
-	bool singular = false;
+	bool singular = false, truncated = false;
+	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
+	double G[6][6], U6[6][6];
+	bool keepm[6] = {true, true, true, true, true, true};
 	{
-		double G[6][6], tr = 0.0;
+		double tr = 0.0;
 		UNR for (int a = 0; a < 6; a++)
 			UNR for (int c = 0; c <= a; c++) {
 				double s = 0.0;
@@ -514,12 +519,57 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 	}
+	if (trunc_mode) {
+		UNR for (int i = 0; i < 6; i++)
+			UNR for (int j = 0; j < 6; j++) U6[i][j] = (i == j) ? 1.0 : 0.0;
+	}
+	if (trunc_mode && __any(singular)) {
+		// disableSingularityHandling(): _N = _N_ns and tau = tau_ns (SingularityHandler.cpp:146-148, 319-330): the task acts on the left singular
+		// directions with sigma_i / sigma_0 >= s_max (the count of those = the first index below s_max of the sorted spectrum, :100-121).
+		// Eigen-pairs of G = J J^T by the register Jacobi solve, in every lane of the wavefront (it only runs when some instance needs it).
+		double E[6][6], Ue[6][6];
+		UNR for (int i = 0; i < 6; i++)
+			UNR for (int j = 0; j < 6; j++) E[i][j] = G[i][j];
+		oct_jacobi_n<6>(E, Ue);
+		double lmax = 0.0;
+		UNR for (int c = 0; c < 6; c++) lmax = fmax(lmax, E[c][c]);
+		const double s0 = sqrt(lmax);
+		int ns = 0;
+		bool kp[6];
+		UNR for (int c = 0; c < 6; c++) {
+			kp[c] = (s0 >= mf.s_abs_tol) && (sqrt(fmax(E[c][c], 0.0)) / s0 >= mf.s_max);
+			ns += kp[c] ? 1 : 0;
+		}
+		const bool reduce = singular && ns >= 2 && ns < 6;  // fewer than two directions left (or a fully singular task): stays flagged, the general kernel behind handles it
+		if (reduce) {
+			singular = false;
+			truncated = true;
+			UNR for (int c = 0; c < 6; c++) keepm[c] = kp[c];
+			UNR for (int i = 0; i < 6; i++)
+				UNR for (int j = 0; j < 6; j++) U6[i][j] = Ue[i][j];
+		}
+		// rows of the reduced Jacobian: J_ns = U_ns^T J, dropped directions zero (their diagonals are padded below)
+		double jc6[6], jn[6];
+		UNR for (int i = 0; i < 6; i++) jc6[i] = sm.J[i][rr];
+		UNR for (int a = 0; a < 6; a++) {
+			double sj = 0.0;
+			UNR for (int i = 0; i < 6; i++) sj = fma(U6[i][a], jc6[i], sj);
+			jn[a] = keepm[a] ? sj : 0.0;
+		}
+		__syncthreads();
+		UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jn[a];
+		__syncthreads();
+		UNR for (int a = 0; a < 6; a++)
+			UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
+	}
+	bool keep_ra = true;  // is this lane's row of the task kept (partial task: rows >= k are not; reduced task: the dropped directions)
 	STAMP(7);
 	// ---- operationalSpaceMatrices(J): this lane's COLUMN of T1 = J M^-1 (M^-1 symmetric: its column rr is the row this lane solved for),
 	// then its ROW of A = T1 J^T; the same with M_BIE^-1
 	double mcol[N], beta = 0.0;
 	UNR for (int j = 0; j < N; j++) mcol[j] = 0.0;
 	const int ra = r < 6 ? r : 5;
+	UNR for (int a = 0; a < 6; a++) keep_ra = (a == ra) ? (keepm[a] && a < kmf) : keep_ra;
 	double t1c[6];
 	{
 		double tbc[6];
@@ -556,7 +606,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				s = fma(t1[j], Jf[c][j], s);
 				if (general_bie) s2 = fma(tb[j], Jf[c][j], s2);
 			}
-			const bool padrow = FULL && ra >= kmf && c == ra;  // zero row of a partial task: keep the factorisation regular
+			const bool padrow = FULL && !keep_ra && c == ra;  // zero row of a partial / reduced task: keep the factorisation regular
 			sm.A[r][c] = padrow ? 1.0 : s;
 			if (general_bie) sm.Am[r][c] = padrow ? 1.0 : s2;
 		}
@@ -669,6 +719,15 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				mf.integ[(size_t)i * ld + b] = ip[i];
 				mf.integ[(size_t)(3 + i) * ld + b] = io[i];
 			}
+		}
+		if (trunc_mode) {  // task_range_ns^T F_um (SingularityHandler.cpp:321-322); the identity for instances that were not reduced
+			double fh[6];
+			UNR for (int a = 0; a < 6; a++) {
+				double sf = 0.0;
+				UNR for (int i = 0; i < 6; i++) sf = fma(U6[i][a], Fum[i], sf);
+				fh[a] = keepm[a] ? sf : 0.0;
+			}
+			UNR for (int a = 0; a < 6; a++) Fum[a] = fh[a];
 		}
 		// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
 		double s = Ffa;
@@ -851,7 +910,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		// rank 7 - k (2..5).  Column-pivoted Gram-Schmidt over the instance's lanes (lane j owns column j): arg-max of the column norms by
 		// a DPP butterfly carrying the index, the pivot column travels by ds_bpermute, the deflation coefficients are the rows of
 		// Jh = U^T Jp (the same clean-gap rule as the lane kernel; an ambiguous gap is reported as status 1, never silently truncated).
-		const int rmax = N - kmf;  // wave-uniform
+		const int rmax = trunc_mode ? 5 : N - kmf;  // wave-uniform bound; a reduced task leaves rank 7 - ns <= 5, found by the clean-gap rule
 		double Wc[N], jh[5], uown[5];
 		UNR for (int i = 0; i < N; i++) Wc[i] = act ? cj[i] : 0.0;
 		UNR for (int s5 = 0; s5 < 5; s5++) jh[s5] = uown[s5] = 0.0;
@@ -1172,7 +1231,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	if (singular) tv = __builtin_nan("");
 	if (live && act) P.tau[(size_t)r * ld + b] = tv;
-	if (live && r == 0) P.status[b] = singular ? 1 : 0;
+	if (live && r == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
 	STAMP(15);
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	const int tid = threadIdx.x;
 	const int b = blockIdx.x;
 	if (b >= P.B) return;
-	if (P.only_flagged && P.status[b] == 0) {  // slow-path launch behind the lane kernel (workgroup-uniform)
+	if (P.only_flagged && (P.status[b] & 1) == 0) {  // slow-path launch behind the lane / eight-lane kernel (workgroup-uniform); bit 1 = reduced there already
 		// the lane kernel found every task of this instance non-singular: SingularityHandler.cpp:238-244 for the handler states
 		if (tid < P.nt && P.tasks[tid].type == TASK_MOTION_FORCE && P.tasks[tid].sing_strategies && P.tasks[tid].sh) {
 			ShState& st = P.tasks[tid].sh[b];
