@@ -7,10 +7,12 @@
 // are done redundantly (a Cholesky factor per lane, then each lane solves for its own column of the inverse).  4096 instances
 // become 512 wavefronts of 2 500 instructions each.  One wavefront per workgroup: __syncthreads() is a wave-local ordering point.
 //
-// Covers the stack of BASELINE config 2 (and 9 - 14): { full 6-dof MotionForceTask, full JointTask } on a 7-dof chain, default or
-// general control laws (no closed-loop force control), joint limit avoidance, gravity compensation, torque saturation; everything
-// else stays on saip_cycle_lane / saip_cycle_wg (engine: oct_eligible).  Instances outside the non-singular branch are flagged and,
-// where a task can handle them (truncated task, blended strategies), recomputed by the general kernel launched behind.
+// Covers { MotionForceTask, JointTask } stacks on a 7-dof chain (engine: oct_eligible): the headline stack of BASELINE config 2 (full
+// 6-dof task + full joint task; <false, 0> is its lean instantiation), partial motion-force tasks with a joint task of <= 4 rows
+// (config 3, GJ = 1) or a full joint task (GJ = 2), default or general control laws (no closed-loop force control), joint limit
+// avoidance, gravity compensation, torque saturation, and disableSingularityHandling() (near-singular instances reduced in the
+// kernel).  Instances outside the non-singular branch are otherwise flagged and, with the blended strategies on, recomputed by the
+// general kernel launched behind.
 //   SaiModel::updateModel()                       -> prefix-product kinematics, composite inertias, M, M^-1, M_BIE^-1
 //   RobotController::updateControllerTaskModels() -> /root/reference/src/RobotController.cpp:68-77, tasks/MotionForceTask.cpp:247-268,
 //       tasks/SingularityHandler.cpp:75-228 (non-singular branch; others flagged -> slow path), tasks/JointTask.cpp:218-283
