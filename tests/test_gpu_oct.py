@@ -300,3 +300,40 @@ def test_oct_partial_stacks(cfg, B):
         print("oct partial cfg", cfg, "B", B, "cycle", c, "err", err, "flagged", int((~ok).sum()))
         assert err < TOL
         q = q + 1e-3 * rng.standard_normal(q.shape)
+
+
+@pytest.mark.parametrize("cfg", [3, 7, 12])
+def test_oct_general_paths_with_every_controller_option(cfg):
+    """the general joint-task paths (Gram path: 3; multi-pivot path: 7; reduced task: 12) together with joint limit avoidance, gravity
+    compensation, torque saturation and integrators, states pushed towards the joint limits, four cycles"""
+    from oracle import Oracle
+    B = 768
+    d = W.make_inputs(cfg, B)
+    d11 = W.make_inputs(11, B)          # states inside the limit zones
+    spec = W.config_tasks(cfg)
+    for t in spec:
+        if t["type"] == "motion_force":
+            t.update(ki_pos=4.0, ki_ori=6.0)
+        else:
+            t.update(ki=3.0)
+    opts = dict(joint_limit_avoidance=True, gravity_comp=True, torque_saturation=True)
+    orc = Oracle(d["model"], spec, **opts)
+    robot, ctrl, _ = _engine(d["model"].name, spec, B)
+    ctrl.setKernel(OCT)
+    ctrl.enableJointLimitAvoidance(True)
+    ctrl.enableGravityCompensation(True)
+    ctrl.enableTorqueSaturation(True)
+    q = np.where((np.arange(B) % 2 == 0)[:, None], d["q"], d11["q"])
+    dq = np.where((np.arange(B) % 2 == 0)[:, None], d["dq"], d11["dq"])
+    rng = np.random.default_rng(cfg)
+    worst = 0.0
+    for c in range(4):
+        tau = _cycle(robot, ctrl, q, dq, d["goals"])
+        assert ctrl.kernelName() == "saip_cycle_oct"
+        ref, st = orc.step(q, dq, d["goals"], nthreads=8)
+        assert np.array_equal(ctrl.status, st)
+        ok = (st & 1) == 0
+        worst = max(worst, W.torque_error(tau[ok], ref[ok]))
+        q = q + 1e-3 * rng.standard_normal(q.shape)
+    print("oct general paths + options, cfg", cfg, "worst err", worst, "last statuses", np.unique(st, return_counts=True))
+    assert worst < TOL
