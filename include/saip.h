@@ -278,9 +278,44 @@ saip_status saip_batch_compute_control_torques(saip_batch*, double* tau_host /*[
 saip_status saip_batch_step_async(saip_batch*);
 saip_status saip_batch_synchronize(saip_batch*);
 saip_status saip_batch_get_torques_host(saip_batch*, double* tau_host, uint8_t* status_host);
-/* per-task diagnostics of the last cycle, for parity tests of the task models: TemplateTask::getTaskNullspace()
- * ([dof*dof][B] row-major per instance). Re-runs the cycle with the diagnostic kernel variant. */
+/* per-task diagnostics of the hierarchy, for parity tests of the task models: TemplateTask::getTaskNullspace()
+ * ([dof*dof][B] row-major per instance).  Re-evaluates the task models with the general kernel (no control law; torques, status,
+ * integrators, OTG and handler state of the last cycle stay untouched). */
 saip_status saip_batch_get_task_nullspace_host(saip_batch*, int task, double* N /*[dof*dof][B]*/);
+
+/* ---- the reference's per-task plug-in interface, TemplateTask.h:43-60 (pure virtuals of every task):
+ *        virtual void updateTaskModel(const Eigen::MatrixXd& N_prec);
+ *        virtual Eigen::VectorXd computeTorques();
+ *        virtual Eigen::VectorXd computeTorques(const Eigen::VectorXd& tau_prec);
+ *        getTaskNullspace() / getPreviousTasksNullspace() / getTaskAndPreviousNullspace()   (:71-89)
+ * A caller that builds its own hierarchy drives the tasks by hand (examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206):
+ *        N_prec = I;  mf->updateTaskModel(N_prec);  N_prec = mf->getTaskAndPreviousNullspace();  jt->updateTaskModel(N_prec);
+ *        tau = mf->computeTorques() + jt->computeTorques();
+ * Nullspace matrices are [dof*dof][B] (host) / [dof*dof][ld] (device), row-major per instance.  The task keeps its own copy of N_prec
+ * (MotionForceTask.cpp:259-267 / JointTask.cpp:230).  One launch of the general kernel per call, restricted to the task:
+ * update_model evaluates the model for the current state (nullspaces out; SingularityHandler's classification state advances here like in
+ * SingularityHandler::updateTaskModel, .cpp:227), compute_torques evaluates the control law (integrators, internal OTG, the type-2
+ * direction memory advance here like in the reference's computeTorques) and returns THIS task's torques, without any of
+ * RobotController's post-processing.  tau_prec = NULL is computeTorques(); otherwise the joint task subtracts its disturbance
+ * compensation (JointTask.cpp:285-292) and the motion-force task adds nothing (its _Lambda is never written, MotionForceTask.cpp:140,273).
+ * compute_torques after a state change without a new update_model is SAIP_ERR_ORDER (the reference would mix a fresh Jacobian with
+ * stale Lambda / N_prec, MotionForceTask.cpp:280-283).  status: per-instance codes as for the whole cycle (torques NaN where 1). */
+saip_status saip_batch_task_update_model(saip_batch*, int task, const double* N_prec_host /* NULL = identity */);
+saip_status saip_batch_task_update_model_device(saip_batch*, int task, const double* N_prec_dev /* NULL = identity; asynchronous */);
+saip_status saip_batch_task_compute_torques(saip_batch*, int task, const double* tau_prec_host /*[dof][B] or NULL*/, double* tau_host /*[dof][B]*/, uint8_t* status_host /*[B] or NULL*/);
+/* asynchronous flavour on the engine stream: tau_prec_dev [dof][ld] or NULL, tau_dev [dof][ld] or NULL (= the task's own buffer, saip_batch_task_device_torques) */
+saip_status saip_batch_task_compute_torques_device(saip_batch*, int task, const double* tau_prec_dev, double* tau_dev);
+/* getTaskNullspace (N), getPreviousTasksNullspace (N_prec), getTaskAndPreviousNullspace (N N_prec) of the last update_model; any pointer may be NULL */
+saip_status saip_batch_task_get_nullspaces_host(saip_batch*, int task, double* N, double* N_prec, double* N_total);
+/* the same on the device: which = 0 N, 1 N_prec (NULL when the identity was used), 2 N N_prec; NULL before the first update_model */
+const double* saip_batch_task_device_nullspace(saip_batch*, int task, int which);
+double* saip_batch_task_device_torques(saip_batch*, int task);
+/* robot->setQ/setDq from arrays already on the device ([dof][ld], e.g. the state of another batch of the same robots): asynchronous D2D copy */
+saip_status saip_batch_set_state_device(saip_batch*, const double* q_dev, const double* dq_dev);
+/* device-side ordering between two batches' streams (no host synchronisation): everything enqueued so far on `producer` happens before
+ * what is enqueued on `waiter` from now on.  Needed when one batch consumes device arrays another batch has just written (tasks driven
+ * by hand that live in batches of their own). */
+saip_status saip_batch_wait_for(saip_batch* waiter, saip_batch* producer);
 
 /* kernel selection: 0 = auto, 1 = general workgroup-per-instance kernel, 2 = lane-per-instance register kernel (dof <= 8),
  * 3 = eight-lanes-per-instance kernel (7-dof chain, full MotionForceTask + full JointTask; the auto choice for batches <= 8192) */

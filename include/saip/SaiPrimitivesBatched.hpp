@@ -10,6 +10,8 @@
 //   controller->updateControllerTaskModels();                       controller->updateControllerTaskModels();
 //   task->setGoalPosition(x) ...                                    task->setGoalPosition(x) ...                               x: [3][B]
 //   tau = controller->computeControlTorques();                      tau = controller->computeControlTorques();                  tau: [dof][B]
+//   task->updateTaskModel(N_prec); task->computeTorques()           the same (TemplateTask.h:43-60; examples/04-task_and_redundancy):      N_prec: [dof*dof][B]
+//   N_prec = task->getTaskAndPreviousNullspace()                    a task driven by hand without a RobotController owns a private one-task batch
 //
 // Reference interface: /root/reference/src/RobotController.h:47-90, src/tasks/TemplateTask.h:26-124,
 // src/tasks/MotionForceTask.h:96-110,211-300,423,670-736, src/tasks/JointTask.h:56-75,140-175,237-257,323,363.
@@ -42,6 +44,13 @@ inline void check(saip_status st) {
 }
 
 class RobotController;
+class TemplateTask;
+
+// a [dof*dof][ld] nullspace matrix resident on the GPU: what getTaskAndPreviousNullspaceDevice() returns and updateTaskModel accepts
+struct DeviceNullspace {
+	saip_batch* batch = nullptr;
+	const double* ptr = nullptr;
+};
 
 // B instances of one robot: constants + host-side q/dq staging (the kinematics/dynamics run inside the GPU cycle)
 class SaiModel {
@@ -70,16 +79,42 @@ public:
 		_dq = dq;
 		_version++;
 	}
-	void updateModel();  // pushes the state to the device (defined after RobotController)
+	// pushes the state to every batch that mirrors this robot (the RobotController's and the private batches of tasks driven by hand)
+	void updateModel() {
+		for (auto& a : _attached) push(a);
+	}
 	const saip_model* handle() const { return _model; }
 
 private:
 	friend class RobotController;
+	friend class TemplateTask;
+	struct Attached {
+		saip_batch* batch;
+		long pushed;
+	};
+	void attach(saip_batch* b) { _attached.push_back({b, -1}); }
+	void detach(saip_batch* b) {
+		for (size_t i = 0; i < _attached.size(); i++)
+			if (_attached[i].batch == b) {
+				_attached.erase(_attached.begin() + i);
+				return;
+			}
+	}
+	void push(Attached& a) {
+		if (a.pushed != _version) {
+			check(saip_batch_set_state_host(a.batch, _q.data(), _dq.data()));
+			a.pushed = _version;
+		}
+	}
+	void pushTo(saip_batch* b) {
+		for (auto& a : _attached)
+			if (a.batch == b) push(a);
+	}
 	saip_model* _model = nullptr;
 	int _batch, _device;
 	std::vector<double> _q, _dq;
 	long _version = 0;
-	RobotController* _controller = nullptr;
+	std::vector<Attached> _attached;
 };
 
 // TemplateTask.h:26-124
@@ -87,7 +122,9 @@ class TemplateTask {
 public:
 	TemplateTask(std::shared_ptr<SaiModel>& robot, const std::string& task_name, TaskType type, double loop_timestep)
 		: _robot(robot), _task_name(task_name), _task_type(type), _loop_timestep(loop_timestep) {}
-	virtual ~TemplateTask() = default;
+	virtual ~TemplateTask() { dropPrivateBatch(); }
+	TemplateTask(const TemplateTask&) = delete;
+	TemplateTask& operator=(const TemplateTask&) = delete;
 	const std::shared_ptr<SaiModel>& getConstRobotModel() const { return _robot; }
 	const double& getLoopTimestep() const { return _loop_timestep; }
 	const TaskType& getTaskType() const { return _task_type; }
@@ -99,10 +136,46 @@ public:
 		cfg([=](saip_batch* b, int id) { return saip_batch_set_bie_threshold(b, id, thr); });
 	}
 	double getBoundedInertiaEstimateThreshold() const { return _bie_threshold; }
-	// TemplateTask::reInitializeTask of this task alone; the per-task updateTaskModel / computeTorques of the reference do not exist here:
-	// the hierarchy is evaluated as a whole by RobotController::updateControllerTaskModels / computeControlTorques
+	// ---- the reference's per-task interface, TemplateTask.h:43-60, driven by hand in examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206
+	// N_prec: [dof*dof][B] (row-major per instance) or dof*dof values shared by every instance
+	void updateTaskModel(const std::vector<double>& N_prec) {
+		need();
+		const size_t n = _robot->dof(), B = _robot->batchSize();
+		if (N_prec.size() == n * n) {
+			std::vector<double> all(n * n * B);
+			for (size_t e = 0; e < n * n; e++)
+				for (size_t b = 0; b < B; b++) all[e * B + b] = N_prec[e];
+			pushAndUpdate(all.data());
+		} else if (N_prec.size() == n * n * B) {
+			pushAndUpdate(N_prec.data());
+		} else {
+			throw std::invalid_argument("N_prec matrix size not consistent with robot dof in updateTaskModel\n");  // JointTask.cpp:224-229
+		}
+	}
+	// N_prec stays on the GPU: the handle another task's getTaskAndPreviousNullspaceDevice() returned
+	void updateTaskModel(const DeviceNullspace& N_prec) {
+		need();
+		_robot->pushTo(_batch);
+		if (N_prec.batch && N_prec.batch != _batch) check(saip_batch_wait_for(_batch, N_prec.batch));
+		check(saip_batch_task_update_model_device(_batch, _id, N_prec.ptr));
+		_manual = true;
+	}
+	// [dof][B] torques of THIS task (no RobotController post-processing); per-instance status in status()
+	std::vector<double> computeTorques() { return torques(nullptr); }
+	// ... with the feed-forward compensation of the torques of the previous tasks (JointTask.cpp:285-292)
+	std::vector<double> computeTorques(const std::vector<double>& tau_prec) {
+		if (tau_prec.size() != (size_t)_robot->dof() * _robot->batchSize()) throw std::invalid_argument("tau_prec: expected [dof][B]");
+		return torques(tau_prec.data());
+	}
+	const std::vector<uint8_t>& status() const { return _status; }
+	DeviceNullspace getTaskAndPreviousNullspaceDevice() {
+		if (!_manual) throw std::runtime_error("getTaskAndPreviousNullspaceDevice: call updateTaskModel first");
+		return DeviceNullspace{_batch, saip_batch_task_device_nullspace(_batch, _id, 2)};
+	}
+	// TemplateTask::reInitializeTask of this task alone
 	void reInitializeTask() {
 		need();
+		_robot->pushTo(_batch);
 		check(saip_batch_reinitialize_task(_batch, _id));
 	}
 	// resetIntegrators (both tasks), resetIntegratorsLinear / Angular (MotionForceTask.cpp:988-1002)
@@ -137,7 +210,8 @@ public:
 		need();
 		const int n = _robot->dof();
 		std::vector<double> N((size_t)n * n * _robot->batchSize());
-		check(saip_batch_get_task_nullspace_host(_batch, _id, N.data()));
+		if (_manual) check(saip_batch_task_get_nullspaces_host(_batch, _id, N.data(), nullptr, nullptr));
+		else check(saip_batch_get_task_nullspace_host(_batch, _id, N.data()));
 		return N;
 	}
 	// N_prec this task was updated with = N_{t-1} ... N_0 of the tasks above it (identity for the first), TemplateTask.h:79-83; same layout
@@ -146,6 +220,10 @@ public:
 		const int n = _robot->dof();
 		const size_t B = _robot->batchSize();
 		std::vector<double> Np((size_t)n * n * B, 0.0), Ns(Np.size()), T(Np.size());
+		if (_manual) {
+			check(saip_batch_task_get_nullspaces_host(_batch, _id, nullptr, Np.data(), nullptr));
+			return Np;
+		}
 		for (int i = 0; i < n; i++)
 			for (size_t b = 0; b < B; b++) Np[((size_t)i * n + i) * B + b] = 1.0;
 		for (int s = 0; s < _id; s++) {
@@ -159,6 +237,11 @@ public:
 	std::vector<double> getTaskAndPreviousNullspace() {
 		const int n = _robot->dof();
 		const size_t B = _robot->batchSize();
+		if (_manual) {
+			std::vector<double> Nt((size_t)n * n * B);
+			check(saip_batch_task_get_nullspaces_host(_batch, _id, nullptr, nullptr, Nt.data()));
+			return Nt;
+		}
 		std::vector<double> N = getTaskNullspace(), Np = getPreviousTasksNullspace(), T(N.size());
 		matmulBatched(N, Np, T, n, B);
 		return T;
@@ -177,11 +260,48 @@ protected:
 	}
 	template <typename F>
 	void cfg(F f) {
+		_log.emplace_back(f);  // replayed into whichever batch the task joins later
 		if (_batch) check(f(_batch, _id));
-		else _pending.emplace_back(f);
 	}
-	void need() const {
-		if (!_batch) throw std::runtime_error("task [" + _task_name + "] is not part of a RobotController yet");
+	// the batch this task is evaluated in: its RobotController's, or -- for a task driven by hand like in the reference's example 04 --
+	// a private one-task batch created on first use
+	void need() {
+		if (_batch) return;
+		saip_batch* b = nullptr;
+		check(saip_batch_create(_robot->handle(), _robot->batchSize(), _robot->device(), &b));
+		try {
+			check(add(b, &_id));
+			check(saip_batch_finalize(b));
+			for (auto& f : _log) check(f(b, _id));
+		} catch (...) {
+			saip_batch_destroy(b);
+			throw;
+		}
+		_batch = b;
+		_private = true;
+		_robot->attach(b);
+	}
+	void dropPrivateBatch() {
+		if (_private && _batch) {
+			_robot->detach(_batch);
+			saip_batch_destroy(_batch);
+		}
+		_private = false;
+		_batch = nullptr;
+	}
+	void pushState() { _robot->pushTo(_batch); }
+	void pushAndUpdate(const double* N_prec) {
+		_robot->pushTo(_batch);
+		check(saip_batch_task_update_model(_batch, _id, N_prec));
+		_manual = true;
+	}
+	std::vector<double> torques(const double* tau_prec) {
+		need();
+		if (!_manual) throw std::runtime_error("task [" + _task_name + "]: call updateTaskModel(N_prec) before computeTorques()");
+		std::vector<double> tau((size_t)_robot->dof() * _robot->batchSize());
+		_status.assign(_robot->batchSize(), 0);
+		check(saip_batch_task_compute_torques(_batch, _id, tau_prec, tau.data(), _status.data()));
+		return tau;
 	}
 	void setField(int first, int comps, const std::vector<double>& v, const char* what) {
 		need();
@@ -198,7 +318,10 @@ protected:
 	double _bie_threshold = 0.1;
 	saip_batch* _batch = nullptr;
 	int _id = -1;
-	std::vector<std::function<saip_status(saip_batch*, int)>> _pending;
+	bool _private = false;  // _batch is this task's own one-task batch (no RobotController)
+	bool _manual = false;   // model last updated through updateTaskModel(N_prec)
+	std::vector<uint8_t> _status;
+	std::vector<std::function<saip_status(saip_batch*, int)>> _log;
 };
 
 class MotionForceTask : public TemplateTask {
@@ -283,12 +406,14 @@ public:
 	std::vector<double> getCurrentPosition() {
 		need();
 		std::vector<double> p((size_t)3 * _robot->batchSize());
+		pushState();
 		check(saip_batch_get_current_pose_host(_batch, _id, p.data(), nullptr));
 		return p;
 	}
 	std::vector<double> getCurrentOrientation() {
 		need();
 		std::vector<double> r((size_t)9 * _robot->batchSize());
+		pushState();
 		check(saip_batch_get_current_pose_host(_batch, _id, nullptr, r.data()));
 		return r;
 	}
@@ -382,25 +507,43 @@ public:
 		if (tasks.empty()) throw std::invalid_argument("RobotController must have at least one task");
 		for (auto& t : tasks)
 			if (t->getConstRobotModel() != robot) throw std::invalid_argument("All tasks must have the same robot model in RobotController");
+		for (auto& t : tasks)
+			if (t->_batch && !t->_private) throw std::invalid_argument("task [" + t->getTaskName() + "] already belongs to a RobotController");
 		check(saip_batch_create(robot->handle(), robot->batchSize(), robot->device(), &_batch));
+		std::vector<int> ids(tasks.size(), -1);
 		try {
-			for (auto& t : tasks) check(t->add(_batch, &t->_id));
+			for (size_t i = 0; i < tasks.size(); i++) check(tasks[i]->add(_batch, &ids[i]));
 			check(saip_batch_finalize(_batch));
 		} catch (...) {
 			saip_batch_destroy(_batch);
 			_batch = nullptr;
 			throw;
 		}
-		for (auto& t : tasks) {
+		for (size_t i = 0; i < tasks.size(); i++) {
+			auto& t = tasks[i];
+			// a task that was driven by hand before moves here: configuration replayed, goal kept, integrators start afresh
+			std::vector<double> goal;
+			if (t->_private && robot->device() >= 0) {
+				goal.resize((size_t)saip_batch_goal_components(t->_batch, t->_id) * robot->batchSize());
+				check(saip_batch_get_goal_host(t->_batch, t->_id, goal.data()));
+			}
+			t->dropPrivateBatch();
 			t->_batch = _batch;
-			for (auto& f : t->_pending) check(f(_batch, t->_id));
-			t->_pending.clear();
+			t->_id = ids[i];
+			t->_manual = false;
+			for (auto& f : t->_log) check(f(_batch, t->_id));
+			if (!goal.empty()) check(saip_batch_set_goal_host(_batch, t->_id, goal.data()));
 			_task_names.push_back(t->getTaskName());
 		}
-		robot->_controller = this;
+		robot->attach(_batch);
 	}
 	~RobotController() {
-		if (_robot->_controller == this) _robot->_controller = nullptr;
+		for (auto& t : _tasks)
+			if (t->_batch == _batch) {
+				t->_batch = nullptr;
+				t->_manual = false;
+			}
+		_robot->detach(_batch);
 		saip_batch_destroy(_batch);
 	}
 	RobotController(const RobotController&) = delete;
@@ -409,6 +552,7 @@ public:
 	void updateControllerTaskModels() {
 		pushState();
 		check(saip_batch_update_task_models(_batch));
+		for (auto& t : _tasks) t->_manual = false;
 	}
 	// [dof][B] joint torques; instances that left the non-singular branch carry NaN and status()[b] == 1
 	std::vector<double> computeControlTorques() {
@@ -429,12 +573,7 @@ public:
 	std::shared_ptr<JointTask> getJointTaskByName(const std::string& name) { return byName<JointTask>(name, JOINT_TASK, "JointTask"); }
 	std::shared_ptr<MotionForceTask> getMotionForceTaskByName(const std::string& name) { return byName<MotionForceTask>(name, MOTION_FORCE_TASK, "MotionForceTask"); }
 	saip_batch* handle() { return _batch; }
-	void pushState() {
-		if (_pushed != _robot->_version) {
-			check(saip_batch_set_state_host(_batch, _robot->_q.data(), _robot->_dq.data()));
-			_pushed = _robot->_version;
-		}
-	}
+	void pushState() { _robot->pushTo(_batch); }
 
 private:
 	template <typename T>
@@ -452,11 +591,6 @@ private:
 	std::vector<std::string> _task_names;
 	std::vector<uint8_t> _status;
 	saip_batch* _batch = nullptr;
-	long _pushed = -1;
 };
-
-inline void SaiModel::updateModel() {
-	if (_controller) _controller->pushState();
-}
 
 }  // namespace SaiPrimitivesBatched

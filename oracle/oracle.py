@@ -52,6 +52,7 @@ def lib():
         L.orc_reset_state.argtypes = [C.c_void_p]
         L.orc_step_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(dp), dp, C.POINTER(C.c_ubyte), C.c_int]
         L.orc_step_details.argtypes = [C.c_void_p, dp, dp, C.POINTER(dp), dp, dp, dp, dp, dp, dp]
+        L.orc_task_step.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
         _LIB = L
     return _LIB
 
@@ -176,6 +177,23 @@ class Oracle:
                              dq_soa.ctypes.data_as(C.POINTER(C.c_double)), gp,
                              tau.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_ubyte)), nthreads)
         return tau, st
+
+    def task_step(self, task, q, dq, goal, N_prec=None, tau_prec=None):
+        """The per-task interface (TemplateTask.h:43-60) for a batch, one instance at a time: updateTaskModel(N_prec) then
+        computeTorques() / computeTorques(tau_prec).  q, dq (B,n); goal (B,goal_size); N_prec (B,n,n) or None (identity); tau_prec (B,n)
+        or None.  Returns tau (B,n), N (B,n,n), N N_prec (B,n,n), status (B,)."""
+        B, n = q.shape[0], self.n
+        tau, N, Nt, st = np.empty((B, n)), np.empty((B, n, n)), np.empty((B, n, n)), np.zeros(B, np.int32)
+        P = C.POINTER(C.c_double)
+        for b in range(B):
+            keep = [_d(q[b]), _d(dq[b]), _d(goal[b])]
+            npk = _d(N_prec[b]) if N_prec is not None else (None, None)
+            tpk = _d(tau_prec[b]) if tau_prec is not None else (None, None)
+            t1, n1, n2 = np.empty(n), np.empty((n, n)), np.empty((n, n))
+            st[b] = lib().orc_task_step(self._h, task, keep[0][1], keep[1][1], npk[1], tpk[1], keep[2][1], t1.ctypes.data_as(P),
+                                        n1.ctypes.data_as(P), n2.ctypes.data_as(P))
+            tau[b], N[b], Nt[b] = t1, n1, n2
+        return tau, N, Nt, st
 
     def details(self, q, dq, goals):
         """single instance: dict(tau, N[t], Lambda[t] (MAXNxMAXN buffers), sv[t], M, task_tau[t], status)"""

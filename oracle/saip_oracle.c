@@ -1472,4 +1472,42 @@ int orc_step_details(const orc_ctx* c, const double* q, const double* dq, const 
 	orc_details d = {N_out, Lambda_out, sv_out, M_out, task_tau};
 	return orc_instance_cycle(c, q, dq, goals, integ, NULL, NULL, tau, &d);
 }
+/* The reference's per-task interface for ONE instance (TemplateTask.h:43-60, driven by hand in examples/04-task_and_redundancy/
+ * 04-task_and_redundancy.cpp:141-206): robot->updateModel(); task->updateTaskModel(N_prec); tau = task->computeTorques[(tau_prec)].
+ * N_prec n*n row-major (NULL = identity), tau_prec n (NULL = computeTorques()).  N_out = getTaskNullspace(), Ntot_out =
+ * getTaskAndPreviousNullspace().  Integrators start at 0, no handler / passivity state.  Returns the instance status. */
+int orc_task_step(const orc_ctx* c, int task, const double* q, const double* dq, const double* N_prec_in, const double* tau_prec,
+				  const double* goal, double* tau, double* N_out, double* Ntot_out) {
+	int n = c->n;
+	if (task < 0 || task >= c->nt) return -1;
+	robot_state rs;
+	task_model tm;
+	double N_prec[MAXN * MAXN], integ[MAXN], zero[MAXN];
+	memset(integ, 0, sizeof(integ));
+	memset(zero, 0, sizeof(zero));
+	memcpy(rs.q, q, sizeof(double) * n);
+	memcpy(rs.dq, dq, sizeof(double) * n);
+	update_model(c, &rs);
+	if (N_prec_in) memcpy(N_prec, N_prec_in, sizeof(double) * n * n);
+	else eye(N_prec, n);
+	const orc_task* tk = &c->task[task];
+	int status = ST_OK;
+	if (tk->type == TASK_MOTION_FORCE) {
+		tm.sh = NULL;
+		mf_update_task_model(c, tk, &rs, N_prec, &tm);
+		if (tm.singular) status = ST_SINGULAR;
+		else if (tm.truncated) status = ST_TRUNCATED;
+	} else {
+		jt_update_task_model(c, tk, &rs, N_prec, &tm);
+	}
+	if (status == ST_SINGULAR) {
+		for (int i = 0; i < n; i++) tau[i] = NAN;
+		return status;
+	}
+	if (N_out) memcpy(N_out, tm.N, sizeof(double) * n * n);
+	if (Ntot_out) mm(tm.N, tm.N_prec, Ntot_out, n, n, n);
+	if (tk->type == TASK_MOTION_FORCE) mf_compute_torques(c, tk, &rs, &tm, goal, integ, NULL, tau);
+	else jt_compute_torques(c, tk, &rs, &tm, goal, integ, tau_prec ? tau_prec : zero, tau);
+	return status;
+}
 int orc_maxn(void) { return MAXN; }

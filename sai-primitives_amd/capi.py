@@ -165,6 +165,15 @@ def lib():
         "saip_batch_synchronize": (C.c_int, [vp]),
         "saip_batch_get_torques_host": (C.c_int, [vp, dp, u8p]),
         "saip_batch_get_task_nullspace_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_task_update_model": (C.c_int, [vp, C.c_int, dp]),
+        "saip_batch_task_update_model_device": (C.c_int, [vp, C.c_int, vp]),
+        "saip_batch_task_compute_torques": (C.c_int, [vp, C.c_int, dp, dp, u8p]),
+        "saip_batch_task_compute_torques_device": (C.c_int, [vp, C.c_int, vp, vp]),
+        "saip_batch_task_get_nullspaces_host": (C.c_int, [vp, C.c_int, dp, dp, dp]),
+        "saip_batch_task_device_nullspace": (vp, [vp, C.c_int, C.c_int]),
+        "saip_batch_task_device_torques": (vp, [vp, C.c_int]),
+        "saip_batch_set_state_device": (C.c_int, [vp, vp, vp]),
+        "saip_batch_wait_for": (C.c_int, [vp, vp]),
         "saip_batch_set_kernel": (C.c_int, [vp, C.c_int]),
         "saip_batch_kernel_name": (C.c_char_p, [vp]),
         "saip_batch_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp]),

@@ -7,8 +7,9 @@ per-robot Eigen vector replaced by a (B, size) NumPy array.  Differences from th
   * the internal OTG is ENABLED by default like in the reference: the acceleration-limited mode (the reference default) of both
     the joint OTG (OTG_joints) and the Cartesian OTG (OTG_6dof_cartesian) runs on the device; the jerk-limited mode raises
     SaipUnsupported;
-  * singular / blended SingularityHandler branches and closed-loop force control are "next" rows: requesting them raises
-    SaipUnsupported; instances that leave the non-singular branch get status 1 and NaN torques.
+  * a task can be driven by hand exactly like in the reference (TemplateTask.h:43-60: updateTaskModel(N_prec), computeTorques(),
+    computeTorques(tau_prec), get*Nullspace; examples/04-task_and_redundancy): inside a RobotController it uses the controller's batch,
+    on its own it owns a private one-task batch on the same device.
 """
 from __future__ import annotations
 
@@ -95,6 +96,7 @@ class SaiModel:
         self._q = np.zeros((self.batch_size, self._n))
         self._dq = np.zeros((self.batch_size, self._n))
         self._controller = None
+        self._controllers = []  # every batch that mirrors this robot's state: the RobotController and the private batches of tasks driven by hand
         self._state_version = 0
 
     def __del__(self):
@@ -127,8 +129,8 @@ class SaiModel:
 
     def updateModel(self):
         """pushes q/dq to the device; kinematics and dynamics are evaluated inside the cycle kernel"""
-        if self._controller is not None:
-            self._controller._push_state()
+        for c in self._controllers:
+            c._push_state()
 
     def jointLimits(self):
         n = self._n
@@ -149,8 +151,9 @@ class _Task:
         self._otg_enabled = True  # reference default (JointTask.h:38, MotionForceTask.h:67)
         self._ctrl = None
         self._id = -1
-        self._pending = []  # configuration calls issued before the controller exists
+        self._log = []  # every configuration call, replayed into the batch the task joins (its RobotController's or its private one)
         self._keepalive = []
+        self._manual = False  # model last updated through updateTaskModel(N_prec) rather than updateControllerTaskModels()
 
     # -- TemplateTask accessors
     def getConstRobotModel(self):
@@ -166,9 +169,8 @@ class _Task:
         return self._name
 
     def _cfg(self, fn_name, *args):
-        if self._ctrl is None:
-            self._pending.append((fn_name, args))
-        else:
+        self._log.append((fn_name, args))
+        if self._ctrl is not None:
             self._ctrl._call(fn_name, self._id, *args)
 
     def reInitializeTask(self):
@@ -176,11 +178,55 @@ class _Task:
         self._need_ctrl()._push_state()
         self._ctrl._call("saip_batch_reinitialize_task", self._id)
 
-    def updateTaskModel(self, N_prec=None):
-        raise NotImplementedError("the task models of a hierarchy are evaluated together on the device: RobotController.updateControllerTaskModels()")
+    # -- the reference's per-task interface, TemplateTask.h:43-60 (driven by hand in examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206)
+    def updateTaskModel(self, N_prec):
+        """TemplateTask::updateTaskModel(N_prec): N_prec = nullspace of the higher-priority tasks, (dof, dof) for every instance,
+        (B, dof, dof), or the DeviceNullspace another task's getTaskAndPreviousNullspace(device=True) returned (stays on the GPU)."""
+        ctrl = self._need_ctrl()
+        ctrl._push_state()
+        n, B = self._robot.dof(), ctrl.batch_size
+        L = capi.lib()
+        if isinstance(N_prec, DeviceNullspace):
+            if N_prec.n != n or N_prec.batch_size != B:
+                raise ValueError("N_prec matrix size not consistent with robot dof in updateTaskModel")
+            if N_prec.ctrl is not ctrl:
+                capi.check(L.saip_batch_wait_for(ctrl._h, N_prec.ctrl._h))
+            capi.check(L.saip_batch_task_update_model_device(ctrl._h, self._id, N_prec.ptr))
+        else:
+            a = np.asarray(N_prec, float)
+            if a.ndim < 2 or a.shape[-1] != a.shape[-2]:  # JointTask.cpp:219-223
+                raise ValueError("N_prec matrix not square in updateTaskModel")
+            if a.shape[-1] != n or a.ndim > 3 or (a.ndim == 3 and a.shape[0] != B):  # :224-229
+                raise ValueError("N_prec matrix size not consistent with robot dof in updateTaskModel")
+            a = np.ascontiguousarray(np.broadcast_to(a, (B, n, n)).reshape(B, n * n).T)
+            capi.check(L.saip_batch_task_update_model(ctrl._h, self._id, _dptr(a)))
+        self._manual = True
 
     def computeTorques(self, tau_prec=None):
-        raise NotImplementedError("the torques of a hierarchy are evaluated together on the device: RobotController.computeControlTorques()")
+        """TemplateTask::computeTorques() / computeTorques(tau_prec): (B, dof) torques of THIS task; tau_prec (B, dof) = torques of the
+        previous tasks (the joint task feed-forward compensates them, JointTask.cpp:285-292).  Per-instance status in self.status."""
+        ctrl = self._need_ctrl()
+        if not self._manual:
+            raise capi.SaipError(f"task [{self._name}]: call updateTaskModel(N_prec) before computeTorques()")
+        n, B = self._robot.dof(), ctrl.batch_size
+        tau, st = np.empty((n, B)), np.zeros(B, np.uint8)
+        tp = None if tau_prec is None else _soa(tau_prec, B, n, "tau_prec")
+        capi.check(capi.lib().saip_batch_task_compute_torques(ctrl._h, self._id, None if tp is None else _dptr(tp), _dptr(tau),
+                                                               st.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        self.status = st
+        return tau.T.copy()
+
+    def _manual_nullspace(self, which, device):
+        ctrl = self._need_ctrl()
+        n, B = self._robot.dof(), ctrl.batch_size
+        if device:
+            ptr = capi.lib().saip_batch_task_device_nullspace(ctrl._h, self._id, which)
+            return DeviceNullspace(ctrl, self, which, ptr, n, B)
+        out = np.empty((n * n, B))
+        args = [None, None, None]
+        args[which] = _dptr(out)
+        capi.check(capi.lib().saip_batch_task_get_nullspaces_host(ctrl._h, self._id, *args))
+        return out.T.reshape(B, n, n).copy()
 
     def _gains(self, fn, kp, kv, ki):
         self._gain_cache = getattr(self, "_gain_cache", {})
@@ -249,8 +295,10 @@ class _Task:
         return [PIDGains(*d) for d in default] if g is None else [PIDGains(*v) for v in zip(*(np.broadcast_to(x, (max(len(y) for y in g),)) for x in g))]
 
     def _need_ctrl(self):
+        """the batch this task is evaluated in: its RobotController's, or -- for a task driven by hand like in the reference's example 04 --
+        a private one-task batch created on first use"""
         if self._ctrl is None:
-            raise capi.SaipError(f"task [{self._name}] is not part of a RobotController yet")
+            RobotController(self._robot, [self], _private=True)
         return self._ctrl
 
     def _set_field(self, first, comps, value, what):
@@ -265,8 +313,10 @@ class _Task:
         capi.check(capi.lib().saip_batch_get_goal_host(ctrl._h, self._id, _dptr(out)))
         return out.T.copy()
 
-    def getTaskNullspace(self):
+    def getTaskNullspace(self, device=False):
         """(B, dof, dof) nullspace projector N of this task for the current state (TemplateTask.h:71-77)"""
+        if self._manual:
+            return self._manual_nullspace(0, device)
         ctrl = self._need_ctrl()
         n = self._robot.dof()
         out = np.empty((n * n, ctrl._robot.batch_size))
@@ -276,6 +326,8 @@ class _Task:
     def getPreviousTasksNullspace(self):
         """(B, dof, dof) N_prec this task was updated with: the product N_{t-1} ... N_0 of the tasks above it (TemplateTask.h:79-83,
         RobotController.cpp:68-77); the identity for the first task"""
+        if self._manual:
+            return self._manual_nullspace(1, False)
         ctrl = self._need_ctrl()
         n, B = self._robot.dof(), ctrl._robot.batch_size
         Np = np.broadcast_to(np.eye(n), (B, n, n)).copy()
@@ -285,9 +337,23 @@ class _Task:
             Np = out.T.reshape(B, n, n) @ Np
         return Np
 
-    def getTaskAndPreviousNullspace(self):
-        """(B, dof, dof) N N_prec, what the next task in the hierarchy is updated with (TemplateTask.h:85-89)"""
+    def getTaskAndPreviousNullspace(self, device=False):
+        """(B, dof, dof) N N_prec, what the next task in the hierarchy is updated with (TemplateTask.h:85-89); device=True (after
+        updateTaskModel) returns a DeviceNullspace handle instead: pass it to the next task's updateTaskModel, nothing crosses PCIe"""
+        if self._manual:
+            return self._manual_nullspace(2, device)
         return self.getTaskNullspace() @ self.getPreviousTasksNullspace()
+
+
+class DeviceNullspace:
+    """a (B, dof, dof) nullspace matrix resident on the GPU ([dof*dof][ld] row-major per instance): what task.getTaskAndPreviousNullspace(
+    device=True) returns and task.updateTaskModel accepts.  Valid until the producing task's next updateTaskModel."""
+
+    def __init__(self, ctrl, task, which, ptr, n, batch_size):
+        self.ctrl, self.task, self.which, self.ptr, self.n, self.batch_size = ctrl, task, which, ptr, n, batch_size
+
+    def numpy(self):
+        return self.task._manual_nullspace(self.which, False)
 
 
 class MotionForceTask(_Task):
@@ -305,8 +371,9 @@ class MotionForceTask(_Task):
         self.pos = np.asarray(compliant_frame_pos, float).reshape(3).copy()
         self.rot = None if compliant_frame_rot is None else np.ascontiguousarray(np.asarray(compliant_frame_rot, float).reshape(9))
         self.partial = controlled_directions_translation is not None or controlled_directions_rotation is not None
-        self.dt_ = np.ascontiguousarray(np.asarray(controlled_directions_translation or np.zeros((0, 3)), float).reshape(-1, 3))
-        self.dr_ = np.ascontiguousarray(np.asarray(controlled_directions_rotation or np.zeros((0, 3)), float).reshape(-1, 3))
+        none = np.zeros((0, 3))
+        self.dt_ = np.ascontiguousarray(np.asarray(controlled_directions_translation if controlled_directions_translation is not None else none, float).reshape(-1, 3))
+        self.dr_ = np.ascontiguousarray(np.asarray(controlled_directions_rotation if controlled_directions_rotation is not None else none, float).reshape(-1, 3))
         if self.partial and len(self.dt_) == 0 and len(self.dr_) == 0:  # MotionForceTask.cpp:47-53
             raise ValueError("controlled_directions_translation and controlled_directions_rotation cannot both be empty "
                              "in MotionForceTask::MotionForceTask")
@@ -351,8 +418,8 @@ class MotionForceTask(_Task):
     def _space(self, fn, dim, axis):
         a = np.ascontiguousarray(np.asarray(axis if axis is not None else (0.0, 0.0, 0.0), float).reshape(3))
         self._keepalive.append(a)
+        self._log.append((fn, (int(dim), _dptr(a), None)))
         if self._ctrl is None:
-            self._pending.append((fn, (int(dim), _dptr(a), None)))
             return None
         ch = C.c_int(0)
         self._ctrl._call(fn, self._id, int(dim), _dptr(a), C.byref(ch))
@@ -731,13 +798,16 @@ class JointTask(_Task):
 class RobotController:
     """RobotController.h:47-90 for B robots at once."""
 
-    def __init__(self, robot: SaiModel, tasks):
+    def __init__(self, robot: SaiModel, tasks, _private=False):
         L = capi.lib()
         if len(tasks) == 0:  # RobotController.cpp:11-14
             raise ValueError("RobotController must have at least one task")
         for t in tasks:
             if t.getConstRobotModel() is not robot:  # :28-31
                 raise ValueError("All tasks must have the same robot model in RobotController")
+        for t in tasks:
+            if t._ctrl is not None and not t._ctrl._private:
+                raise ValueError(f"task [{t.getTaskName()}] already belongs to a RobotController")
         h = C.c_void_p()
         capi.check(L.saip_batch_create(robot._h, robot.batch_size, robot.device, C.byref(h)))
         self._h = h
@@ -752,12 +822,25 @@ class RobotController:
             L.saip_batch_destroy(h)
             self._h = None
             raise
+        self._private = bool(_private)  # the one-task batch of a task driven by hand (TemplateTask.h:43-60), not a user-visible controller
         for t in tasks:
+            goal = None
+            if t._ctrl is not None:  # the task was driven by hand before: it moves here (configuration replayed, goal kept; integrators start afresh)
+                if robot.device >= 0:
+                    old_id, t._id = t._id, 0
+                    goal = t._get_goal()
+                    t._id = old_id
+                t._ctrl._release()
             t._ctrl = self
-            for fn, args in t._pending:
+            t._manual = False
+            for fn, args in t._log:
                 self._call(fn, t._id, *args)
-            t._pending = []
-        robot._controller = self
+            if goal is not None:
+                a = np.ascontiguousarray(goal.T)
+                capi.check(L.saip_batch_set_goal_host(h, t._id, _dptr(a)))
+        if not _private:
+            robot._controller = self
+        robot._controllers.append(self)
         self._pushed_version = -1
         self._has_device = robot.device >= 0
 
@@ -765,6 +848,12 @@ class RobotController:
         if getattr(self, "_h", None):
             capi.lib().saip_batch_destroy(self._h)
             self._h = None
+
+    def _release(self):
+        """a private one-task batch whose task joins a RobotController"""
+        if self in self._robot._controllers:
+            self._robot._controllers.remove(self)
+        self.__del__()
 
     def _call(self, fn_name, *args):
         capi.check(getattr(capi.lib(), fn_name)(self._h, *args))
@@ -780,6 +869,8 @@ class RobotController:
     def updateControllerTaskModels(self):
         self._push_state()
         self._call("saip_batch_update_task_models")
+        for t in self._tasks:
+            t._manual = False
 
     def computeControlTorques(self):
         """returns (B, dof) joint torques; per-instance status in self.status (0 ok, 1 singular -> NaN row)"""
@@ -907,6 +998,13 @@ class RobotController:
 def controller_from_specs(description, tasks, batch_size, device=0, *, disable_otg=True):
     """Build (robot, controller, task objects) from workloads.py-style task specs (used by tests and bench)."""
     robot = SaiModel(description, batch_size, device)
+    objs = tasks_from_specs(robot, tasks, disable_otg=disable_otg)
+    ctrl = RobotController(robot, objs)
+    return robot, ctrl, objs
+
+
+def tasks_from_specs(robot, tasks, *, disable_otg=True):
+    """task objects (not yet in any RobotController) from workloads.py-style task specs"""
     objs = []
     for t in tasks:
         if t["type"] == "motion_force":
@@ -956,5 +1054,4 @@ def controller_from_specs(description, tasks, batch_size, device=0, *, disable_o
         if disable_otg:
             o.disableInternalOtg()
         objs.append(o)
-    ctrl = RobotController(robot, objs)
-    return robot, ctrl, objs
+    return objs

@@ -88,7 +88,9 @@ struct TaskDev {
 	double kvinv[SAIP_MAXN], sat[SAIP_MAXN];   // joint task
 	double S[SAIP_MAXN * SAIP_MAXN]; // m x n row-major
 	double* goal;      // [goal_comps][ld]
-	double* integ;     // [6 or m][ld]
+	double* integ;     // [12 or m][ld]
+	double* integ_new; // same shape: what this cycle's control law advanced the integrators to; committed to `integ` at the end of the
+	                   // cycle unless the instance ends flagged (status 1) -- a flagged instance advances nothing, whichever kernel ran
 	double* diag_N;    // optional [n*n][ld] task nullspace dump (diagnostic variant), else nullptr
 	ShState* sh;       // [B] handler states when sing_strategies, else nullptr
 	double* popc;      // [7 + popc_cap][ld] passivity observer state: PO, E_correction, Rc, sum |vcl|^2, counter, ring head, ring size, ring
@@ -118,6 +120,15 @@ struct CycleParams {
 	int oct_partial_mf;           // eight-lane kernel: the motion-force task is partial (k < 6)
 	int oct_truncate;             // eight-lane kernel: singularity handling disabled -> near-singular instances are reduced in the kernel
 	double bie_thr;
+	// per-task entry points of the general kernel (TemplateTask::updateTaskModel(N_prec) / computeTorques() / computeTorques(tau_prec),
+	// TemplateTask.h:43-60): evaluate ONE task with a caller-supplied N_prec instead of walking the hierarchy
+	int single_task;              // -1: the whole hierarchy (RobotController); >= 0: this task only, no RobotController post-processing
+	int phase;                    // 0: model + torques fused; 1: model only (updateTaskModel: nullspaces out, handler classification state
+	                              // advanced, no control law); 2: torques only (computeTorques: control law, integrators, no classification)
+	const double* ext_nprec;      // [n*n][ld] row-major per instance, nullptr = identity
+	const double* ext_tau_prec;   // [n][ld] torques of the previous tasks (disturbance compensation), nullptr = none
+	double* out_N;                // [n*n][ld] task nullspace N (getTaskNullspace), optional
+	double* out_Ntot;             // [n*n][ld] N N_prec (getTaskAndPreviousNullspace), optional
 };
 
 // forward dynamics + semi-implicit Euler step (saip_dynamics.hip)

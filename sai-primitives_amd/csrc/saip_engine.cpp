@@ -324,8 +324,15 @@ struct TaskHost {
 	bool full_joint = false;
 	double* goal_dev = nullptr;
 	double* integ_dev = nullptr;
+	double* integ_new_dev = nullptr;
 	double* diag_dev = nullptr;
 	int integ_rows = 0;
+	// per-task entry points (TemplateTask::updateTaskModel(N_prec) / computeTorques): the N_prec the task was last updated with, its
+	// nullspaces N and N N_prec, its own torques and status; allocated on first use
+	double *nprec_dev = nullptr, *ntask_dev = nullptr, *ntot_dev = nullptr, *ttau_dev = nullptr, *tprec_dev = nullptr;
+	uint8_t* tstatus_dev = nullptr;
+	bool nprec_identity = true;
+	long model_epoch = -1;  // state epoch of the last updateTaskModel (-1: never)
 };
 struct saip_batch {
 	const saip_model* model = nullptr;
@@ -344,6 +351,10 @@ struct saip_batch {
 	double* pose_dev = nullptr;              // [12][ld] scratch of saip_batch_get_current_pose_host
 	hipGraph_t rollout_graph = nullptr;      // one captured closed-loop period (saip_batch_rollout_async)
 	hipGraphExec_t rollout_exec = nullptr;
+	long state_epoch = 0;                    // bumped whenever the resident state changes (per-task models become stale)
+	double* diag_tau = nullptr;              // scratch torques / status of diagnostic launches (the last cycle's results stay intact)
+	uint8_t* diag_status = nullptr;
+	hipEvent_t sync_event = nullptr;         // saip_batch_wait_for
 };
 
 static bool has_device(const saip_batch* b) { return b->device >= 0; }
@@ -376,6 +387,7 @@ extern "C" void saip_batch_destroy(saip_batch* b) {
 	if (has_device(b)) {
 		(void)hipSetDevice(b->device);
 		if (b->stream) (void)hipStreamSynchronize(b->stream);  // nothing of this batch may still be in flight
+		if (b->sync_event) (void)hipEventDestroy(b->sync_event);
 		if (b->rollout_exec) (void)hipGraphExecDestroy(b->rollout_exec);
 		if (b->rollout_graph) (void)hipGraphDestroy(b->rollout_graph);
 		for (void* p : b->allocs) (void)hipFree(p);
@@ -613,9 +625,12 @@ extern "C" saip_status saip_batch_finalize(saip_batch* b) {
 			(st = dev_alloc(b, &b->status, ld)) || (st = dev_alloc(b, &b->model_dev, 1)) || (st = dev_alloc(b, &b->tasks_dev, b->tasks.size())))
 			return st;
 		for (auto& T : b->tasks) {
-			if ((st = dev_alloc(b, &T.goal_dev, (size_t)T.dev.goal_comps * ld)) || (st = dev_alloc(b, &T.integ_dev, (size_t)T.integ_rows * ld))) return st;
+			if ((st = dev_alloc(b, &T.goal_dev, (size_t)T.dev.goal_comps * ld)) || (st = dev_alloc(b, &T.integ_dev, (size_t)T.integ_rows * ld)) ||
+				(st = dev_alloc(b, &T.integ_new_dev, (size_t)T.integ_rows * ld)))
+				return st;
 			T.dev.goal = T.goal_dev;
 			T.dev.integ = T.integ_dev;
+			T.dev.integ_new = T.integ_new_dev;
 		}
 		HIP_TRY(hipMemcpy(b->model_dev, &b->model->dev, sizeof(ModelDev), hipMemcpyHostToDevice));
 	}
@@ -1086,6 +1101,7 @@ extern "C" saip_status saip_batch_set_state_host(saip_batch* b, const double* q,
 	if (st) return st;
 	if (!q || !dq) return fail(SAIP_ERR_INVALID_ARGUMENT, "null state pointer");
 	b->models_valid = false;
+	b->state_epoch++;
 	if ((st = copy_h2d(b, b->q, q, b->model->n))) return st;
 	b->state_pushed = true;
 	return copy_h2d(b, b->dq, dq, b->model->n);
@@ -1209,6 +1225,14 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.dq = b->dq;
 	P.tau = b->tau_bound ? b->tau_bound : b->tau;
 	P.status = b->status;
+	if (diag) {
+		// a diagnostic launch re-evaluates the task models only (phase 1: no control law, no integrator / OTG / handler / passivity state
+		// is advanced) and writes its torques and status to scratch: the results of the last cycle stay what integrate() / getTorques() see
+		saip_status st;
+		if (!b->diag_tau && ((st = dev_alloc(b, &b->diag_tau, (size_t)b->model->n * b->ld)) || (st = dev_alloc(b, &b->diag_status, (size_t)b->ld)))) return st;
+		P.tau = b->diag_tau;
+		P.status = b->diag_status;
+	}
 	P.model = b->model_dev;
 	P.tasks = b->tasks_dev;
 	// lane kernel: motion-force task slots, batch-uniform rank bounds, the shared BIE threshold
@@ -1235,6 +1259,12 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	}
 	P.reinit_task = -1;
 	P.reinit_mask = 7;
+	P.single_task = -1;
+	P.phase = diag ? 1 : 0;
+	P.ext_nprec = nullptr;
+	P.ext_tau_prec = nullptr;
+	P.out_N = nullptr;
+	P.out_Ntot = nullptr;
 	P.lane_general = 0;
 	P.oct_general_joint = 0;
 	P.oct_partial_mf = 0;
@@ -1477,19 +1507,154 @@ extern "C" saip_status saip_batch_get_task_nullspace_host(saip_batch* b, int t, 
 	const int n = b->model->n;
 	TaskHost& T = b->tasks[t];
 	if (!T.diag_dev && (st = dev_alloc(b, &T.diag_dev, (size_t)n * n * b->ld))) return st;
-	// the diagnostic pass must not advance integrator state: it re-evaluates the models only
-	bool ia = b->integ_always;
-	std::vector<int> hk;
-	for (auto& X : b->tasks) hk.push_back(X.dev.has_ki), X.dev.has_ki = 0;
-	b->integ_always = false;
+	// the diagnostic pass re-evaluates the models only (make_params: phase 1, scratch outputs): no state of the batch is advanced
 	st = launch_cycle(b, true);
-	b->integ_always = ia;
-	for (size_t i = 0; i < b->tasks.size(); i++) b->tasks[i].dev.has_ki = hk[i];
 	b->config_dirty = true;
 	if (st) return st;
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	return copy_d2h(b, N, T.diag_dev, n * n);
 }
+// ------------------------------------------------------------------ per-task entry points, TemplateTask.h:43-60
+// The reference's plug-in interface: a caller that builds its own hierarchy drives each task by hand
+// (examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206): updateTaskModel(N_prec), N_prec = getTaskAndPreviousNullspace(),
+// computeTorques() / computeTorques(tau_prec).  One launch of the general kernel per call, restricted to the task.
+static saip_status ensure_task_buffers(saip_batch* b, TaskHost& T) {
+	if (T.tstatus_dev) return SAIP_OK;
+	const size_t n = b->model->n, ld = b->ld;
+	saip_status st;
+	if ((st = dev_alloc(b, &T.nprec_dev, n * n * ld)) || (st = dev_alloc(b, &T.ntask_dev, n * n * ld)) || (st = dev_alloc(b, &T.ntot_dev, n * n * ld)) ||
+		(st = dev_alloc(b, &T.ttau_dev, n * ld)) || (st = dev_alloc(b, &T.tprec_dev, n * ld)) || (st = dev_alloc(b, &T.tstatus_dev, ld)))
+		return st;
+	return SAIP_OK;
+}
+static saip_status launch_task(saip_batch* b, int t, int phase, const double* tau_prec_dev, double* tau_out_dev) {
+	CycleParams P;
+	saip_status st = make_params(b, P, false);
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	if (phase == 2 && T.otg_enabled) {
+		// computeTorques steps the task's internal OTG (JointTask.cpp:313-319, MotionForceTask.cpp:394-406); updateTaskModel does not
+		if (!T.otg_inited && (st = run_otg(b, t, 1))) return st;
+		if ((st = run_otg(b, t, 0))) return st;
+	}
+	P.single_task = t;
+	P.phase = phase;
+	P.rank_bound[t] = T.dev.type == saip::TASK_JOINT ? T.dev.m : T.dev.k;  // N_prec is the caller's: nothing is known about the ranks above
+	P.ext_nprec = T.nprec_identity ? nullptr : T.nprec_dev;
+	P.ext_tau_prec = phase == 2 ? tau_prec_dev : nullptr;
+	P.out_N = phase == 1 ? T.ntask_dev : nullptr;
+	P.out_Ntot = phase == 1 ? T.ntot_dev : nullptr;
+	P.tau = tau_out_dev ? tau_out_dev : T.ttau_dev;
+	P.status = T.tstatus_dev;
+	hipError_t e = saip::launch_cycle_wg(P, b->stream);
+	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "per-task kernel launch failed: %s", hipGetErrorString(e));
+	return SAIP_OK;
+}
+static saip_status task_ready(saip_batch* b, int t, const char* fn) {
+	saip_status st = need_ready(b, fn);
+	if (st) return st;
+	if (t < 0 || t >= (int)b->tasks.size()) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: task id %d out of range", fn, t);
+	if (!b->state_pushed) return fail(SAIP_ERR_ORDER, "%s: no robot state has been set (saip_batch_set_state_host)", fn);
+	return ensure_task_buffers(b, b->tasks[t]);
+}
+static saip_status task_update_model(saip_batch* b, int t) {
+	saip_status st = launch_task(b, t, 1, nullptr, nullptr);
+	if (st) return st;
+	b->tasks[t].model_epoch = b->state_epoch;
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_task_update_model(saip_batch* b, int t, const double* N_prec_host) {
+	saip_status st = task_ready(b, t, "saip_batch_task_update_model");
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	T.nprec_identity = N_prec_host == nullptr;
+	if (N_prec_host && (st = copy_h2d(b, T.nprec_dev, N_prec_host, b->model->n * b->model->n))) return st;
+	return task_update_model(b, t);
+}
+extern "C" saip_status saip_batch_task_update_model_device(saip_batch* b, int t, const double* N_prec_dev) {
+	saip_status st = task_ready(b, t, "saip_batch_task_update_model_device");
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	T.nprec_identity = N_prec_dev == nullptr;
+	if (N_prec_dev && N_prec_dev != T.nprec_dev)  // the task keeps its own copy like the reference (_N_prec = N_prec)
+		HIP_TRY(hipMemcpyAsync(T.nprec_dev, N_prec_dev, (size_t)b->model->n * b->model->n * b->ld * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+	return task_update_model(b, t);
+}
+static saip_status task_model_fresh(saip_batch* b, int t, const char* fn) {
+	if (b->tasks[t].model_epoch != b->state_epoch)
+		return fail(SAIP_ERR_ORDER, "%s: task [%s] has no model for the current robot state: call updateTaskModel(N_prec) first (stale task models are not supported)",
+					fn, b->tasks[t].name.c_str());
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_task_compute_torques_device(saip_batch* b, int t, const double* tau_prec_dev, double* tau_dev) {
+	saip_status st = task_ready(b, t, "saip_batch_task_compute_torques_device");
+	if (st || (st = task_model_fresh(b, t, "computeTorques"))) return st;
+	return launch_task(b, t, 2, tau_prec_dev, tau_dev);
+}
+extern "C" saip_status saip_batch_task_compute_torques(saip_batch* b, int t, const double* tau_prec_host, double* tau_host, uint8_t* status_host) {
+	saip_status st = task_ready(b, t, "saip_batch_task_compute_torques");
+	if (st || (st = task_model_fresh(b, t, "computeTorques"))) return st;
+	TaskHost& T = b->tasks[t];
+	if (tau_prec_host && (st = copy_h2d(b, T.tprec_dev, tau_prec_host, b->model->n))) return st;
+	if ((st = launch_task(b, t, 2, tau_prec_host ? T.tprec_dev : nullptr, nullptr))) return st;
+	if (tau_host && (st = copy_d2h(b, tau_host, T.ttau_dev, b->model->n))) return st;
+	if (status_host) HIP_TRY(hipMemcpyAsync(status_host, T.tstatus_dev, b->B, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return SAIP_OK;
+}
+extern "C" const double* saip_batch_task_device_nullspace(saip_batch* b, int t, int which) {
+	if (!b || t < 0 || t >= (int)b->tasks.size() || b->tasks[t].model_epoch < 0) return nullptr;
+	const TaskHost& T = b->tasks[t];
+	return which == 0 ? T.ntask_dev : (which == 1 ? (T.nprec_identity ? nullptr : T.nprec_dev) : (which == 2 ? T.ntot_dev : nullptr));
+}
+extern "C" double* saip_batch_task_device_torques(saip_batch* b, int t) {
+	return (b && t >= 0 && t < (int)b->tasks.size()) ? b->tasks[t].ttau_dev : nullptr;
+}
+extern "C" saip_status saip_batch_task_get_nullspaces_host(saip_batch* b, int t, double* N, double* N_prec, double* N_total) {
+	saip_status st = task_ready(b, t, "saip_batch_task_get_nullspaces_host");
+	if (st) return st;
+	TaskHost& T = b->tasks[t];
+	if (T.model_epoch < 0) return fail(SAIP_ERR_ORDER, "task [%s]: updateTaskModel has not been called", T.name.c_str());
+	const int n = b->model->n;
+	if (N && (st = copy_d2h(b, N, T.ntask_dev, n * n))) return st;
+	if (N_total && (st = copy_d2h(b, N_total, T.ntot_dev, n * n))) return st;
+	if (N_prec) {
+		if (T.nprec_identity) {
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++)
+					for (int k = 0; k < b->B; k++) N_prec[((size_t)i * n + j) * b->B + k] = (i == j) ? 1.0 : 0.0;
+		} else if ((st = copy_d2h(b, N_prec, T.nprec_dev, n * n))) {
+			return st;
+		}
+	}
+	return SAIP_OK;
+}
+// resident state shared between batches (tasks driven by hand live in batches of their own): device-to-device copy of q, dq [dof][ld]
+extern "C" saip_status saip_batch_set_state_device(saip_batch* b, const double* q_dev, const double* dq_dev) {
+	saip_status st = need_ready(b, "saip_batch_set_state_device");
+	if (st) return st;
+	if (!q_dev || !dq_dev) return fail(SAIP_ERR_INVALID_ARGUMENT, "null state pointer");
+	const size_t bytes = (size_t)b->model->n * b->ld * sizeof(double);
+	b->models_valid = false;
+	b->state_epoch++;
+	if (q_dev != b->q) HIP_TRY(hipMemcpyAsync(b->q, q_dev, bytes, hipMemcpyDeviceToDevice, b->stream));
+	if (dq_dev != b->dq) HIP_TRY(hipMemcpyAsync(b->dq, dq_dev, bytes, hipMemcpyDeviceToDevice, b->stream));
+	b->state_pushed = true;
+	return SAIP_OK;
+}
+// everything enqueued so far on `producer`'s stream happens before what is enqueued on `waiter`'s stream from now on (device-side
+// ordering, no host synchronisation): lets one batch consume device arrays another batch has just written
+extern "C" saip_status saip_batch_wait_for(saip_batch* waiter, saip_batch* producer) {
+	saip_status st = need_ready(waiter, "saip_batch_wait_for");
+	if (st || (st = need_ready(producer, "saip_batch_wait_for"))) return st;
+	if (waiter == producer) return SAIP_OK;
+	if (waiter->device != producer->device) return fail(SAIP_ERR_UNSUPPORTED, "saip_batch_wait_for: batches live on different devices");
+	if (!producer->sync_event) HIP_TRY(hipEventCreateWithFlags(&producer->sync_event, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(producer->sync_event, producer->stream));
+	HIP_TRY(hipStreamWaitEvent(waiter->stream, producer->sync_event, 0));
+	return SAIP_OK;
+}
+
 extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
 	if (!b || which < 0 || which > 3) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1, 2 or 3");
 	b->kernel_choice = which;
@@ -1515,6 +1680,7 @@ static saip_status enqueue_integrate(saip_batch* b, double dt, int substeps, con
 	hipError_t e = saip::launch_integrate(S, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "integrate launch failed: %s", hipGetErrorString(e));
 	b->models_valid = false;  // the state moved: like after robot->setQ(), updateControllerTaskModels() is due
+	b->state_epoch++;
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_integrate(saip_batch* b, double dt, int substeps, const double* gravity, double damping) {

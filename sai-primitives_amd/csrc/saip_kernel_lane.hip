@@ -519,10 +519,10 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - tk->kp_ori[i] * dphi[i] - tk->kv_ori[i] * (w[i] - G24[15 + i]) - tk->ki_ori[i] * io[i];
 			UNR for (int i = 0; i < 3; i++) Fum[3 + i] = tk->sig_o[3 * i] * tmp[0] + tk->sig_o[3 * i + 1] * tmp[1] + tk->sig_o[3 * i + 2] * tmp[2];
 		}
-		if (track && live && !singular) {  // flagged instances are recomputed from scratch by the slow path (or stay invalid)
+		if (track && live) {  // shadow copy: committed in the epilogue once the instance's final status is known (a later task may still flag it)
 			UNR for (int i = 0; i < 3; i++) {
-				tk->integ[(size_t)i * ld + b] = ip[i];
-				tk->integ[(size_t)(3 + i) * ld + b] = io[i];
+				tk->integ_new[(size_t)i * ld + b] = ip[i];
+				tk->integ_new[(size_t)(3 + i) * ld + b] = io[i];
 			}
 		}
 		double fh[6], ff[6];  // fhat = Bm^T F_um, Bm^T F_f  (columns >= k of Bm are zero)
@@ -783,7 +783,7 @@ __device__ __forceinline__ void lane_joint_task(const CycleParams& P, SMT& sm, c
 			double ie = 0.0;
 			if (track && i < m) ie = tk->integ[(size_t)i * ld + b];
 			ie += e * dt_;  // :323-324
-			if (track && live && !singular && i < m) tk->integ[(size_t)i * ld + b] = ie;
+			if (track && live && i < m) tk->integ_new[(size_t)i * ld + b] = ie;
 			double fi;
 			if (GL && tk->vel_sat) {  // JointTask.cpp:327-341
 				double vdes = -tk->kp[i] * tk->kvinv[i] * e - tk->ki[i] * tk->kvinv[i] * ie;
@@ -1167,6 +1167,16 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 			P.tau[(size_t)j * ld + b] = tv;
 		}
 		P.status[b] = singular ? 1 : 0;
+		// integrators: commit what the control laws advanced them to, unless the instance ended flagged (then nothing advances: the slow
+		// path launched behind recomputes it from the untouched state, or it stays invalid)
+		if (!singular) {
+			_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
+				const TaskCPtr tk = tasks + t;
+				if (!(tk->has_ki || P.integ_always)) continue;
+				const int rows = tk->type == TASK_MOTION_FORCE ? 6 : tk->m;
+				_Pragma("unroll 1") for (int i = 0; i < rows; i++) tk->integ[(size_t)i * ld + b] = tk->integ_new[(size_t)i * ld + b];
+			}
+		}
 	}
 	PHASE_FENCE();
 }

@@ -716,10 +716,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		UNR for (int i = 0; i < 3; i++) io[i] = fma(oe[i], mf.dt, io[i]);
 		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = G24[21 + i] - mf.kp_ori[i] * oe[i] - mf.kv_ori[i] * (vw[3 + i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
 		}
-		if (track_mf && live && !singular && r == 0) {
+		if (track_mf && live && r == 0) {  // shadow copy: committed in the epilogue once the final status is known (the joint task may still flag the instance)
 			UNR for (int i = 0; i < 3; i++) {
-				mf.integ[(size_t)i * ld + b] = ip[i];
-				mf.integ[(size_t)(3 + i) * ld + b] = io[i];
+				mf.integ_new[(size_t)i * ld + b] = ip[i];
+				mf.integ_new[(size_t)(3 + i) * ld + b] = io[i];
 			}
 		}
 		if (trunc_mode) {  // task_range_ns^T F_um (SingularityHandler.cpp:321-322); the identity for instances that were not reduced
@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			double ie = 0.0;
 			if (track && row) ie = jt.integ[(size_t)i * ld + b];
 			ie += e * jt.dt;  // :323-324
-			if (track && row && live && !singular && r == 0) jt.integ[(size_t)i * ld + b] = ie;
+			if (track && row && live && r == 0) jt.integ_new[(size_t)i * ld + b] = ie;
 			double fi;
 			if (jt.vel_sat) {  // :327-341
 				double vdes = -jt.kp[i] * jt.kvinv[i] * e - jt.ki[i] * jt.kvinv[i] * ie;
@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		double ie = 0.0;
 		if (track) ie = jt.integ[(size_t)rr * ld + b];
 		ie += e * jt.dt;
-		if (track && live && !singular && act) jt.integ[(size_t)r * ld + b] = ie;
+		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
 		double fi;
 		if (jt.vel_sat) {
 			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
@@ -1152,7 +1152,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		double ie = 0.0;
 		if (track) ie = jt.integ[(size_t)rr * ld + b];
 		ie += e * jt.dt;  // :323-324
-		if (track && live && !singular && act) jt.integ[(size_t)r * ld + b] = ie;
+		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
 		double fi;
 		if (jt.vel_sat) {  // :327-341
 			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
@@ -1234,6 +1234,21 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	if (singular) tv = __builtin_nan("");
 	if (live && act) P.tau[(size_t)r * ld + b] = tv;
 	if (live && r == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
+	// integrators: commit what the control laws advanced them to unless the instance ended flagged (then nothing advances: the slow path
+	// launched behind recomputes it from the untouched state, or it stays invalid); the lanes that wrote the shadow rows copy them
+	if (live && !singular) {
+		if (track_mf && r == 0) {
+			UNR for (int i = 0; i < 6; i++) mf.integ[(size_t)i * ld + b] = mf.integ_new[(size_t)i * ld + b];
+		}
+		if (jt.has_ki || P.integ_always) {
+			if (GJ == 1) {
+				if (r == 0)
+					for (int i = 0; i < mj; i++) jt.integ[(size_t)i * ld + b] = jt.integ_new[(size_t)i * ld + b];
+			} else if (act) {
+				jt.integ[(size_t)r * ld + b] = jt.integ_new[(size_t)r * ld + b];
+			}
+		}
+	}
 	STAMP(15);
 }
 

@@ -51,6 +51,7 @@ struct WgSmem {
 	static constexpr int MS = NMAX * LD;
 	static constexpr int NWORK = 9;
 	double Minv[MS], MBinv[MS], NpA[MS], NpB[MS];
+	double Nx[MS];  // per-task entry points: N_ns of a blended task (getTaskNullspace = N_js N_ns)
 	double W[NWORK][MS];
 	double fkA[NMAX * 12], fkB[NMAX * 12];  // per body: R (9, row-major) + o (3), world frame
 	double zax[NMAX * 3];                   // world joint axes
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	if (tid < n) {
 		sm.q[tid] = P.q[(size_t)tid * P.ld + b];
 		sm.dq[tid] = P.dq[(size_t)tid * P.ld + b];
-		sm.tau[tid] = 0.0;
+		sm.tau[tid] = P.ext_tau_prec ? P.ext_tau_prec[(size_t)tid * P.ld + b] : 0.0;  // computeTorques(tau_prec), TemplateTask.h:59
 	}
 	SYNC();
 	// ---------------------------------------------------------------- updateModel(): kinematics
@@ -253,15 +254,38 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 	double* Np2 = sm.NpB;
 	for (int e = tid; e < n * n; e += T) {
 		int i = e / n, j = e - i * n;
-		Np[i * LD + j] = (i == j) ? 1.0 : 0.0;
+		Np[i * LD + j] = P.ext_nprec ? P.ext_nprec[(size_t)e * P.ld + b] : ((i == j) ? 1.0 : 0.0);  // updateTaskModel(N_prec), TemplateTask.h:43
 	}
 	SYNC();
+	// per-task entry points (TemplateTask.h:43-60): one task, split into its model and its torque half
+	const int t_first = P.single_task >= 0 ? P.single_task : 0;
+	const int t_last = P.single_task >= 0 ? P.single_task + 1 : P.nt;
+	const bool do_law = P.phase != 1;    // updateTaskModel computes no torques (and advances neither integrators nor OTG)
+	const bool do_state = P.phase != 2 && !P.diag;  // computeTorques does not classify (SingularityHandler::classifySingularity runs in updateTaskModel, .cpp:227)
+	auto dump_nullspaces = [&](const double* Ntask, const double* Ntotal) {  // [n*n][ld] row-major per instance
+		for (int e = tid; e < n * n; e += T) {
+			int i = e / n, j = e - i * n;
+			if (P.out_N) P.out_N[(size_t)e * P.ld + b] = Ntask ? Ntask[i * LD + j] : ((i == j) ? 1.0 : 0.0);
+			if (P.out_Ntot) P.out_Ntot[(size_t)e * P.ld + b] = Ntotal[i * LD + j];
+		}
+	};
 
+	unsigned commit_lo = 0, commit_hi = 0;  // tasks whose control law wrote shadow integrator rows this cycle (lo: position / orientation / joint, hi: force / moment)
+	auto commit_integrators = [&]() {  // workgroup-uniform; call after a barrier that follows the last shadow store
+		for (int t = t_first; t < t_last; t++) {
+			const TaskDev& tk = P.tasks[t];
+			const int rows = tk.type == TASK_MOTION_FORCE ? 6 : tk.m;
+			if ((commit_lo >> t) & 1u)
+				for (int i = tid; i < rows; i += T) tk.integ[(size_t)i * P.ld + b] = tk.integ_new[(size_t)i * P.ld + b];
+			if ((commit_hi >> t) & 1u)
+				for (int i = tid; i < 6; i += T) tk.integ[(size_t)(6 + i) * P.ld + b] = tk.integ_new[(size_t)(6 + i) * P.ld + b];
+		}
+	};
 	bool singular = false;
 	bool truncated = false;  // some motion-force task was reduced to its non-singular subspace (singularity handling disabled)
 	bool blended = false;    // some motion-force task ran the blended type-1 / type-2 singularity strategies
 	// ---------------------------------------------------------------- task hierarchy
-	for (int t = 0; t < P.nt; t++) {
+	for (int t = t_first; t < t_last; t++) {
 		const TaskDev& tk = P.tasks[t];
 		double* Jh = sm.W[4];
 		int r = 0;           // rank of the task in its range basis
@@ -433,7 +457,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				}
 			}
 			if (sing) singular = true;
-			if (strategies && !blend && tid == 0) {  // no singular directions: SingularityHandler.cpp:238-244
+			if (strategies && !blend && do_state && tid == 0) {  // no singular directions: SingularityHandler.cpp:238-244
 				ShState& st = tk.sh[b];
 				st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
 			}
@@ -642,14 +666,17 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				bool ovf = false;
 				law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, G, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, P.ld, &ovf);
 				if (ovf) sm.flag2 = 1;
+				// shadow copies: committed at the end of the cycle unless the instance ends flagged (a later task may still flag it)
 				if (closed)
-					for (int i = 0; i < 6; i++) tk.integ[(size_t)(6 + i) * P.ld + b] = ifm[i];
+					for (int i = 0; i < 6; i++) tk.integ_new[(size_t)(6 + i) * P.ld + b] = ifm[i];
 				if (track)
 					for (int i = 0; i < 3; i++) {
-						tk.integ[(size_t)i * P.ld + b] = ip[i];
-						tk.integ[(size_t)(3 + i) * P.ld + b] = io[i];
+						tk.integ_new[(size_t)i * P.ld + b] = ip[i];
+						tk.integ_new[(size_t)(3 + i) * P.ld + b] = io[i];
 					}
 			}
+			if (track) commit_lo |= 1u << t;
+			if (tk.cl_force || tk.cl_moment) commit_hi |= 1u << t;
 			SYNC();
 			if (tid < tk.k) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
 				double s = 0.0, s2 = 0.0;
@@ -686,8 +713,9 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				Jh[i * LD + j] = sm.W[0][i * LD + j];
 			}
 			const double alpha = fmin(fmax((sm.dv[ns] / sm.dv[0] - tk.s_min) / (tk.s_max - tk.s_min), 0.0), 1.0);  // :114-115
-			mf_law();
-			{
+			double fTd = 0.0;
+			if (do_law) {
+				mf_law();
 				double s = 0.0, s2 = 0.0;
 				if (tid < k)
 					for (int i = 0; i < k; i++) {
@@ -700,38 +728,48 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					sm.v4[tid] = s2;  // U^T F_f
 				}
 				SYNC();
+				double fn2 = 0.0;
+				for (int i = 0; i < 6; i++) fn2 = fma(sm.Fum[i] + sm.Ff[i], sm.Fum[i] + sm.Ff[i], fn2);
+				fTd = (sm.v2[ns] + sm.v4[ns]) / sqrt(fn2);  // :346-347
 			}
-			double fn2 = 0.0;
-			for (int i = 0; i < 6; i++) fn2 = fma(sm.Fum[i] + sm.Ff[i], sm.Fum[i] + sm.Ff[i], fn2);
-			const double fTd = (sm.v2[ns] + sm.v4[ns]) / sqrt(fn2);  // :346-347
 			// non-singular part (:104-112): Lambda_ns, N_ns, tau_ns (:321-322)
 			osm(Jh, ns, true);
-			if (tid < ns) {
-				double s = sm.v4[tid];
-				for (int i = 0; i < ns; i++) s = fma(Lmod[tid * LD + i], sm.v2[i], s);
-				sm.v3[tid] = s;
+			if (do_law) {
+				if (tid < ns) {
+					double s = sm.v4[tid];
+					for (int i = 0; i < ns; i++) s = fma(Lmod[tid * LD + i], sm.v2[i], s);
+					sm.v3[tid] = s;
+				}
+				SYNC();
+				for (int j = tid; j < n; j += T) {
+					double s = 0.0;
+					for (int c = 0; c < ns; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+					tns[j] = s;
+				}
 			}
-			SYNC();
-			for (int j = tid; j < n; j += T) {
-				double s = 0.0;
-				for (int c = 0; c < ns; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
-				tns[j] = s;
-			}
+			const bool want_task_N = P.out_N || (P.diag && tk.diag_N);
+			if (want_task_N)
+				for (int e = tid; e < n * n; e += T) {
+					int i = e / n, j = e - i * n;
+					sm.Nx[i * LD + j] = Nt[i * LD + j];  // N_ns, for getTaskNullspace = N_js N_ns
+				}
 			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);  // X = N_ns N_prec
 			SYNC();
 			// singular part (:116-121): Lambda_s, tau_s clamped to the torque limits (:358-366)
-			osm(Jh + ns * LD, nsg, false);
-			if (tid < nsg) {
-				double s = sm.v4[ns + tid];
-				for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], sm.v2[ns + i], s);
-				sm.v3[tid] = s;
-			}
-			SYNC();
-			for (int j = tid; j < n; j += T) {
-				double s = 0.0;
-				for (int c = 0; c < nsg; c++) s = fma(Jh[(ns + c) * LD + j], sm.v3[c], s);
-				const double lim = md.effort[j];
-				ts[j] = (s != s) ? 0.0 : fmin(fmax(s, -lim), lim);
+			if (do_law) {
+				osm(Jh + ns * LD, nsg, false);
+				if (tid < nsg) {
+					double s = sm.v4[ns + tid];
+					for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], sm.v2[ns + i], s);
+					sm.v3[tid] = s;
+				}
+				SYNC();
+				for (int j = tid; j < n; j += T) {
+					double s = 0.0;
+					for (int c = 0; c < nsg; c++) s = fma(Jh[(ns + c) * LD + j], sm.v3[c], s);
+					const double lim = md.effort[j];
+					ts[j] = (s != s) ? 0.0 : fmin(fmax(s, -lim), lim);
+				}
 			}
 			// classifySingularity (:230-295): task-space motion along u_c of the control frame at q +- 5 v_c
 			double* qp = sm.W[5];  // [2 nsg][n] perturbed postures (W[5] and W[6] are contiguous)
@@ -741,14 +779,14 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 			if (tid < n) {  // :232-235 with the counters of the previous cycle
 				double qpr = st.q_prior[tid];
-				if (st.ntypes == 0 || st.c2 > st.c1) {
+				if (do_state && (st.ntypes == 0 || st.c2 > st.c1)) {
 					qpr = sm.q[tid];
 					st.q_prior[tid] = qpr;
 				}
 				sm.v0[tid] = qpr;
 			}
 			SYNC();
-			if (tid < 2 * nsg) {
+			if (do_state && tid < 2 * nsg) {
 				double x1[3], R1[9], w6[6] = {0, 0, 0, 0, 0, 0};
 				fk_control_frame(md, tk, qp + tid * n, 1, 0, x1, R1);
 				for (int e = 0; e < 3; e++) w6[e] = x1[e] - sm.xp[e];
@@ -770,28 +808,31 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 			SYNC();
 			if (tid == 0) {
-				bool any1 = false;
-				for (int c = 0; c < nsg; c++)
-					if (fmax(sm.cs[2 * c], sm.cs[2 * c + 1]) > 0.5) any1 = true;  // _type_1_tol
-				st.ntypes = nsg;
-				int head = st.head, size = st.size, c1 = st.c1, c2 = st.c2;
-				if (size == SH_BUFFER) {  // :285-292
-					if (st.hist[head] == 1) c1--;
-					else c2--;
-					head = (head + 1) % SH_BUFFER;
-					size--;
+				int c1 = st.c1, c2 = st.c2;
+				if (do_state) {
+					bool any1 = false;
+					for (int c = 0; c < nsg; c++)
+						if (fmax(sm.cs[2 * c], sm.cs[2 * c + 1]) > 0.5) any1 = true;  // _type_1_tol
+					st.ntypes = nsg;
+					int head = st.head, size = st.size;
+					if (size == SH_BUFFER) {  // :285-292
+						if (st.hist[head] == 1) c1--;
+						else c2--;
+						head = (head + 1) % SH_BUFFER;
+						size--;
+					}
+					st.hist[(head + size) % SH_BUFFER] = any1 ? 1 : 2;
+					size++;
+					if (any1) c1++;
+					else c2++;
+					st.head = head;
+					st.size = size;
+					st.c1 = c1;
+					st.c2 = c2;
 				}
-				st.hist[(head + size) % SH_BUFFER] = any1 ? 1 : 2;
-				size++;
-				if (any1) c1++;
-				else c2++;
-				st.head = head;
-				st.size = size;
-				st.c1 = c1;
-				st.c2 = c2;
 				unsigned dn = st.dir_neg;
 				const bool t1 = (c1 > c2) || tk.sh_force_type1;  // :329
-				if (!t1) {  // type-2 strategy: torque direction flips near the joint limits (:339-345)
+				if (!t1 && do_law) {  // type-2 strategy: torque direction flips near the joint limits (:339-345; inside computeTorques)
 					for (int j = 0; j < n; j++)
 						if (Jh[ns * LD + j] != 0.0) {
 							if (fabs(sm.q[j] - md.q_upper[j]) < 5.0 * M_PI / 180.0) dn |= 1u << j;
@@ -805,7 +846,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			SYNC();
 			const bool type1 = sm.flag != 0;
 			const unsigned dir_neg = (unsigned)sm.rank;
-			if (tid < n) {
+			if (do_law && tid < n) {
 				if (type1) {  // hold the entering posture (:333-336)
 					sm.v1[tid] = -tk.sh_kp1 * (sm.q[tid] - sm.v0[tid]) - tk.sh_kv1 * sm.dq[tid];
 				} else {      // :346-354
@@ -814,7 +855,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				}
 			}
 			SYNC();
-			if (tid < nsg) {  // V_s^T unit
+			if (do_law && tid < nsg) {  // V_s^T unit
 				double a = 0.0, b2 = 0.0;
 				for (int j = 0; j < n; j++) {
 					a = fma(Jh[(ns + tid) * LD + j], sm.v1[j], a);
@@ -832,20 +873,32 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 			SYNC();
 			osm(Jh, nsg, true);
-			if (tid < nsg) {
-				double s = type1 ? 0.0 : wA[tid];
-				for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], type1 ? wA[i] : wB[i], s);
-				sm.v3[tid] = s;
-			}
-			SYNC();
-			for (int j = tid; j < n; j += T) {
-				double s = 0.0;
-				for (int c = 0; c < nsg; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
-				if (tk.decoupling == DEC_IMPEDANCE) sm.tau[j] += tns[j];  // :311-313
-				else sm.tau[j] += tns[j] + alpha * ts[j] + (1.0 - alpha) * s;  // :367
+			if (do_law) {
+				if (tid < nsg) {
+					double s = type1 ? 0.0 : wA[tid];
+					for (int i = 0; i < nsg; i++) s = fma(Lmod[tid * LD + i], type1 ? wA[i] : wB[i], s);
+					sm.v3[tid] = s;
+				}
+				SYNC();
+				for (int j = tid; j < n; j += T) {
+					double s = 0.0;
+					for (int c = 0; c < nsg; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+					if (tk.decoupling == DEC_IMPEDANCE) sm.tau[j] += tns[j];  // :311-313
+					else sm.tau[j] += tns[j] + alpha * ts[j] + (1.0 - alpha) * s;  // :367
+				}
 			}
 			gemm<T>(Np, LD, Nt, LD, 1, Np2, LD, 1, n, n, n, tid);  // N_prec <- N_js N_ns N_prec (:157 + getTaskAndPreviousNullspace)
 			SYNC();
+			if (want_task_N) {  // _N = N_js N_ns (:157)
+				gemm<T>(Np2, LD, Nt, LD, 1, sm.Nx, LD, 1, n, n, n, tid);
+				SYNC();
+				if (P.diag && tk.diag_N)
+					for (int e = tid; e < n * n; e += T) {
+						int i = e / n, j = e - i * n;
+						tk.diag_N[(size_t)e * P.ld + b] = Np2[i * LD + j];
+					}
+			}
+			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Np2, Np);
 		} else if (!empty && !singular) {
 			osm(Jh, r, true);
 			if (P.diag && tk.diag_N) {
@@ -856,7 +909,9 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 
 			// ------------------------------------------------------------ control law -> g (r) in v3, then tau_t = Jh^T g
-			if (tk.type == TASK_MOTION_FORCE) {
+			if (!do_law) {
+				// updateTaskModel only: the nullspaces are all that is asked for
+			} else if (tk.type == TASK_MOTION_FORCE) {
 				mf_law();
 				if (mf_trunc) {  // U_ns^T of both (task_range_ns^T F, SingularityHandler.cpp:321-322)
 					double s = 0.0, s2 = 0.0;
@@ -882,6 +937,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			} else {
 				const int m = tk.m;
 				// e, f (m-vectors)
+				if (track) commit_lo |= 1u << t;
 				for (int i = tid; i < m; i += T) {
 					double cur = 0.0, vel = 0.0;
 					if (tk.s_identity) {
@@ -896,7 +952,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					double e = cur - sm.goal[i];
 					double ie = track ? tk.integ[(size_t)i * P.ld + b] : 0.0;
 					ie += e * tk.dt;  // JointTask.cpp:323-324
-					if (track) tk.integ[(size_t)i * P.ld + b] = ie;
+					if (track) tk.integ_new[(size_t)i * P.ld + b] = ie;
 					if (tk.vel_sat) {  // JointTask.cpp:327-341
 						double vdes = -tk.kp[i] * tk.kvinv[i] * e - tk.ki[i] * tk.kvinv[i] * ie;
 						vdes = fmin(fmax(vdes, -tk.sat[i]), tk.sat[i]);
@@ -945,27 +1001,49 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				}
 				SYNC();
 			}
-			for (int j = tid; j < n; j += T) {  // tau += Jh^T g
-				double s = 0.0;
-				for (int c = 0; c < r; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
-				sm.tau[j] += s;
-			}
+			if (do_law)
+				for (int j = tid; j < n; j += T) {  // tau += Jh^T g
+					double s = 0.0;
+					for (int c = 0; c < r; c++) s = fma(Jh[c * LD + j], sm.v3[c], s);
+					sm.tau[j] += s;
+				}
 			// N_prec <- N N_prec   (getTaskAndPreviousNullspace)
 			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);
 			SYNC();
 			double* t_ = Np;
 			Np = Np2;
 			Np2 = t_;
-		} else if (empty && P.diag && tk.diag_N) {
-			for (int e = tid; e < n * n; e += T) {
-				int i = e / n, j = e - i * n;
-				tk.diag_N[(size_t)e * P.ld + b] = (i == j) ? 1.0 : 0.0;
-			}
+			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Nt, Np);
+		} else if (empty) {
+			// no controllable direction left: N = I (JointTask.cpp:234-239), a fully singular reduced motion-force task is passed through
+			if (P.diag && tk.diag_N)
+				for (int e = tid; e < n * n; e += T) {
+					int i = e / n, j = e - i * n;
+					tk.diag_N[(size_t)e * P.ld + b] = (i == j) ? 1.0 : 0.0;
+				}
+			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(nullptr, Np);
 		}
 		SYNC();
 		if (singular) break;
 	}
 
+	if (P.single_task >= 0) {
+		// TemplateTask::computeTorques[(tau_prec)]: this task's torques alone (sm.tau started from tau_prec: it feeds the joint task's
+		// disturbance compensation, JointTask.cpp:285-292); none of RobotController's post-processing.  A flagged instance reports NaN.
+		const double nanv = __builtin_nan("");
+		if (tid < n && do_law) {
+			const double tp = P.ext_tau_prec ? P.ext_tau_prec[(size_t)tid * P.ld + b] : 0.0;
+			P.tau[(size_t)tid * P.ld + b] = singular ? nanv : sm.tau[tid] - tp;
+		}
+		if (singular && !do_law)
+			for (int e = tid; e < n * n; e += T) {
+				if (P.out_N) P.out_N[(size_t)e * P.ld + b] = nanv;
+				if (P.out_Ntot) P.out_Ntot[(size_t)e * P.ld + b] = nanv;
+			}
+		if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0) | (blended ? 8 : 0));
+		if (!singular) commit_integrators();
+		return;
+	}
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (tid < n && P.torque_sat) {
 		const double lim = md.effort[tid];
@@ -1032,6 +1110,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		P.tau[(size_t)tid * P.ld + b] = tv;
 	}
 	if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0) | (blended ? 8 : 0));
+	if (!singular) commit_integrators();  // a flagged instance advances nothing, like in the lane / eight-lane kernels
 }
 
 // ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)

@@ -2,6 +2,9 @@
 // drives the reference: MotionForceTask + JointTask in a RobotController, one control cycle.
 //   facade_example <robot.txt> cfgonly            host-logic checks without a GPU (device -1)
 //   facade_example <robot.txt> run <B> <in.bin> <out.bin>   one cycle on GPU 0: in = q,dq,goal0[24],goal1[21] as [c][B] doubles
+//   facade_example <robot.txt> ex04 <B> <in.bin> <out.bin>  the same tasks WITHOUT a controller, hierarchy built by hand like
+//       /root/reference/examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206; out = tau_mf, tau_joint, tau_joint with
+//       computeTorques(tau_prec), tau_joint through the device-resident N_prec, then a RobotController on the same tasks: 5 x [dof][B]
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -111,6 +114,57 @@ int main(int argc, char** argv) {
 		std::ofstream o(argv[5], std::ios::binary);
 		o.write((const char*)control_torques.data(), control_torques.size() * sizeof(double));
 		std::cout << "FACADE_RUN_OK" << std::endl;
+		return 0;
+	}
+	if (std::string(argv[2]) == "ex04" && argc == 6) {
+		const int B = atoi(argv[3]);
+		auto robot = std::make_shared<SaiModel>(links, B, 0);
+		const int dof = robot->dof();
+		std::vector<double> in((size_t)(2 * dof + 24 + 3 * dof) * B);
+		std::ifstream f(argv[4], std::ios::binary);
+		f.read((char*)in.data(), in.size() * sizeof(double));
+		if (!f) return 3;
+		auto slice = [&](size_t first, size_t comps) { return std::vector<double>(in.begin() + first * B, in.begin() + (first + comps) * B); };
+		// tasks, no controller (04-task_and_redundancy.cpp:97-128)
+		auto motion_force_task = std::make_shared<MotionForceTask>(robot, "end-effector", pos_in_link);
+		motion_force_task->disableInternalOtg();
+		auto joint_task = std::make_shared<JointTask>(robot);
+		joint_task->disableInternalOtg();
+		// one pass of the control loop (:136-206)
+		robot->setQ(slice(0, dof));
+		robot->setDq(slice(dof, dof));
+		robot->updateModel();
+		std::vector<double> N_prec((size_t)dof * dof, 0.0);  // MatrixXd::Identity(dof, dof)
+		for (int i = 0; i < dof; i++) N_prec[(size_t)i * dof + i] = 1.0;
+		motion_force_task->updateTaskModel(N_prec);
+		N_prec = motion_force_task->getTaskAndPreviousNullspace();
+		joint_task->updateTaskModel(N_prec);
+		size_t g = 2 * dof;
+		motion_force_task->setGoalPosition(slice(g, 3));
+		motion_force_task->setGoalOrientation(slice(g + 3, 9));
+		motion_force_task->setGoalLinearVelocity(slice(g + 12, 3));
+		motion_force_task->setGoalAngularVelocity(slice(g + 15, 3));
+		motion_force_task->setGoalLinearAcceleration(slice(g + 18, 3));
+		motion_force_task->setGoalAngularAcceleration(slice(g + 21, 3));
+		g += 24;
+		joint_task->setGoalPosition(slice(g, dof));
+		joint_task->setGoalVelocity(slice(g + dof, dof));
+		joint_task->setGoalAcceleration(slice(g + 2 * dof, dof));
+		std::vector<double> motion_force_task_torques = motion_force_task->computeTorques();
+		std::vector<double> joint_task_torques = joint_task->computeTorques();
+		std::vector<double> joint_task_torques_comp = joint_task->computeTorques(motion_force_task_torques);  // RobotController.cpp:82-84
+		// the same with N_prec kept on the GPU
+		joint_task->updateTaskModel(motion_force_task->getTaskAndPreviousNullspaceDevice());
+		std::vector<double> joint_task_torques_dev = joint_task->computeTorques(motion_force_task_torques);
+		// and the tasks handed to a RobotController afterwards (configuration and goals travel with them)
+		std::vector<std::shared_ptr<TemplateTask>> task_list = {motion_force_task, joint_task};
+		RobotController robot_controller(robot, task_list);
+		robot_controller.updateControllerTaskModels();
+		std::vector<double> control_torques = robot_controller.computeControlTorques();
+		std::ofstream o(argv[5], std::ios::binary);
+		for (auto* v : {&motion_force_task_torques, &joint_task_torques, &joint_task_torques_comp, &joint_task_torques_dev, &control_torques})
+			o.write((const char*)v->data(), v->size() * sizeof(double));
+		std::cout << "FACADE_EX04_OK" << std::endl;
 		return 0;
 	}
 	return 2;

@@ -50,3 +50,28 @@ def test_cpp_facade_cycle_matches_oracle(tmp_path):
     tau = np.fromfile(outp).reshape(7, B).T
     ref, _ = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"])
     assert W.torque_error(tau, ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_cpp_facade_example04_manual_hierarchy(tmp_path):
+    """the reference's per-task interface (TemplateTask.h:43-60) through the C++ facade: tasks without a RobotController, hierarchy
+    built by hand like examples/04-task_and_redundancy/04-task_and_redundancy.cpp:141-206"""
+    from oracle import Oracle
+    exe, robot = _build(tmp_path)
+    B = 192
+    d = W.make_inputs(2, B)
+    blob = np.concatenate([d["q"].T, d["dq"].T, d["goals"][0].T, d["goals"][1].T], axis=0)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    np.ascontiguousarray(blob).tofile(inp)
+    out = subprocess.run([exe, robot, "ex04", str(B), str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "FACADE_EX04_OK" in out.stdout, out.stdout + out.stderr
+    tau_mf, tau_jt, tau_jt_comp, tau_jt_dev, tau_ctrl = (x.T for x in np.fromfile(outp).reshape(5, 7, B))
+    orc = Oracle(d["model"], d["tasks"])
+    r_mf, _, Nt, st = orc.task_step(0, d["q"], d["dq"], d["goals"][0])
+    assert (st & 1).sum() == 0
+    r_jt, _, _, _ = orc.task_step(1, d["q"], d["dq"], d["goals"][1], N_prec=Nt)
+    r_jtc, _, _, _ = orc.task_step(1, d["q"], d["dq"], d["goals"][1], N_prec=Nt, tau_prec=r_mf)
+    assert W.torque_error(tau_mf, r_mf) < 1e-5 and W.torque_error(tau_jt, r_jt) < 1e-5 and W.torque_error(tau_jt_comp, r_jtc) < 1e-5
+    assert np.array_equal(tau_jt_dev, tau_jt_comp)
+    ref, _ = orc.step(d["q"], d["dq"], d["goals"])
+    assert W.torque_error(tau_mf + tau_jt_comp, ref) < 1e-5 and W.torque_error(tau_ctrl, ref) < 1e-5
