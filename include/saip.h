@@ -54,12 +54,14 @@ typedef enum { SAIP_TASK_UNDEFINED = 0, SAIP_TASK_JOINT_LIMIT_AVOIDANCE = 1, SAI
 /* SaiPrimitives::DynamicDecouplingType, helper_modules/SaiPrimitivesCommonDefinitions.h:14-20 (same values) */
 typedef enum { SAIP_FULL_DYNAMIC_DECOUPLING = 0, SAIP_BOUNDED_INERTIA_ESTIMATES = 1, SAIP_IMPEDANCE = 2 } saip_decoupling_type;
 
-/* per-instance status written by a cycle (uint8).  SINGULAR excludes the others; TRUNCATED and POPC_OVERFLOW are informational bits
- * on valid torques and may combine. */
+/* per-instance status written by a cycle (uint8).  SINGULAR excludes the others; TRUNCATED, POPC_OVERFLOW and BLENDED are
+ * informational bits on valid torques and may combine. */
 enum {
 	SAIP_INSTANCE_OK = 0,
-	SAIP_INSTANCE_SINGULAR = 1,       /* left SingularityHandler's non-singular branch with the handling strategy enabled: torques = NaN */
-	SAIP_INSTANCE_TRUNCATED = 2,      /* handling disabled: a motion-force task was reduced to its non-singular subspace (or passed through) */
+	SAIP_INSTANCE_SINGULAR = 1,       /* the engine could not evaluate the instance (blended strategies switched off and the instance outside the
+	                                     non-singular branch; sigma_min/sigma_0 < 1e-6; an ambiguous rank gap): its torques are NOT written -- the
+	                                     last valid ones are held -- or NaN, see saip_batch_set_flagged_torque_policy; integrators do not advance */
+	SAIP_INSTANCE_TRUNCATED = 2,      /* a motion-force task was reduced to its non-singular subspace (handling disabled) or passed through (fully singular) */
 	SAIP_INSTANCE_POPC_OVERFLOW = 4,  /* the passivity observer's energy window exceeded the 1024 samples kept on the device */
 	SAIP_INSTANCE_BLENDED = 8         /* a motion-force task ran the blended type-1 / type-2 singularity strategies (valid torques) */
 };
@@ -129,8 +131,8 @@ saip_status saip_batch_set_joint_gains(saip_batch*, int task, const double* kp, 
 saip_status saip_batch_set_dynamic_decoupling_type(saip_batch*, int task, int type);
 saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold);
 /* MotionForceTask::enableSingularityHandling / disableSingularityHandling (.h:715-725 -> SingularityHandler.h:146-158).
- * enabled (reference default): instances that leave the fully non-singular branch need the reference's blended singularity
- * strategies, which are not on the device -> status 1, NaN torques.
+ * enabled (reference default): instances that leave the fully non-singular branch run the reference's blended singularity
+ * strategies (next entry).
  * disabled: the reference then uses only the non-singular part of the task, _N = _N_ns and tau = tau_ns
  * (SingularityHandler.cpp:146-148, 319-330): the task acts on the span of the leading left singular vectors of its projected
  * Jacobian, up to the first sigma_i / sigma_0 < s_max (:100-121); a fully singular task (sigma_0 < 1e-3) is passed through.
@@ -138,13 +140,15 @@ saip_status saip_batch_set_bie_threshold(saip_batch*, int task, double threshold
  * kernel launched behind it as a device-side slow path). */
 saip_status saip_batch_set_singularity_handling(saip_batch*, int task, int enabled);
 /* Blended singularity strategies of SingularityHandler (updateTaskModel :100-121, 146-228; classifySingularity :230-295;
- * computeTorques :310-367) for instances inside the bounds (s_min, s_max), with the handling strategy enabled.  Off by default
- * (such instances are then flagged, see above).  On: the task is split into its non-singular and singular directions, the
+ * computeTorques :310-367) for instances inside the bounds (s_min, s_max), with the handling strategy enabled.  ON by default, like in the
+ * reference (which has no switch for them); switching them off is an engine extra: such instances are then flagged (status 1) and
+ * nothing but the fully non-singular branch is ever evaluated.  On: the task is split into its non-singular and singular directions, the
  * singular ones are blended out by alpha = (sigma_s/sigma_0 - s_min)/(s_max - s_min) in favour of a joint strategy (type 1: hold
  * the entering posture, kp 50 / kv 14; type 2: constant torque 1e-2 x the torque limit along the open direction, damping kv 5),
  * chosen by the majority of the last 200 classifications; status bit 8.  Per-instance handler state (entering posture, type
  * window, type-2 direction) lives on the device and is reset by this call.  Conventions where the reference depends on the sign
- * its SVD happens to return are fixed as DESIGN.md states; sigma_0 < 1e-3 or sigma_min/sigma_0 < 1e-6 -> status 1. */
+ * its SVD happens to return are fixed as DESIGN.md states.  A fully singular task (sigma_0 < 1e-3) is passed through like in the reference
+ * (zero torques, N = N_prec, :149-151, 316-317; status bit 2; its classification is skipped); sigma_min/sigma_0 < 1e-6 -> status 1. */
 saip_status saip_batch_set_singularity_strategies(saip_batch*, int task, int enabled);
 /* MotionForceTask::setSingularityHandlingGains (.h:749 -> SingularityHandler.h:119; defaults 50, 14, 5) */
 saip_status saip_batch_set_singularity_gains(saip_batch*, int task, double kp_type_1, double kv_type_1, double kv_type_2);
@@ -233,6 +237,9 @@ saip_status saip_batch_set_control_to_sensor_transform(saip_batch*, int task, co
 saip_status saip_batch_enable_gravity_compensation(saip_batch*, int enabled);
 saip_status saip_batch_enable_joint_limit_avoidance(saip_batch*, int enabled); /* JLA wrap, RobotController.cpp:96-112 */
 saip_status saip_batch_enable_torque_saturation(saip_batch*, int enabled);
+/* torques of an instance that ends a cycle flagged (status 1): 0 (default) = not written, i.e. the last valid torques of that instance are
+ * held (zero before the first valid cycle); 1 = NaN.  The reference has no such state: it never refuses an instance. */
+saip_status saip_batch_set_flagged_torque_policy(saip_batch*, int nan);
 /* integrator state policy: 0 = advance the integral terms only while the task's ki != 0 (default; elides the
  * state traffic), 1 = advance every cycle like the reference does (MotionForceTask.cpp:411-413,446; JointTask.cpp:323) */
 saip_status saip_batch_set_integrator_tracking(saip_batch*, int always);

@@ -352,7 +352,7 @@ public:
 	void setOriControlGains(double kp, double kv, double ki = 0) { cfg([=](saip_batch* b, int id) { return saip_batch_set_ori_control_gains(b, id, &kp, &kv, &ki, 1); }); }
 	void enableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 1); }); }    // MotionForceTask.h:715
 	void disableSingularityHandling() { cfg([](saip_batch* b, int id) { return saip_batch_set_singularity_handling(b, id, 0); }); }  // :723
-	// blended type-1 / type-2 strategies for instances inside the singularity bounds (default: such instances are flagged)
+	// blended type-1 / type-2 strategies for instances inside the singularity bounds: on by default like in the reference; off = flagged instead
 	void setSingularityStrategies(bool enabled) { cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_strategies(b, id, enabled ? 1 : 0); }); }
 	void setSingularityHandlingGains(double kp_type_1, double kv_type_1, double kv_type_2) {  // MotionForceTask.h:749
 		cfg([=](saip_batch* b, int id) { return saip_batch_set_singularity_gains(b, id, kp_type_1, kv_type_1, kv_type_2); });
@@ -565,6 +565,8 @@ public:
 	void enableGravityCompensation(bool e) { check(saip_batch_enable_gravity_compensation(_batch, e)); }
 	void enableJointLimitAvoidance(bool e) { check(saip_batch_enable_joint_limit_avoidance(_batch, e)); }
 	void enableTorqueSaturation(bool e) { check(saip_batch_enable_torque_saturation(_batch, e)); }
+	// torques of instances that end a cycle flagged (status 1): false (default) = the last valid torques are held, true = NaN
+	void setFlaggedTorquePolicy(bool nan) { check(saip_batch_set_flagged_torque_policy(_batch, nan ? 1 : 0)); }
 	void reinitializeTasks() {
 		pushState();
 		check(saip_batch_reinitialize_tasks(_batch));

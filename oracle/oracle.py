@@ -106,7 +106,7 @@ class Oracle:
                 L.orc_set_mf_gains(self._h, tid, *[x[1] for x in g])
                 L.orc_set_singularity_bounds(self._h, tid, t["s_min"], t["s_max"])
                 L.orc_set_singularity_handling(self._h, tid, int(bool(t.get("singularity_handling", True))))
-                L.orc_set_singularity_strategies(self._h, tid, int(bool(t.get("singularity_strategies", False))))
+                L.orc_set_singularity_strategies(self._h, tid, int(bool(t.get("singularity_strategies", True))))
                 if "sh_gains" in t:
                     L.orc_set_singularity_gains(self._h, tid, *map(float, t["sh_gains"]))
                 L.orc_set_all_singularities_type1(self._h, tid, int(bool(t.get("sh_all_type1", False))))

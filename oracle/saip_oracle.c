@@ -28,7 +28,7 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be
  * built here (Eigen3, sai-model, RBDL absent).  This oracle is pinned only by (i) the analytic invariants
  * of SURVEY.md Appendix E (tests/test_oracle_invariants.py) and (ii) agreement <=1e-10 with the independent
- * NumPy restatement in workloads.py (tests/golden/, tests/test_oracle_vs_numpy.py).
+ * NumPy restatement in oracle/restatement.py (tests/golden/, tests/test_oracle.py).
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -493,7 +493,7 @@ typedef struct {
 
 
 /* Blended singularity strategies (handling enforced): updateTaskModel :83-121, 146-228 and classifySingularity :230-295, with the
- * three choices documented at workloads.sh_blend (sign-invariant classification, intended type-2 torque ratio, invariance of the
+ * three choices documented at restatement.sh_blend (sign-invariant classification, intended type-2 torque ratio, invariance of the
  * torque formulas).  Returns 0 when the task is fully non-singular (the caller continues on the ordinary path). */
 static void position_in_world(const robot_state* rs, int link, const double pos_in_link[3], double p[3]);
 static void orientation_error(const double Rd[9], const double Rc[9], double e[3]);
@@ -825,7 +825,7 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	mat3v(sig_m, goal_moment, tmp);
 	for (int i = 0; i < 3; i++) F_f[3 + i] += (t->cl_force ? t->kff_moment : 1.0) * tmp[i];
 	/* SingularityHandler::computeTorques, :307-309 (and :316-330 with the handling strategy disabled) */
-	if (tm->blend) { /* computeTorques in the singular branches, :310-367 (conventions: workloads.sh_blend_torques) */
+	if (tm->blend) { /* computeTorques in the singular branches, :310-367 (conventions: restatement.sh_blend_torques) */
 		sh_state* st = tm->sh;
 		const int ns = tm->k, nsg = tm->nsg;
 		for (int i = 0; i < n; i++) tau[i] = 0;
@@ -1137,7 +1137,7 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 		if (tk->type == TASK_MOTION_FORCE) {
 			tm[t].sh = sh ? sh + t : NULL;
 			mf_update_task_model(c, tk, &rs, N_prec, &tm[t]);
-			if (tm[t].blend) info |= ST_BLENDED;
+			if (tm[t].blend) info |= tm[t].k == 0 ? ST_TRUNCATED : ST_BLENDED; /* fully singular: passed through (:149-151, 316-317) */
 			if (tm[t].singular) status = ST_SINGULAR;
 			if (tm[t].truncated) info |= ST_TRUNCATED;
 			if (det && det->sv_out) memcpy(det->sv_out + 6 * t, tm[t].sv, sizeof(double) * 6);
@@ -1475,7 +1475,7 @@ int orc_step_details(const orc_ctx* c, const double* q, const double* dq, const 
 /* The reference's per-task interface for ONE instance (TemplateTask.h:43-60, driven by hand in examples/04-task_and_redundancy/
  * 04-task_and_redundancy.cpp:141-206): robot->updateModel(); task->updateTaskModel(N_prec); tau = task->computeTorques[(tau_prec)].
  * N_prec n*n row-major (NULL = identity), tau_prec n (NULL = computeTorques()).  N_out = getTaskNullspace(), Ntot_out =
- * getTaskAndPreviousNullspace().  Integrators start at 0, no handler / passivity state.  Returns the instance status. */
+ * getTaskAndPreviousNullspace().  Integrators start at 0, a fresh SingularityHandler (first cycle), no passivity state.  Returns the instance status. */
 int orc_task_step(const orc_ctx* c, int task, const double* q, const double* dq, const double* N_prec_in, const double* tau_prec,
 				  const double* goal, double* tau, double* N_out, double* Ntot_out) {
 	int n = c->n;
@@ -1492,11 +1492,14 @@ int orc_task_step(const orc_ctx* c, int task, const double* q, const double* dq,
 	else eye(N_prec, n);
 	const orc_task* tk = &c->task[task];
 	int status = ST_OK;
+	sh_state sh; /* a fresh SingularityHandler: the state of the first cycle */
+	memset(&sh, 0, sizeof(sh));
 	if (tk->type == TASK_MOTION_FORCE) {
-		tm.sh = NULL;
+		tm.sh = &sh;
 		mf_update_task_model(c, tk, &rs, N_prec, &tm);
 		if (tm.singular) status = ST_SINGULAR;
 		else if (tm.truncated) status = ST_TRUNCATED;
+		else if (tm.blend) status = tm.k == 0 ? ST_TRUNCATED : ST_BLENDED;
 	} else {
 		jt_update_task_model(c, tk, &rs, N_prec, &tm);
 	}

@@ -652,8 +652,8 @@ class MotionForceTask(_Task):
         self._cfg("saip_batch_set_singularity_handling", 0)
 
     def setSingularityStrategies(self, enabled=True):
-        """blended type-1 / type-2 strategies of SingularityHandler for instances inside the singularity bounds (status bit 8);
-        off (default): such instances are flagged (status 1)"""
+        """blended type-1 / type-2 strategies of SingularityHandler for instances inside the singularity bounds (status bit 8): ON by default
+        like in the reference; off (an engine extra): such instances are flagged (status 1) instead"""
         self._cfg("saip_batch_set_singularity_strategies", int(bool(enabled)))
 
     def setSingularityHandlingGains(self, kp_type_1, kv_type_1, kv_type_2):  # MotionForceTask.h:749
@@ -912,6 +912,10 @@ class RobotController:
         return self._by_name(name, TaskType.MOTION_FORCE_TASK, "MotionForceTask")
 
     # -- engine extras (resident pipelines, benchmarking)
+    def setFlaggedTorquePolicy(self, nan: bool):
+        """torques of instances that end a cycle flagged (status 1): False (default) = the last valid torques are held, True = NaN"""
+        self._call("saip_batch_set_flagged_torque_policy", int(bool(nan)))
+
     def setIntegratorTracking(self, always: bool):
         self._call("saip_batch_set_integrator_tracking", int(always))
 
@@ -1016,8 +1020,7 @@ def tasks_from_specs(robot, tasks, *, disable_otg=True):
             o.setSingularityHandlingBounds(t["s_min"], t["s_max"])
             if not t.get("singularity_handling", True):
                 o.disableSingularityHandling()
-            if t.get("singularity_strategies", False):
-                o.setSingularityStrategies(True)
+            o.setSingularityStrategies(bool(t.get("singularity_strategies", True)))
             if "sh_gains" in t:
                 o.setSingularityHandlingGains(*t["sh_gains"])
             if t.get("sh_all_type1", False):

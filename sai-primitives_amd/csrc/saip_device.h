@@ -46,6 +46,9 @@ struct ShState {
 	double q_prior[SAIP_MAXN];
 	unsigned dir_neg;
 	int ntypes, c1, c2, head, size;
+	int last_cycle;    // cycle number (CycleParams::task_cycle) of the last cycle this instance had singular directions: the counters and the
+	                   // window above are void unless that was the previous cycle (SingularityHandler.cpp:238-244 clears them whenever a cycle
+	                   // finds none) -- instances outside the singular region never have to touch their state
 	unsigned char hist[SH_BUFFER];
 };
 
@@ -129,6 +132,15 @@ struct CycleParams {
 	const double* ext_tau_prec;   // [n][ld] torques of the previous tasks (disturbance compensation), nullptr = none
 	double* out_N;                // [n*n][ld] task nullspace N (getTaskNullspace), optional
 	double* out_Ntot;             // [n*n][ld] N N_prec (getTaskAndPreviousNullspace), optional
+	int task_cycle[SAIP_MAXT];    // per task: how many times its model has been updated (SingularityHandler state: see ShState::last_cycle)
+	int flag_nan;                 // torques of an instance that ends flagged (status 1): 0 = left as they were (the last valid torque is held), 1 = NaN
+	// instances the lane / eight-lane kernel could not finish (status 1) are appended here; the general kernel launched behind as the
+	// device-side slow path (a fixed grid striding over the list) recomputes them.  Two count / list pairs used alternately: the lane /
+	// eight-lane kernel of a cycle appends to `flag_count` / `flag_list` and zeroes `flag_count_next` (whose readers -- the slow path of the
+	// previous cycle -- are done by stream order), so an empty list costs the slow path one load per workgroup and no atomic at all
+	int* flag_count;
+	int* flag_list;
+	int* flag_count_next;
 };
 
 // forward dynamics + semi-implicit Euler step (saip_dynamics.hip)

@@ -2,7 +2,7 @@
 // rollouts (OTG -> control cycle -> dynamics) stay on the device.  It stands in for what the reference's examples do with the
 // external physics engine: sim->setJointTorques(...); sim->integrate()   (/root/reference/examples/05-using_robot_controller/
 // 05-using_robot_controller.cpp:225-231; sai-simulation is not part of the reference tree, so there is no reference arithmetic to
-// match -- the oracle is the Lagrangian restatement in workloads.forward_dynamics, see tests/test_gpu_dynamics.py).
+// match -- the oracle is the Lagrangian restatement in oracle/restatement.forward_dynamics, see tests/test_gpu_dynamics.py).
 //
 //   M(q) qdd + b(q, dq) + g(q) = tau        b: Coriolis / centrifugal, g: gravity
 //   dq <- dq + dt qdd ;  q <- q + dt dq     (semi-implicit Euler, `substeps` times per call with the torque held)

@@ -15,6 +15,7 @@
 
 namespace saip {
 hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream);
+hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
@@ -333,6 +334,7 @@ struct TaskHost {
 	uint8_t* tstatus_dev = nullptr;
 	bool nprec_identity = true;
 	long model_epoch = -1;  // state epoch of the last updateTaskModel (-1: never)
+	int sh_cycle = 0;       // how many times this task's model has been updated (CycleParams::task_cycle; ShState::last_cycle)
 };
 struct saip_batch {
 	const saip_model* model = nullptr;
@@ -355,6 +357,10 @@ struct saip_batch {
 	double* diag_tau = nullptr;              // scratch torques / status of diagnostic launches (the last cycle's results stay intact)
 	uint8_t* diag_status = nullptr;
 	hipEvent_t sync_event = nullptr;         // saip_batch_wait_for
+	hipEvent_t time_ev[2] = {nullptr, nullptr};  // saip_batch_time_steps (created once: event creation is not part of a timed region)
+	bool flag_nan = false;                   // saip_batch_set_flagged_torque_policy
+	int* flag_buf = nullptr;                 // [2 * (32 + ld)]: two { count, list } pairs of the device-side slow path, used alternately (CycleParams::flag_*)
+	unsigned flag_parity = 0;
 };
 
 static bool has_device(const saip_batch* b) { return b->device >= 0; }
@@ -388,6 +394,8 @@ extern "C" void saip_batch_destroy(saip_batch* b) {
 		(void)hipSetDevice(b->device);
 		if (b->stream) (void)hipStreamSynchronize(b->stream);  // nothing of this batch may still be in flight
 		if (b->sync_event) (void)hipEventDestroy(b->sync_event);
+		for (hipEvent_t e : b->time_ev)
+			if (e) (void)hipEventDestroy(e);
 		if (b->rollout_exec) (void)hipGraphExecDestroy(b->rollout_exec);
 		if (b->rollout_graph) (void)hipGraphDestroy(b->rollout_graph);
 		for (void* p : b->allocs) (void)hipFree(p);
@@ -490,6 +498,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	T.dev.s_max = 6e-2;
 	T.dev.s_abs_tol = 1e-3;  // SingularityHandler.cpp:11
 	T.dev.sing_handling = 1; // _enforce_handling_strategy = true, SingularityHandler.cpp:61
+	T.dev.sing_strategies = 1;  // the reference always runs its blended type-1 / type-2 strategies while the handling is enforced (:100-121, 146-158, 310-367)
 	T.dev.sh_kp1 = 50.0;     // KP_TYPE_1, KV_TYPE_1, KV_TYPE_2, SingularityHandler.cpp:17-19
 	T.dev.sh_kv1 = 14.0;
 	T.dev.sh_kv2 = 5.0;
@@ -622,7 +631,8 @@ extern "C" saip_status saip_batch_finalize(saip_batch* b) {
 		const size_t n = b->model->n, ld = b->ld;
 		saip_status st;
 		if ((st = dev_alloc(b, &b->q, n * ld)) || (st = dev_alloc(b, &b->dq, n * ld)) || (st = dev_alloc(b, &b->tau, n * ld)) ||
-			(st = dev_alloc(b, &b->status, ld)) || (st = dev_alloc(b, &b->model_dev, 1)) || (st = dev_alloc(b, &b->tasks_dev, b->tasks.size())))
+			(st = dev_alloc(b, &b->status, ld)) || (st = dev_alloc(b, &b->model_dev, 1)) || (st = dev_alloc(b, &b->tasks_dev, b->tasks.size())) ||
+			(st = dev_alloc(b, &b->flag_buf, 2 * (ld + 32))))
 			return st;
 		for (auto& T : b->tasks) {
 			if ((st = dev_alloc(b, &T.goal_dev, (size_t)T.dev.goal_comps * ld)) || (st = dev_alloc(b, &T.integ_dev, (size_t)T.integ_rows * ld)) ||
@@ -1069,6 +1079,11 @@ extern "C" saip_status saip_batch_enable_torque_saturation(saip_batch* b, int e)
 	b->torque_sat = e != 0;
 	return SAIP_OK;
 }
+extern "C" saip_status saip_batch_set_flagged_torque_policy(saip_batch* b, int nan) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->flag_nan = nan != 0;
+	return SAIP_OK;
+}
 extern "C" saip_status saip_batch_set_integrator_tracking(saip_batch* b, int always) {
 	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
 	b->integ_always = always != 0;
@@ -1265,6 +1280,11 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.ext_tau_prec = nullptr;
 	P.out_N = nullptr;
 	P.out_Ntot = nullptr;
+	for (int t = 0; t < SAIP_MAXT; t++) P.task_cycle[t] = t < (int)b->tasks.size() ? b->tasks[t].sh_cycle : 0;
+	P.flag_nan = b->flag_nan ? 1 : 0;
+	P.flag_count = nullptr;  // set by launch_cycle when a device-side slow path follows the lane / eight-lane kernel
+	P.flag_count_next = nullptr;
+	P.flag_list = nullptr;
 	P.lane_general = 0;
 	P.oct_general_joint = 0;
 	P.oct_partial_mf = 0;
@@ -1274,8 +1294,8 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
 						  b->tasks[1].dev.m == P.n && !b->tasks[0].dev.general_law) ? 1 : 0;
 	{
-		const char* la = getenv("SAIP_LANE_ACTIVE");
-		int a = la ? atoi(la) : 64;
+		static const char* la = getenv("SAIP_LANE_ACTIVE");  // diagnostic knob, read once
+		static const int a = la ? atoi(la) : 64;
 		P.lane_active = (a >= 1 && a <= 64) ? a : 64;
 	}
 	return SAIP_OK;
@@ -1328,6 +1348,8 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 }
 static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;
+	if (!diag)
+		for (auto& T : b->tasks) T.sh_cycle++;  // updateControllerTaskModels: every task's model is updated once per cycle
 	saip_status st = make_params(b, P, diag);
 	if (st) return st;
 	for (size_t t = 0; t < b->tasks.size(); t++) {
@@ -1356,6 +1378,21 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	bool lane_ok = false;
 	if (!diag && b->kernel_choice == 3 && !oct_eligible(b, P)) return fail(SAIP_ERR_UNSUPPORTED, "the eight-lanes-per-instance kernel does not cover this robot/task stack");
 	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
+		// slow path: instances the lane / eight-lane kernel flags (outside the fully non-singular branch) are recomputed by the general kernel
+		// when a task can handle them there (blended strategies -- the reference default -- or singularity handling disabled: the task is
+		// reduced to its non-singular subspace).  Flagged instances are appended to a list on the device; the general kernel launched
+		// behind strides over it with a small fixed grid, no host round trip, and leaves at once when the list is empty.
+		bool slow = false;
+		for (auto& T : b->tasks)
+			if (T.dev.type == saip::TASK_MOTION_FORCE && (!T.dev.sing_handling || T.dev.sing_strategies)) slow = true;
+		if (slow) {
+			int* cur = b->flag_buf + (size_t)(b->flag_parity & 1u) * (b->ld + 32);
+			int* nxt = b->flag_buf + (size_t)((b->flag_parity + 1u) & 1u) * (b->ld + 32);
+			b->flag_parity++;
+			P.flag_count = cur;
+			P.flag_list = cur + 32;
+			P.flag_count_next = nxt;
+		}
 		// small batches of the headline stack: eight lanes per instance (the lane kernel would leave most of the chip idle)
 		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
 		const int oct_max = oct_env ? atoi(oct_env) : 8192;  // four wavefronts per CU (35 KB of LDS each): beyond that the lane kernel wins (measured)
@@ -1365,16 +1402,8 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
 			b->kernel_name = oct ? "saip_cycle_oct" : "saip_cycle_lane";
-			// slow path: instances the lane kernel flagged (outside the fully non-singular branch) are recomputed by the general kernel
-			// when a task can handle them there (singularity handling disabled: the task is reduced to its non-singular subspace;
-			// blended strategies switched on: type-1 / type-2 handling);
-			// workgroups of unflagged instances exit at once, no host round trip
-			bool slow = false;
-			for (auto& T : b->tasks)
-				if (T.dev.type == saip::TASK_MOTION_FORCE && (!T.dev.sing_handling || T.dev.sing_strategies)) slow = true;
 			if (slow) {
-				P.only_flagged = 1;
-				hipError_t e2 = saip::launch_cycle_wg(P, b->stream);
+				hipError_t e2 = saip::launch_cycle_wg_list(P, b->stream);
 				if (e2 != hipSuccess) return fail(SAIP_ERR_DEVICE, "slow-path kernel launch failed: %s", hipGetErrorString(e2));
 			}
 			return SAIP_OK;
@@ -1532,6 +1561,7 @@ static saip_status launch_task(saip_batch* b, int t, int phase, const double* ta
 	saip_status st = make_params(b, P, false);
 	if (st) return st;
 	TaskHost& T = b->tasks[t];
+	if (phase == 1) P.task_cycle[t] = ++T.sh_cycle;
 	if (phase == 2 && T.otg_enabled) {
 		// computeTorques steps the task's internal OTG (JointTask.cpp:313-319, MotionForceTask.cpp:394-406); updateTaskModel does not
 		if (!T.otg_inited && (st = run_otg(b, t, 1))) return st;
@@ -1709,8 +1739,11 @@ extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double
 		return s2 ? s2 : enqueue_integrate(b, sim_dt, substeps, gravity, damping);
 	};
 	static const bool use_graph = getenv("SAIP_ROLLOUT_GRAPH") != nullptr;
+	bool cycle_dependent = false;  // the device-side slow path and the blended singularity strategies read per-cycle launch parameters
+	for (auto& T : b->tasks)               // (list parity, CycleParams::task_cycle): not capturable
+		if (T.dev.type == saip::TASK_MOTION_FORCE && (!T.dev.sing_handling || T.dev.sing_strategies)) cycle_dependent = true;
 	int done = 0;
-	if (use_graph && steps >= 4) {
+	if (use_graph && steps >= 4 && !cycle_dependent) {
 		if ((st = period())) return st;  // eager: uploads, OTG initialisation
 		done = 1;
 		HIP_TRY(hipStreamSynchronize(b->stream));  // a graph still executing from an earlier call must not be destroyed under it
@@ -1771,9 +1804,11 @@ extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmu
 	if (steps <= 0 || warmup < 0 || !elapsed_ms) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad timing arguments");
 	for (int i = 0; i < warmup; i++)
 		if ((st = launch_cycle(b, false))) return st;
-	hipEvent_t e0, e1;
-	HIP_TRY(hipEventCreate(&e0));
-	HIP_TRY(hipEventCreate(&e1));
+	if (!b->time_ev[0]) {
+		HIP_TRY(hipEventCreate(&b->time_ev[0]));
+		HIP_TRY(hipEventCreate(&b->time_ev[1]));
+	}
+	hipEvent_t e0 = b->time_ev[0], e1 = b->time_ev[1];
 	HIP_TRY(hipEventRecord(e0, b->stream));
 	for (int i = 0; i < steps; i++)
 		if ((st = launch_cycle(b, false))) return st;
@@ -1781,8 +1816,6 @@ extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmu
 	HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	*elapsed_ms = ms;
 	return SAIP_OK;
 }

@@ -1163,10 +1163,13 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		UNR for (int j = 0; j < N; j++) {
 			double tv = tau[j];
 			if (P.gravity_comp) tv += taug[j];
-			if (singular) tv = __builtin_nan("");
-			P.tau[(size_t)j * ld + b] = tv;
+			// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
+			if (!singular) P.tau[(size_t)j * ld + b] = tv;
+			else if (P.flag_nan) P.tau[(size_t)j * ld + b] = __builtin_nan("");
 		}
 		P.status[b] = singular ? 1 : 0;
+		if (singular && P.flag_list) P.flag_list[atomicAdd(P.flag_count, 1)] = b;  // work list of the device-side slow path
+		if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;   // the other list: its last readers finished a cycle ago
 		// integrators: commit what the control laws advanced them to, unless the instance ended flagged (then nothing advances: the slow
 		// path launched behind recomputes it from the untouched state, or it stays invalid)
 		if (!singular) {

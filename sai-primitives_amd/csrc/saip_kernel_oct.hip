@@ -1231,9 +1231,12 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		const double tgp = -Ic[0] * (z[0] * gv[0] + z[1] * gv[1] + z[2] * gv[2]);
 		tv += rev ? tgr : tgp;
 	}
-	if (singular) tv = __builtin_nan("");
-	if (live && act) P.tau[(size_t)r * ld + b] = tv;
+	// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
+	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
+	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
 	if (live && r == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
+	if (live && r == 0 && singular && P.flag_list) P.flag_list[atomicAdd(P.flag_count, 1)] = b;  // work list of the device-side slow path
+	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;                       // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged (then nothing advances: the slow path
 	// launched behind recomputes it from the untouched state, or it stays invalid); the lanes that wrote the shadow rows copy them
 	if (live && !singular) {

@@ -66,22 +66,12 @@ struct WgSmem {
 	int flag2;  // passivity-observer window overflow (status bit 2)
 };
 
+// one control cycle (or one task's model / torque half, CycleParams::single_task) of instance b by the calling workgroup
 template <int NMAX, int T>
-__global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
+__device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSmem<NMAX>& sm) {
 	using SM = WgSmem<NMAX>;
 	constexpr int LD = SM::LD;
-	__shared__ SM sm;
 	const int tid = threadIdx.x;
-	const int b = blockIdx.x;
-	if (b >= P.B) return;
-	if (P.only_flagged && (P.status[b] & 1) == 0) {  // slow-path launch behind the lane / eight-lane kernel (workgroup-uniform); bit 1 = reduced there already
-		// the lane kernel found every task of this instance non-singular: SingularityHandler.cpp:238-244 for the handler states
-		if (tid < P.nt && P.tasks[tid].type == TASK_MOTION_FORCE && P.tasks[tid].sing_strategies && P.tasks[tid].sh) {
-			ShState& st = P.tasks[tid].sh[b];
-			st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
-		}
-		return;
-	}
 	const int n = P.n;
 	const ModelDev& md = *P.model;
 
@@ -291,6 +281,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		int r = 0;           // rank of the task in its range basis
 		bool empty = false;  // JointTask with no controllable dof left
 		bool u_identity = true;
+		bool passthrough = false;  // fully singular motion-force task with the strategies on: N = N_prec, zero torques
 		bool mf_trunc = false;  // this motion-force task acts on the top-r left singular directions only; W[3] = their k x r coordinates
 		bool blend = false;     // this motion-force task has r < k non-singular directions and the blended strategies are on
 		const bool strategies = tk.type == TASK_MOTION_FORCE && tk.sing_handling && tk.sing_strategies && tk.sh;
@@ -348,6 +339,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			{
 				double tr = 0.0;
 				for (int i = 0; i < k; i++) tr += sm.W[1][i * LD + i];
+				const bool nonfinite = !(tr - tr == 0.0);  // NaN or infinite state / goal: trace(Jh Jh^T) is not a number
 				const double itr = 1.0 / tr;
 				double* Ga = sm.W[5];
 				double* Gb = sm.W[6];
@@ -431,9 +423,21 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 								// task (sigma_0 < 1e-3) or sigma_min / sigma_0 < 1e-6 is reported as singular instead
 								double lmin = lmax;
 								for (int i = 0; i < k; i++) lmin = fmin(lmin, sm.W[1][i * LD + i]);
-								if (r == 0 || !(lmin >= 1e-12 * lmax)) sing = true;
-								else blend = true;
+								if (nonfinite) {
+									sing = true;  // non-finite state: refused, never passed through
+								} else if (r == 0) {
+									// fully singular task (sigma_0 < s_abs_tol): passed through like in the reference -- zero torques (:316-317) and
+									// _N = N_prec (:149-151); its classification (garbage directions at this scale) is skipped
+									empty = true;
+									passthrough = true;
+									truncated = true;
+								} else {
+									blend = true;  // (refused further down if a singular value turns out below 1e-10 sigma_0)
+								}
+								(void)lmin;
 							}
+						} else if (nonfinite) {
+							sing = true;  // non-finite state: refused, never reduced or passed through
 						} else if (r < k) {
 							truncated = true;
 							if (r == 0) {
@@ -457,10 +461,8 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				}
 			}
 			if (sing) singular = true;
-			if (strategies && !blend && do_state && tid == 0) {  // no singular directions: SingularityHandler.cpp:238-244
-				ShState& st = tk.sh[b];
-				st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
-			}
+			// (no singular directions: SingularityHandler.cpp:238-244 clears the handler's counters; here they are void by construction
+			// unless the previous cycle was blended too -- ShState::last_cycle -- so nothing is written for such instances)
 			SYNC();
 		} else {
 			const int m = tk.m;
@@ -519,7 +521,8 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					if (s == 0) {
 						c0 = best;
 						if (frob2 < 1e-6) going = false;  // ||Jp||_F < 1e-3: empty range
-						else if (best < 1e-5) { going = false; need_exact = true; }
+						else if (best < 1e-5 || rb == 0) { going = false; need_exact = true; }  // (rb == 0: the host's rank bound assumed full-rank
+						                                                                        // tasks above; one was passed through -- the exact path decides)
 					} else if (going) {
 						const double ratio = best / c0;
 						if (ratio < 1e-20) going = false;
@@ -696,6 +699,10 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			blended = true;
 			const int k = tk.k, ns = r, nsg = k - r;
 			ShState& st = tk.sh[b];
+			if (do_state) {  // counters and window of an instance that had no singular direction in the previous cycle are void (:238-244)
+				if (tid == 0 && st.last_cycle != P.task_cycle[t] - 1) st.ntypes = st.c1 = st.c2 = st.head = st.size = 0;
+				SYNC();
+			}
 			double* tns = sm.Jw;            // Jw is dead once Jb and vw exist: rows 0..4 = tau_ns, tau_s, tau_js, wA, wB
 			double* ts = sm.Jw + LD;
 			double* wA = sm.Jw + 3 * LD;
@@ -712,6 +719,22 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 				int i = e / n, j = e - i * n;
 				Jh[i * LD + j] = sm.W[0][i * LD + j];
 			}
+			SYNC();
+			// singular values of the singular directions from the rows themselves, sigma_c = |u_c^T Jh| (then V_s = row / sigma_c): accurate
+			// down to sigma_c / sigma_0 ~ 1e-10, where the Gram eigenvalue (sigma^2 against lambda_max) has long drowned in rounding noise
+			if (tid >= ns && tid < k) {
+				double s2 = 0.0;
+				for (int j = 0; j < n; j++) s2 = fma(Jh[tid * LD + j], Jh[tid * LD + j], s2);
+				sm.dv[tid] = sqrt(s2);
+			}
+			SYNC();
+			bool too_small = false;  // workgroup-uniform
+			for (int c = ns; c < k; c++)
+				if (!(sm.dv[c] >= 1e-10 * sm.dv[0])) too_small = true;
+			if (too_small) {  // the direction of V_s is not resolved in double precision: refused (status 1), never guessed
+				singular = true;
+				blended = false;
+			} else {
 			const double alpha = fmin(fmax((sm.dv[ns] / sm.dv[0] - tk.s_min) / (tk.s_max - tk.s_min), 0.0), 1.0);  // :114-115
 			double fTd = 0.0;
 			if (do_law) {
@@ -829,6 +852,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					st.size = size;
 					st.c1 = c1;
 					st.c2 = c2;
+					st.last_cycle = P.task_cycle[t];
 				}
 				unsigned dn = st.dir_neg;
 				const bool t1 = (c1 > c2) || tk.sh_force_type1;  // :329
@@ -899,6 +923,7 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 					}
 			}
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Np2, Np);
+			}  // !too_small
 		} else if (!empty && !singular) {
 			osm(Jh, r, true);
 			if (P.diag && tk.diag_N) {
@@ -1014,6 +1039,20 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			Np = Np2;
 			Np2 = t_;
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Nt, Np);
+		} else if (empty && passthrough) {
+			// SingularityHandler.cpp:149-151: _N = N_prec, so the next task is updated with N_prec N_prec (= N_prec up to rounding for the
+			// projectors of a hierarchy)
+			gemm<T>(Np2, LD, Np, LD, 1, Np, LD, 1, n, n, n, tid);
+			SYNC();
+			if (P.diag && tk.diag_N)
+				for (int e = tid; e < n * n; e += T) {
+					int i = e / n, j = e - i * n;
+					tk.diag_N[(size_t)e * P.ld + b] = Np[i * LD + j];
+				}
+			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Np, Np2);
+			double* t_ = Np;
+			Np = Np2;
+			Np2 = t_;
 		} else if (empty) {
 			// no controllable direction left: N = I (JointTask.cpp:234-239), a fully singular reduced motion-force task is passed through
 			if (P.diag && tk.diag_N)
@@ -1033,7 +1072,8 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 		const double nanv = __builtin_nan("");
 		if (tid < n && do_law) {
 			const double tp = P.ext_tau_prec ? P.ext_tau_prec[(size_t)tid * P.ld + b] : 0.0;
-			P.tau[(size_t)tid * P.ld + b] = singular ? nanv : sm.tau[tid] - tp;
+			if (!singular) P.tau[(size_t)tid * P.ld + b] = sm.tau[tid] - tp;
+			else if (P.flag_nan) P.tau[(size_t)tid * P.ld + b] = nanv;  // otherwise the torques stay what they were: the last valid ones are held
 		}
 		if (singular && !do_law)
 			for (int e = tid; e < n * n; e += T) {
@@ -1106,11 +1146,34 @@ __global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
 			}
 			tv += tg;
 		}
-		if (singular) tv = __builtin_nan("");
-		P.tau[(size_t)tid * P.ld + b] = tv;
+		// a flagged instance (status 1) holds its last valid torques unless NaN was asked for (saip_batch_set_flagged_torque_policy)
+		if (!singular) P.tau[(size_t)tid * P.ld + b] = tv;
+		else if (P.flag_nan) P.tau[(size_t)tid * P.ld + b] = __builtin_nan("");
 	}
 	if (tid == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (sm.flag2 ? 4 : 0) | (blended ? 8 : 0));
 	if (!singular) commit_integrators();  // a flagged instance advances nothing, like in the lane / eight-lane kernels
+}
+
+template <int NMAX, int T>
+__global__ void __launch_bounds__(T) saip_cycle_wg(const CycleParams P) {
+	__shared__ WgSmem<NMAX> sm;
+	const int b = blockIdx.x;
+	if (b >= P.B) return;
+	if (P.only_flagged && (P.status[b] & 1) == 0) return;  // status-driven slow path (diagnostic form; the engine uses the list form below)
+	wg_cycle<NMAX, T>(P, b, sm);
+}
+// Device-side slow path behind the lane / eight-lane kernels: a fixed grid strides over the list of instances those kernels could not
+// finish (CycleParams::flag_list).  No host round trip; when the list is empty every workgroup reads the count and leaves.
+template <int NMAX, int T>
+__global__ void __launch_bounds__(T) saip_cycle_wg_list(const CycleParams P) {
+	__shared__ WgSmem<NMAX> sm;
+	int count = *P.flag_count;  // wave-uniform scalar load; written by the kernel launched just before on the same stream
+	count = count < P.B ? count : P.B;
+	for (int i = blockIdx.x; i < count; i += gridDim.x) {
+		const int b = P.flag_list[i];
+		if (b >= 0 && b < P.B) wg_cycle<NMAX, T>(P, b, sm);
+		__syncthreads();  // the next instance reuses the LDS block
+	}
 }
 
 // ---------------------------------------------------------------- reInitializeTask: goal := current pose (one lane per instance)
@@ -1160,6 +1223,15 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 }
 
 // ---------------------------------------------------------------- host-callable launchers
+hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream) {
+	const int grid = P.B < 1024 ? P.B : 1024;
+	if (P.n <= 8) {
+		hipLaunchKernelGGL((saip_cycle_wg_list<8, 64>), dim3(grid), dim3(64), 0, stream, P);
+	} else {
+		hipLaunchKernelGGL((saip_cycle_wg_list<32, 256>), dim3(grid < 256 ? grid : 256), dim3(256), 0, stream, P);
+	}
+	return hipGetLastError();
+}
 hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream) {
 	if (P.n <= 8) {
 		hipLaunchKernelGGL((saip_cycle_wg<8, 64>), dim3(P.B), dim3(64), 0, stream, P);

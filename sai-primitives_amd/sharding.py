@@ -18,6 +18,12 @@ def shard_range(total: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_ld(total: int, world: int) -> int:
+    """common leading dimension of the per-rank [dof][ld] torque slabs: the engine's ld (multiple of 32) of the LARGEST shard, so that
+    all_gather_into_tensor sees identical shapes on every rank even when the shards differ by one instance"""
+    return (-(-total // world) + 31) // 32 * 32
+
+
 def init_process_group(backend: str):
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -27,15 +33,21 @@ def init_process_group(backend: str):
     return dist
 
 
-def gather_torques(tau_local, world: int):
-    """tau_local: torch tensor [dof, ld] (device for nccl, cpu for gloo) -> [world, dof, ld] on every rank"""
+def gather_buffer(tau_local, world: int):
+    """the [world, dof, ld] result buffer of gather_torques (allocate it outside a timed region)"""
     import torch
+    return torch.empty((world,) + tuple(tau_local.shape), dtype=tau_local.dtype, device=tau_local.device)
+
+
+def gather_torques(tau_local, world: int, out=None):
+    """tau_local: torch tensor [dof, ld] (device for nccl, cpu for gloo) -> [world, dof, ld] on every rank.  Every rank's slab must
+    have the same shape: ranks with uneven shards pad to common_ld(total, world) (see shard_ld)."""
     import torch.distributed as dist
-    out = torch.empty((world,) + tuple(tau_local.shape), dtype=tau_local.dtype, device=tau_local.device)
     if world == 1:
-        out[0].copy_(tau_local)
-    else:
-        dist.all_gather_into_tensor(out.view((-1,) + tuple(tau_local.shape[1:])), tau_local.contiguous())  # concat along dim 0
+        return tau_local.unsqueeze(0)  # a gather over one rank is the identity: the engine already wrote the slab, nothing to move
+    if out is None:
+        out = gather_buffer(tau_local, world)
+    dist.all_gather_into_tensor(out.view((-1,) + tuple(tau_local.shape[1:])), tau_local.contiguous())  # concat along dim 0
     return out
 
 

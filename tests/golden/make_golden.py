@@ -1,5 +1,5 @@
 """Generates tests/golden/*.npz: seeded inputs + expected joint torques of the reference hot path,
-computed by the independent NumPy restatement in workloads.py (NOT by the C oracle, NOT by the
+computed by the independent NumPy restatement in oracle/restatement.py (NOT by the C oracle, NOT by the
 product).  The reference itself cannot be built or imported here (C++ needing Eigen3/sai-model/RBDL,
 SURVEY.md 8(c)), so these vectors pin the C oracle against a second restatement, not against the
 reference binary ("parity unpinned", see oracle/saip_oracle.c header).
@@ -13,7 +13,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import workloads as W  # noqa: E402
+import restatement as RS  # noqa: E402  oracle/restatement.py: the NumPy restatement of the reference path (test infrastructure)
 
 # name -> (config id, instances, controller options)
 SCENARIOS = {
@@ -39,7 +41,7 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name, (cfg, B, opts) in SCENARIOS.items():
         d = W.make_inputs(cfg, B)
-        tau, status = W.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"], **opts)
+        tau, status = RS.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"], **opts)
         assert (status != 1).all(), name   # status 2 = task reduced to its non-singular subspace (config 12), 8 = blended strategies (14)
         arrs = dict(cfg=np.int64(cfg), q=d["q"], dq=d["dq"], tau=tau, status=status,
                     gravity_comp=np.bool_(opts.get("gravity_comp", False)),

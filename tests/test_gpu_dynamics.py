@@ -1,11 +1,12 @@
 """Resident forward dynamics + semi-implicit Euler (the step after the path; csrc/saip_dynamics.hip).
 The reference delegates this step to the external sai-simulation (examples/05-...cpp:225-231), so there is no reference arithmetic:
-the oracle is the Lagrangian restatement workloads.forward_dynamics (finite-difference Christoffel terms, no recursion in common
+the oracle is the Lagrangian restatement oracle/restatement.forward_dynamics (finite-difference Christoffel terms, no recursion in common
 with the kernel's Newton-Euler pass), plus energy conservation and the closed-loop behaviour of the reference's example 05."""
 import numpy as np
 import pytest
 
 import workloads as W
+import restatement as RS  # oracle/restatement.py: the NumPy restatement of the reference path (test infrastructure)
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +39,7 @@ def test_one_step_matches_lagrangian_oracle(robot_name, cfg):
         ctrl.synchronize()
         q1, dq1 = ctrl.pullState()
         qdd = (dq1 - dq) / dt
-        ref = W.forward_dynamics(model, d["q"], dq, tau, g=grav, damping=damping)
+        ref = RS.forward_dynamics(model, d["q"], dq, tau, g=grav, damping=damping)
         err = np.abs(qdd - ref).max() / max(1.0, np.abs(ref).max())
         print(robot_name, "gravity", grav, "max rel qdd error", err)
         assert err < 1e-6
@@ -55,11 +56,11 @@ def test_energy_is_conserved_without_torques():
     robot.setQ(d["q"])
     robot.setDq(dq)
     robot.updateModel()
-    E0 = W.total_energy(model, d["q"], dq)
+    E0 = RS.total_energy(model, d["q"], dq)
     ctrl.integrate(2e-5, 5000)      # 0.1 s of free motion under gravity
     ctrl.synchronize()
     q1, dq1 = ctrl.pullState()
-    E1 = W.total_energy(model, q1, dq1)
+    E1 = RS.total_energy(model, q1, dq1)
     drift = np.abs(E1 - E0).max()
     moved = np.abs(q1 - d["q"]).max()
     print("energy drift", drift, "J over 0.1 s; max joint motion", moved, "rad; E0 range", E0.min(), E0.max())
@@ -130,7 +131,7 @@ def test_eight_lane_dynamics_substeps_ragged_batch_and_coasting():
     tz = np.where(np.isnan(tau), 0.0, tau)
     q_ref, dq_ref = d["q"].copy(), dq.copy()
     for _ in range(3):
-        qdd = W.forward_dynamics(model, q_ref, dq_ref, tz, g=grav, damping=damping)
+        qdd = RS.forward_dynamics(model, q_ref, dq_ref, tz, g=grav, damping=damping)
         dq_ref = dq_ref + dt * qdd
         q_ref = q_ref + dt * dq_ref
     err = np.abs(dq1 - dq_ref).max() / np.abs(dq_ref - dq).max()

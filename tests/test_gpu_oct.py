@@ -11,7 +11,14 @@ OCT = 3
 
 def _engine(model_name, tasks, B):
     from sai_primitives_amd.controller import controller_from_specs
-    return controller_from_specs(model_name, tasks, B, device=0)
+    robot, ctrl, objs = controller_from_specs(model_name, tasks, B, device=0)
+    ctrl.setFlaggedTorquePolicy(True)   # tests: an instance the engine refuses (status 1) shows as NaN, like in the oracle (the default holds the last torque)
+    return robot, ctrl, objs
+
+
+def _flagging(spec):
+    """engine extra: the blended singularity strategies switched off -> instances outside the non-singular branch are flagged (status 1)"""
+    return [dict(t, singularity_strategies=False) if t["type"] == "motion_force" else t for t in spec]
 
 
 def _cycle(robot, ctrl, q, dq, goals):
@@ -164,8 +171,8 @@ def test_oct_flags_and_slow_path(cfg):
     assert ctrl.kernelName() == "saip_cycle_oct"
     assert np.array_equal(ctrl.status, st) and (st != 0).sum() > B // 4
     assert W.torque_error(tau, ref) < TOL
-    # default handling: the same instances are flagged, the others are right
-    robot, ctrl, _ = _engine(d["model"].name, W.config_tasks(2), B)
+    # handling enforced with the blended strategies switched off: the same instances are flagged, the others are right
+    robot, ctrl, _ = _engine(d["model"].name, _flagging(W.config_tasks(2)), B)
     ctrl.setKernel(OCT)
     tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert np.array_equal(ctrl.status == 1, st != 0) and np.isnan(tau[st != 0]).all()

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import workloads as W
+import restatement as RS  # oracle/restatement.py: the NumPy restatement of the reference path (test infrastructure)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -17,7 +18,14 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg
 
 def _engine(model_name, tasks, B, **kw):
     from sai_primitives_amd.controller import controller_from_specs
-    return controller_from_specs(model_name, tasks, B, device=0, **kw)
+    robot, ctrl, objs = controller_from_specs(model_name, tasks, B, device=0, **kw)
+    ctrl.setFlaggedTorquePolicy(True)   # tests: an instance the engine refuses (status 1) shows as NaN, like in the oracle (the default holds the last torque)
+    return robot, ctrl, objs
+
+
+def _flagging(spec):
+    """engine extra: the blended singularity strategies switched off -> instances outside the non-singular branch are flagged (status 1)"""
+    return [dict(t, singularity_strategies=False) if t["type"] == "motion_force" else t for t in spec]
 
 
 def _run(robot, ctrl, q, dq, goals):
@@ -131,18 +139,34 @@ def test_hierarchy_property_full_size():
     assert np.abs(acc).max() < 1e-7 * np.abs(tau).max()
 
 
-def test_singular_instances_are_flagged_not_wrong():
+def test_singular_instances_default_blended_and_flagged_when_switched_off():
+    """reference default: an instance inside the singularity bounds runs the blended type-1 / type-2 strategies (status bit 8, valid
+    torques).  With the strategies switched off (engine extra) it is refused: status 1, its torques held (default) or NaN."""
+    from oracle import Oracle
+    from sai_primitives_amd.controller import controller_from_specs
     d = W.make_inputs(2, 64)
     q = d["q"].copy()
     q[5] = np.array([0.0, 0.0, 0.0, -0.0698, 0.0, 0.0, 0.0])  # outstretched arm
     q[17] = np.array([0.3, 0.5, 0.0, -0.08, 0.0, 0.2, 0.0])
-    from oracle import Oracle
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
     tau = _run(robot, ctrl, q, d["dq"], d["goals"])
     ref, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status, st) and st[5] == 8 and (st & 1).sum() == 0
+    assert np.isfinite(tau).all() and W.torque_error(tau, ref) < TOL
+    spec = _flagging(d["tasks"])
+    robot, ctrl, _ = _engine(d["model"].name, spec, 64)
+    tau = _run(robot, ctrl, q, d["dq"], d["goals"])
+    ref, st = Oracle(d["model"], spec).step(q, d["dq"], d["goals"])
     assert np.array_equal(ctrl.status, st) and st[5] == 1
     assert np.isnan(tau[st == 1]).all()
     assert W.torque_error(tau[st == 0], ref[st == 0]) < TOL
+    # default policy: a refused instance keeps the torques of its last valid cycle, nothing is ever NaN
+    robot, ctrl, _ = controller_from_specs(d["model"].name, spec, 64, device=0)
+    tau0 = _run(robot, ctrl, d["q"], d["dq"], d["goals"])          # every instance valid
+    assert ctrl.status.sum() == 0
+    tau1 = _run(robot, ctrl, q, d["dq"], d["goals"])               # instances 5 and 17 refused
+    assert ctrl.status[5] == 1 and ctrl.status[17] == 1
+    assert np.array_equal(tau1[st == 1], tau0[st == 1]) and W.torque_error(tau1[st == 0], ref[st == 0]) < TOL
 
 
 @pytest.mark.parametrize("cfg", [2, 3, 6])
@@ -157,10 +181,12 @@ def test_branch_predicates_on_unfiltered_configurations(cfg):
     model = d["model"]
     rng = np.random.default_rng(100 + cfg)
     q = model.q_lower + (model.q_upper - model.q_lower) * rng.uniform(0.02, 0.98, (B, model.dof))
-    ref, st = Oracle(model, d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    # (a) the blended strategies switched off: the branch predicate alone decides between status 0 and status 1
+    spec = _flagging(d["tasks"])
+    ref, st = Oracle(model, spec).step(q, d["dq"], d["goals"], nthreads=8)
     assert 0 < (st == 1).sum() < B
     for kernel in (0, 1):
-        robot, ctrl, _ = _engine(model.name, d["tasks"], B)
+        robot, ctrl, _ = _engine(model.name, spec, B)
         ctrl.setKernel(kernel)
         tau = _run(robot, ctrl, q, d["dq"], d["goals"])
         differ = np.flatnonzero(ctrl.status != st)
@@ -169,10 +195,25 @@ def test_branch_predicates_on_unfiltered_configurations(cfg):
         err = W.torque_error(tau[st == 0], ref[st == 0])
         print("cfg", cfg, ctrl.kernelName(), "flagged", int((st == 1).sum()), "of", B, "err on the rest", err)
         assert err < TOL
+    # (b) the default configuration (the reference's: handling enforced, blended strategies): EVERY instance gets finite torques equal to
+    # the oracle's, the near-singular ones through the type-1 / type-2 strategies (status bit 8)
+    ref, st = Oracle(model, d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    assert (st & 8).sum() > 0
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(model.name, d["tasks"], B)
+        ctrl.setKernel(kernel)
+        tau = _run(robot, ctrl, q, d["dq"], d["goals"])
+        differ = np.flatnonzero(ctrl.status != st)
+        assert differ.size == 0, (ctrl.kernelName(), differ[:10], ctrl.status[differ[:10]], st[differ[:10]])
+        ok = (st & 1) == 0
+        assert ok.sum() >= B - 2 and np.isfinite(tau[ok]).all()   # (sigma_min / sigma_0 < 1e-6 would be refused: not met by random postures)
+        err = W.torque_error(tau[ok], ref[ok])
+        print("cfg", cfg, ctrl.kernelName(), "default configuration: blended", int((st & 8 != 0).sum()), "of", B, "err", err)
+        assert err < TOL
 
 
 def test_singularity_handling_disabled_full_size():
-    """disableSingularityHandling() (MotionForceTask.h:723): near-singular instances are not flagged any more, the motion-force task
+    """disableSingularityHandling() (MotionForceTask.h:723): near-singular instances are neither blended nor flagged, the motion-force task
     acts on its non-singular subspace (SingularityHandler.cpp:107-115, 146-148, 319-330).  Lane kernel + device-side slow path and
     the general kernel alone against the oracle, 4096 instances of which a third sit inside the blending region; with the handling
     strategy enabled (default) the same instances are flagged."""
@@ -189,7 +230,7 @@ def test_singularity_handling_disabled_full_size():
         err = W.torque_error(tau, ref)
         print("handling disabled, kernel", ctrl.kernelName(), "truncated", int((st == 2).sum()), "err", err)
         assert err < TOL
-    tasks_on = W.config_tasks(2)
+    tasks_on = _flagging(W.config_tasks(2))   # handling enforced, blended strategies switched off
     robot, ctrl, _ = _engine(d["model"].name, tasks_on, B)
     tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert np.array_equal(ctrl.status == 1, st == 2) and np.isnan(tau[st == 2]).all() and np.isfinite(tau[st == 0]).all()
@@ -601,7 +642,7 @@ def test_current_pose_and_goal_reached():
     e = np.linalg.norm(d["goals"][0][:, 0:3] - x, axis=1)
     assert np.array_equal(mf.goalPositionReached(0.04), e < 0.04) and 0 < (e < 0.04).sum() < B
     Rd = d["goals"][0][:, 3:12].reshape(B, 3, 3)
-    dphi = np.array([W.orientation_error(Rd[b], fr[li][0][b]) for b in range(B)])
+    dphi = np.array([RS.orientation_error(Rd[b], fr[li][0][b]) for b in range(B)])
     assert np.array_equal(mf.goalOrientationReached(0.15), np.linalg.norm(dphi, axis=1) < 0.15)
     ctrl.reinitializeTasks()
     assert mf.goalPositionReached(1e-9).all() and mf.goalOrientationReached(1e-9).all() and jt.goalPositionReached(1e-9).all()

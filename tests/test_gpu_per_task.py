@@ -122,8 +122,8 @@ def test_arbitrary_nprec_and_order_contract():
             tau = task.computeTorques()
             Npb = np.broadcast_to(Np, (B, n, n))
             tau_ref, N_ref, Nt_ref, st = orc.task_step(i, d["q"], d["dq"], d["goals"][i], N_prec=Npb)
-            ok = (st & 1) == 0
-            assert ok.sum() > B // 2 and np.array_equal(ok, (task.status & 1) == 0)
+            ok = (st & 1) == 0   # (a motion-force task can land inside the singularity bounds under an arbitrary N_prec: blended, status 8)
+            assert ok.sum() > B // 2 and np.array_equal(st, task.status)
             assert W.torque_error(tau[ok], tau_ref[ok]) < TOL
             assert np.abs(task.getTaskAndPreviousNullspace()[ok] - Nt_ref[ok]).max() < 1e-8
             assert np.isnan(tau[~ok]).all()

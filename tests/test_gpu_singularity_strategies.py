@@ -12,7 +12,14 @@ TOL = 1e-5
 
 def _engine(model_name, tasks, B):
     from sai_primitives_amd.controller import controller_from_specs
-    return controller_from_specs(model_name, tasks, B, device=0)
+    robot, ctrl, objs = controller_from_specs(model_name, tasks, B, device=0)
+    ctrl.setFlaggedTorquePolicy(True)   # tests: an instance the engine refuses (status 1) shows as NaN, like in the oracle (the default holds the last torque)
+    return robot, ctrl, objs
+
+
+def _flagging(spec):
+    """engine extra: the blended singularity strategies switched off -> instances outside the non-singular branch are flagged (status 1)"""
+    return [dict(t, singularity_strategies=False) if t["type"] == "motion_force" else t for t in spec]
 
 
 def _cycle(robot, ctrl, q, dq, goals):
@@ -157,14 +164,18 @@ def test_strategy_gains_forced_type_one_and_posture():
         assert W.torque_error(tau, ref1) < TOL
 
 
-def test_strategies_off_by_default_and_switchable():
-    """the same postures without the strategies are flagged (status 1, NaN); switching them on and off on a live controller"""
+def test_strategies_on_by_default_and_switchable():
+    """the reference default: config 2's tasks as they come run the blended strategies; without them the same postures are flagged
+    (status 1, NaN); switching them off and on on a live controller"""
     from oracle import Oracle
     B = 96
     d = W.make_inputs(14, B)
     spec = W.config_tasks(14)
     ref, st = Oracle(d["model"], spec).step(d["q"], d["dq"], d["goals"], nthreads=8)
     robot, ctrl, tasks = _engine(d["model"].name, W.config_tasks(2), B)
+    tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert np.array_equal(ctrl.status, st) and (st == 8).sum() > B // 4 and W.torque_error(tau, ref) < TOL
+    tasks[0].setSingularityStrategies(False)
     tau = _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert np.array_equal(ctrl.status == 1, st == 8) and np.isnan(tau[st == 8]).all()
     tasks[0].setSingularityStrategies(True)
@@ -243,3 +254,24 @@ def test_arm_driven_into_the_elbow_singularity_under_dynamics():
     assert seen8.all()
     assert worst < TOL
     assert adv.min() > 0.02 and np.abs(dq).max() < 1.0
+
+
+def test_fully_singular_task_is_passed_through():
+    """a motion-force task whose projected Jacobian vanishes (here: the same 6-dof task a second time, in the nullspace of the first)
+    is fully singular (sigma_0 < 1e-3).  With the handling enforced the reference passes it through: zero torques (SingularityHandler.cpp:
+    316-317) and _N = N_prec (:149-151); status bit 2.  Lane kernel + slow path and the general kernel alone against the oracle."""
+    from oracle import Oracle
+    B = 128
+    d = W.make_inputs(2, B)
+    spec = [d["tasks"][0], dict(d["tasks"][0], name="same_task_again"), d["tasks"][1]]
+    goals = [d["goals"][0], d["goals"][0], d["goals"][1]]
+    ref, st = Oracle(d["model"], spec).step(d["q"], d["dq"], goals, nthreads=4)
+    assert (st == 2).all()
+    ref2, _ = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=4)
+    assert W.torque_error(ref, ref2) < 1e-9   # the passed-through task changes nothing
+    for kernel in (0, 1):
+        robot, ctrl, _ = _engine(d["model"].name, spec, B)
+        ctrl.setKernel(kernel)
+        tau = _cycle(robot, ctrl, d["q"], d["dq"], goals)
+        assert np.array_equal(ctrl.status, st), (kernel, ctrl.status[:8])
+        assert W.torque_error(tau, ref) < TOL

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import workloads as W
+import restatement as RS  # oracle/restatement.py: the NumPy restatement of the reference path (test infrastructure)
 from oracle import Oracle
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))
@@ -48,7 +49,7 @@ def test_golden_inputs_reproducible():
 def test_oracle_matches_numpy_fresh_seed(cfg, B):
     d = W.make_inputs(cfg, B, shard=3)  # instances [3B,4B) of the stream: disjoint from the golden ones
     tau, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"])
-    tn, sn = W.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"])
+    tn, sn = RS.controller_step(d["model"], d["tasks"], d["q"], d["dq"], d["goals"])
     assert st.sum() == 0 and sn.sum() == 0
     assert W.torque_error(tau, tn) < 1e-9
 
@@ -104,7 +105,7 @@ def test_E3_full_decoupling_unit_mass_force():
     i = 1
     det = o.details(d["q"][i], d["dq"][i], [d["goals"][0][i]])
     details = []
-    W.controller_step_single(d["model"], tasks, d["q"][i], d["dq"][i], [d["goals"][0][i]], details=details)
+    RS.controller_step_single(d["model"], tasks, d["q"][i], d["dq"][i], [d["goals"][0][i]], details=details)
     F_um = details[0]["F_um"]
     J = details[0]["J"]
     acc = J @ np.linalg.inv(det["M"]) @ det["tau"]
@@ -117,7 +118,7 @@ def test_E4_config1_closed_form():
     o = Oracle(d["model"], d["tasks"])
     det = o.details(d["q"][0], d["dq"][0], [d["goals"][0][0]])
     M = det["M"]
-    Mb = W.bie_mass(M, 0.1)
+    Mb = RS.bie_mass(M, 0.1)
     g = d["goals"][0][0]
     f = -100.0 * (d["q"][0] - g[:7]) - 20.0 * (d["dq"][0] - g[7:14])
     assert np.allclose(det["tau"], M @ g[14:21] + Mb @ f, rtol=1e-12, atol=1e-12)
@@ -171,14 +172,19 @@ def test_E7_jacobian_finite_difference_and_kinetic_energy():
     assert abs(0.5 * dq @ det["M"] @ dq - T) < 1e-7 * max(T, 1.0)
 
 
-def test_singular_pose_is_flagged():
-    """outstretched arm (q4 ~ 0): the motion-force task leaves the non-singular branch
-    (SingularityHandler.cpp:100-121) -> status 1, NaN torques (no silent wrong numbers)."""
+def test_singular_pose_is_blended_by_default_and_flagged_without_the_strategies():
+    """outstretched arm (q4 ~ 0): the motion-force task leaves the non-singular branch (SingularityHandler.cpp:100-121).  Reference
+    default: blended type-1 / type-2 strategies (status bit 8, valid torques, both restatements agree); with the strategies switched
+    off (engine extra) -> status 1, NaN torques (no silent wrong numbers)."""
     d = W.make_inputs(2, 2)
     q = d["q"].copy()
     q[0] = np.array([0.0, 0.0, 0.0, -0.0698, 0.0, 0.0, 0.0])
     tau, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"])
-    _, sn = W.controller_step(d["model"], d["tasks"], q, d["dq"], d["goals"])
+    tn, sn = RS.controller_step(d["model"], d["tasks"], q, d["dq"], d["goals"])
+    assert st[0] == 8 and sn[0] == 8 and np.isfinite(tau).all() and W.torque_error(tau, tn) < 1e-9
+    off = [dict(t, singularity_strategies=False) if t["type"] == "motion_force" else t for t in d["tasks"]]
+    tau, st = Oracle(d["model"], off).step(q, d["dq"], d["goals"])
+    _, sn = RS.controller_step(d["model"], off, q, d["dq"], d["goals"])
     assert st[0] == 1 and sn[0] == 1 and np.isnan(tau[0]).all()
     assert st[1] == 0 and np.isfinite(tau[1]).all()
 
@@ -193,7 +199,7 @@ def test_integrators_advance_like_reference():
     states = [[dict(int_pos=np.zeros(3), int_ori=np.zeros(3)), dict(int_err=np.zeros(7))] for _ in range(4)]
     for _ in range(3):
         tau, _ = o.step(d["q"], d["dq"], d["goals"])
-        ref = np.stack([W.controller_step_single(d["model"], tasks, d["q"][b], d["dq"][b], [g[b] for g in d["goals"]],
+        ref = np.stack([RS.controller_step_single(d["model"], tasks, d["q"][b], d["dq"][b], [g[b] for g in d["goals"]],
                                                  state=states[b]) for b in range(4)])
         assert W.torque_error(tau, ref) < 1e-9
 
@@ -214,7 +220,7 @@ def test_blended_singularity_strategies_c_vs_numpy_over_cycles():
         tn, sn = np.zeros_like(q), np.zeros(B, np.uint8)
         for b in range(B):
             info = {}
-            tn[b] = W.controller_step_single(model, tasks, q[b], d["dq"][b], [g[b] for g in d["goals"]], state=states[b], info=info)
+            tn[b] = RS.controller_step_single(model, tasks, q[b], d["dq"][b], [g[b] for g in d["goals"]], state=states[b], info=info)
             sn[b] = 8 if info.get("blended") else 0
             sh = states[b][0].get("sh")
             if sh is not None and sh["ntypes"]:
@@ -232,7 +238,7 @@ def test_singularity_strategy_options_c_vs_numpy():
     d = W.make_inputs(14, B)
     tasks = W.config_tasks(14)
     tasks[0].update(sh_gains=(35.0, 9.0, 2.5), sh_all_type1=True)
-    tn, sn = W.controller_step(d["model"], tasks, d["q"], d["dq"], d["goals"])
+    tn, sn = RS.controller_step(d["model"], tasks, d["q"], d["dq"], d["goals"])
     to, so = Oracle(d["model"], tasks).step(d["q"], d["dq"], d["goals"])
     assert np.array_equal(sn, so) and (so == 8).sum() >= B // 3
     assert W.torque_error(to, tn) < 1e-9

@@ -21,6 +21,25 @@ def _free_port():
     return p
 
 
+def _worker_uneven(rank, world, port, total, out_dir):
+    """shards that differ by one instance: every rank pads its slab to sharding.shard_ld(total, world) so that the collective sees equal shapes"""
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from sai_primitives_amd import sharding
+    dist = sharding.init_process_group("gloo")
+    lo, hi = sharding.shard_range(total, world, rank)
+    ld = sharding.shard_ld(total, world)
+    slab = torch.zeros((7, ld), dtype=torch.float64)
+    slab[:, :hi - lo] = torch.arange(lo, hi, dtype=torch.float64)[None, :] + 1000.0 * torch.arange(7, dtype=torch.float64)[:, None]
+    gathered = sharding.gather_torques(slab, world, out=sharding.gather_buffer(slab, world))
+    np.save(os.path.join(out_dir, f"uneven_{rank}.npy"), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, per_rank, out_dir):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -66,6 +85,19 @@ def test_two_rank_shards_and_gather(tmp_path):
         lo, hi = sharding.shard_range(world * per_rank, world, r)
         assert (lo, hi) == (r * per_rank, (r + 1) * per_rank)
         assert np.array_equal(g0[r][:, :per_rank].T, ref[lo:hi])
+
+
+def test_uneven_shards_gather(tmp_path):
+    import torch.multiprocessing as mp
+    from sai_primitives_amd import sharding
+    world, total = 2, 65                                 # 33 + 32 instances: engine ld 64 and 32, common ld 64
+    assert sharding.shard_ld(total, world) == 64 and sharding.shard_ld(65536, 8) == 8192 and sharding.shard_ld(5, 8) == 32
+    mp.spawn(_worker_uneven, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(tmp_path / "uneven_0.npy")
+    assert np.array_equal(g, np.load(tmp_path / "uneven_1.npy")) and g.shape == (2, 7, 64)
+    for r in range(world):
+        lo, hi = sharding.shard_range(total, world, r)
+        assert np.array_equal(g[r][3, :hi - lo], np.arange(lo, hi) + 3000.0)
 
 
 def test_shard_range_covers_everything_once():
