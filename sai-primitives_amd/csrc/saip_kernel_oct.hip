@@ -616,7 +616,14 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	__syncthreads();
 	STAMP(8);
 	double lam[6], lmod[6];
-	{
+	// headline stack (GJ == 0): nobody needs Lambda itself, only its action on three vectors -- every lane keeps the Cholesky factor of
+	// A = J M^-1 J^T and solves (no row of the inverse, no exchange of Lambda between the lanes)
+	double L6[6][6], dinv6[6];
+	if (GJ == 0) {
+		UNR for (int i = 0; i < 6; i++)
+			UNR for (int j = 0; j <= i; j++) L6[i][j] = sm.A[i][j];
+		oct_cholesky<6>(L6, dinv6);
+	} else {
 		double L[6][6], dinv[6];
 		UNR for (int i = 0; i < 6; i++)
 			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.A[i][j];
@@ -650,8 +657,11 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int c = 0; c < 6; c++) lmod[c] = fma(gamma * lt_own, lt[c], lam[c]);
 		}
 	}
-	UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
+	if (GJ != 0) {
+		UNR for (int c = 0; c < 6; c++) sm.Lam[r][c] = lam[c];
+	}
 	STAMP(9);
+	double Fum6[6], Ff6[6] = {0, 0, 0, 0, 0, 0};  // GJ == 0: the task forces, identical in every lane of the instance
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
 	{
@@ -671,6 +681,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int e = 0; e < 6; e++) G30[24 + e] = sm.vec[5][e];
 			law_motion_force_general<false>(&mf, vw, pw, Rc, G30, ip, io, (double*)nullptr, Fum, Ff);
 			UNR for (int a = 0; a < 6; a++) Ffa = (a == ra) ? Ff[a] : Ffa;
+			UNR for (int a = 0; a < 6; a++) Ff6[a] = Ff[a];
 		} else if (FULL && !mf.bm_identity) {
 			// partial task: the short law with its projections (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0), then
 			// F in the basis of range(P): fhat = Bm^T F_um
@@ -731,18 +742,142 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 			UNR for (int a = 0; a < 6; a++) Fum[a] = fh[a];
 		}
-		// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
-		double s = Ffa;
-		UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
-		sm.vec[2][r] = s;
+		if (GJ == 0) {
+			UNR for (int a = 0; a < 6; a++) Fum6[a] = Fum[a];
+		} else {
+			// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
+			double s = Ffa;
+			UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
+			sm.vec[2][r] = s;
+		}
 	}
-	__syncthreads();
+	if (GJ != 0) __syncthreads();
 	STAMP(10);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
 	// basis works on), N1[i][rr] = d_i,rr - sum_a T1[a][i] (Lambda J[:, rr])_a, and parks it as a row of the transposed matrix
 	double tau_r;
 	double cj[N];  // column rr of N_1
 	double cn = 0.0;
+	double tv;
+	if (GJ == 0) {
+		// ---- headline stack: full 6-dof task + full joint task.  g = Lambda_mod F_um + F_f by solves with the factor of A: FULL g = A^-1 F;
+		// bounded inertia estimates with one clamped entry (A_mod = A - beta t t^T, t = J m): Sherman-Morrison on the solves,
+		// g = y1 + gamma y2 (t . y1), y1 = A^-1 F, y2 = A^-1 t, gamma = beta / (1 - beta t . y2); several clamped entries: A_mod is
+		// factored too.  tau_1 = J^T g in full in every lane (the joint task's disturbance compensation wants M^-1 tau_1).
+		double g[6];
+		if (mf.decoupling == DEC_IMPEDANCE) {
+			UNR for (int a = 0; a < 6; a++) g[a] = Fum6[a] + Ff6[a];
+		} else if (mf.decoupling == DEC_BIE && general_bie) {
+			double Lb[6][6], dinvb[6], y[6];
+			UNR for (int i = 0; i < 6; i++)
+				UNR for (int j = 0; j <= i; j++) Lb[i][j] = sm.Am[i][j];
+			oct_cholesky<6>(Lb, dinvb);
+			oct_solve<6>(Lb, dinvb, Fum6, y);
+			UNR for (int a = 0; a < 6; a++) g[a] = y[a] + Ff6[a];
+		} else {
+			double y1[6];
+			oct_solve<6>(L6, dinv6, Fum6, y1);
+			if (mf.decoupling == DEC_BIE) {  // rank-one form (beta = 0 when nothing is clamped)
+				double t[6], y2[6], ty1 = 0.0, ty2 = 0.0;
+				UNR for (int a = 0; a < 6; a++) {
+					double sacc = 0.0;
+					UNR for (int l = 0; l < N; l++) sacc = fma(Jf[a][l], mcol[l], sacc);
+					t[a] = sacc;
+				}
+				oct_solve<6>(L6, dinv6, t, y2);
+				UNR for (int a = 0; a < 6; a++) {
+					ty1 = fma(t[a], y1[a], ty1);
+					ty2 = fma(t[a], y2[a], ty2);
+				}
+				const double gamma = beta * oct_rcp(fma(-beta, ty2, 1.0));
+				UNR for (int a = 0; a < 6; a++) g[a] = fma(gamma * ty1, y2[a], y1[a]) + Ff6[a];
+			} else {
+				UNR for (int a = 0; a < 6; a++) g[a] = y1[a] + Ff6[a];
+			}
+		}
+		double tau1[N], wr = 0.0;
+		UNR for (int j = 0; j < N; j++) {
+			double s = 0.0;
+			UNR for (int a = 0; a < 6; a++) s = fma(Jf[a][j], g[a], s);
+			tau1[j] = s;
+			wr = fma(mi[j], s, wr);  // (M^-1 tau_prec)_rr: M^-1 symmetric, mi = its column rr
+		}
+		tau_r = 0.0;
+		UNR for (int j = 0; j < N; j++) tau_r = (j == rr) ? tau1[j] : tau_r;
+		// ---- JointTask (S = I) in the nullspace of the 6-dof task, JointTask.cpp:218-356.  N_1 = I - M^-1 J^T Lambda J has rank one:
+		// N_1 = z z^T M / (z^T M z), z spanning null(J).  Its ROW rr, e_rr - J^T (A^-1 t1c) with t1c = this lane's column of T1 = J M^-1,
+		// needs nothing from the other lanes and is z_rr (M z)^T / (z^T M z).  The row of largest norm (largest |z_rr|) is broadcast:
+		// v ~ M z, then z'_rr = (M^-1 v)_rr from this lane's column of M^-1.  With the range basis U = z' / |z'| (matrixRangeBasis of
+		// Jp = N_1, one direction) the task reduces to scalars: Jh = U^T Jp = v^T / (|z'| s'), Lambda = (Jh M^-1 Jh^T)^-1 = z'.v / |z'|^2, and
+		//   tau_joint = Jh^T (Lambda a1 + Lambda_mod b1) = v / |z'|^2 (z'.a + rho z'.f),   a = ddq_d - M^-1 tau_prec, f = the PD(I) force,
+		// rho = Lambda_mod / Lambda: 1 (full decoupling), |z'|^2 / z'.v (impedance), z'.v / (z'.v - beta z'_e^2) (bounded inertia, one
+		// clamped entry e: M_BIE^-1 = M^-1 - beta m m^T and m^T M z' = z'_e), z'.v / (v^T M_BIE^-1 v) (several clamped entries).
+		double x6[6], rowv[N], nr = 0.0;
+		oct_solve<6>(L6, dinv6, t1c, x6);
+		UNR for (int j = 0; j < N; j++) {
+			double acc = (j == rr) ? 1.0 : 0.0;
+			UNR for (int a = 0; a < 6; a++) acc = fma(-Jf[a][j], x6[a], acc);
+			rowv[j] = acc;
+			nr = fma(acc, acc, nr);
+		}
+		double bestw = act ? nr : -1.0;
+		int jbw = r;
+#define OCT_ARGMAX_STEP(CTRL)                                                                                   \
+	{                                                                                                           \
+		const double ob = oct_dpp<CTRL>(bestw);                                                                 \
+		const int oj = __builtin_amdgcn_update_dpp(0, jbw, CTRL, 0xF, 0xF, true);                               \
+		const bool take = ob > bestw || (ob == bestw && oj < jbw);                                              \
+		bestw = take ? ob : bestw;                                                                              \
+		jbw = take ? oj : jbw;                                                                                  \
+	}
+		OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
+		OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
+		OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+#undef OCT_ARGMAX_STEP
+		const int src = (lane & ~7) | jbw;
+		double v[N], zr = 0.0, v_own = 0.0;
+		UNR for (int j = 0; j < N; j++) {
+			v[j] = __shfl(rowv[j], src);
+			zr = fma(mi[j], v[j], zr);
+			v_own = (j == rr) ? v[j] : v_own;
+		}
+		zr = act ? zr : 0.0;
+		// control law of this lane's joint (JointTask.cpp:299-345)
+		const bool track = (jt.has_ki || P.integ_always);
+		const double e = q_r - jg_q;
+		double ie = 0.0;
+		if (track) ie = jt.integ[(size_t)rr * ld + b];
+		ie += e * jt.dt;  // :323-324
+		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
+		double fi;
+		if (jt.vel_sat) {  // :327-341
+			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
+			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
+			fi = -jt.kv[rr] * (dq_r - vdes);
+		} else {
+			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
+		}
+		const double ai = jg_ddq - wr;
+		const double zz = oct_group_sum(zr * zr);
+		const double zv = oct_group_sum(zr * v_own);
+		const double za = oct_group_sum(zr * ai);
+		const double zf = oct_group_sum(zr * fi);
+		double rho = 1.0;
+		if (jt.decoupling == DEC_IMPEDANCE) {
+			rho = zz * oct_rcp(zv);
+		} else if (jt.decoupling == DEC_BIE) {
+			if (general_bie) {
+				double mbv = 0.0;
+				UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], v[j], mbv);  // (M_BIE^-1 v)_rr
+				const double qb = oct_group_sum(act ? v_own * mbv : 0.0);
+				rho = zv * oct_rcp(qb);
+			} else {
+				const double ze = oct_group_sum((act && r == eclamp) ? zr : 0.0);
+				rho = zv * oct_rcp(fma(-beta * ze, ze, zv));
+			}
+		}
+		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
+	} else {
 	{
 		double g[6], t3[6], jc[6];
 		UNR for (int a = 0; a < 6; a++) {
@@ -771,7 +906,6 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// motion-force task.  Lane j holds column j of Jp = S N_1 (m x 7).  Left singular vectors / squared singular values of Jp = eigen-pairs
 	// of its 4 x 4 Gram matrix (sums over the lanes by DPP), by an unrolled Jacobi solve in registers; matrixRangeBasis keeps the directions
 	// with sigma_i / sigma_0 >= 1e-3 (JointTask.cpp:233); the rest of the task algebra is r x r with dropped directions padded.
-	double tv;
 	if (GJ == 1) {
 		double cp[4];
 		UNR for (int i = 0; i < 4; i++) {
@@ -1050,129 +1184,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			tj = fma(jh[c], (c < rank) ? gc : 0.0, tj);
 		}
 		tv = tj;
-	} else {
-	// ---------------------------------------------------------------- JointTask (S = I): range basis of Jp = N_1 (rank <= 1), JointTask.cpp:218-283
-	sm.vec[3][r] = act ? cn : -1.0;
-	__syncthreads();
-	double best = -1.0, frob2 = 0.0;
-	int jb = 0;
-	UNR for (int j = 0; j < N; j++) {
-		const double c = sm.vec[3][j];
-		frob2 += c;
-		if (c > best) {
-			best = c;
-			jb = j;
-		}
 	}
-	STAMP(12);
-	bool empty = false, need_exact = false;
-	if (frob2 < 1e-6) empty = true;  // ||Jp||_F < 1e-3: empty range (matrixRangeBasis)
-	else if (best < 1e-5) need_exact = true;
-	double u[N], d_r, u_own;
-	{
-		const double inv = oct_rsqrt(best);
-		u_own = sm.N1[jb][rr] * inv;
-		double dd = 0.0;
-		UNR for (int i = 0; i < N; i++) {
-			u[i] = sm.N1[jb][i] * inv;
-			dd = fma(u[i], cj[i], dd);
-		}
-		d_r = dd;  // (u^T Jp)_rr: the row of Jh = U^T Jp
-		double c2 = 0.0;
-		UNR for (int i = 0; i < N; i++) {
-			const double wv = fma(-u[i], d_r, cj[i]);
-			c2 = fma(wv, wv, c2);
-		}
-		const double best2 = oct_group_max(act ? c2 : -1.0);
-		if (!empty && !need_exact && !(best2 < 1e-20 * best)) need_exact = true;  // not numerically rank one: the exact path decides
-	}
-#if defined(SAIP_OCT_FORCE_EXACT)
-	need_exact = !empty;
-#endif
-	if (__any(need_exact)) {  // exact path (rare): Gram eigen-decomposition with the reference's tolerances, one lane per instance
-		if (need_exact && r == 0) {
-			double* Gm = &sm.Gx[0][0];
-			double* Vm = &sm.T1[0][0];  // 64 doubles over T1 / A: dead by now
-			double trc = 0.0;
-			for (int a = 0; a < N; a++)
-				for (int c = 0; c < N; c++) {
-					double s = 0.0;
-					for (int j = 0; j < N; j++) s = fma(sm.N1[j][a], sm.N1[j][c], s);  // (Jp Jp^T)_ac from the transposed storage
-					Gm[a * 8 + c] = s;
-					if (a == c) trc += s;
-				}
-			oct_serial_jacobi(Gm, Vm, N, 8);
-			double lmax = 0.0;
-			for (int i = 0; i < N; i++) lmax = fmax(lmax, Gm[i * 8 + i]);
-			int cnt = 0, col = 0;
-			if (sqrt(fmax(trc, 0.0)) >= 1e-3 && sqrt(lmax) >= 1e-3)
-				for (int i = 0; i < N; i++)
-					if (sqrt(fmax(Gm[i * 8 + i], 0.0) / lmax) >= 1e-3) {
-						if (cnt == 0) col = i;
-						cnt++;
-					}
-			sm.vec[9][1] = (double)cnt;
-			for (int i = 0; i < N; i++) sm.vec[7][i] = cnt ? Vm[i * 8 + col] : 0.0;
-		}
-		__syncthreads();
-		if (need_exact) {
-			const int cnt = (int)sm.vec[9][1];
-			if (cnt > 1) singular = true;  // cannot happen while the motion-force task has rank 6; never silently truncate
-			empty = cnt == 0;
-			double dd = 0.0;
-			UNR for (int i = 0; i < N; i++) {
-				u[i] = sm.vec[7][i];
-				dd = fma(u[i], cj[i], dd);
-			}
-			d_r = dd;
-			u_own = sm.vec[7][rr];
-		}
-		__syncthreads();
-	}
-	sm.vec[8][r] = d_r;
-	__syncthreads();
-	STAMP(13);
-	// ---- Lambda (1 x 1), control law of this lane's joint, disturbance compensation (JointTask.cpp:285-356)
-	double g_jt = 0.0;
-	{
-		double dv[N], tauv[N];
-		UNR for (int j = 0; j < N; j++) {
-			dv[j] = sm.vec[8][j];
-			tauv[j] = sm.vec[1][j];
-		}
-		double t1 = 0.0, tb = 0.0, wr = 0.0, dm = 0.0;
-		UNR for (int l = 0; l < N; l++) {
-			t1 = fma(dv[l], mi[l], t1);   // (Jh M^-1)_rr  (M^-1 symmetric: row rr = column rr)
-			tb = fma(dv[l], mb[l], tb);   // general M_BIE path only (mb = mi otherwise)
-			dm = fma(dv[l], mcol[l], dm); // Jh m, rank-one M_BIE path
-			wr = fma(mi[l], tauv[l], wr); // (M^-1 tau_prec)_rr
-		}
-		const bool track = (jt.has_ki || P.integ_always);
-		const double e = q_r - jg_q;
-		double ie = 0.0;
-		if (track) ie = jt.integ[(size_t)rr * ld + b];
-		ie += e * jt.dt;  // :323-324
-		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
-		double fi;
-		if (jt.vel_sat) {  // :327-341
-			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
-			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
-			fi = -jt.kv[rr] * (dq_r - vdes);
-		} else {
-			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
-		}
-		const double ai = jg_ddq - wr;
-		const double A1 = oct_group_sum(act ? t1 * d_r : 0.0);
-		double Ab = general_bie ? oct_group_sum(act ? tb * d_r : 0.0) : 0.0;
-		const double a1 = oct_group_sum(act ? u_own * ai : 0.0);
-		const double b1 = oct_group_sum(act ? u_own * fi : 0.0);
-		const double Lam1 = oct_rcp(A1);
-		if (!general_bie) Ab = fma(-beta * dm, dm, A1);  // Jh M_BIE^-1 Jh^T = Jh M^-1 Jh^T - beta (Jh m)^2
-		const double Lmod1 = (jt.decoupling == DEC_FULL) ? Lam1 : ((jt.decoupling == DEC_IMPEDANCE) ? 1.0 : oct_rcp(Ab));
-		g_jt = empty ? 0.0 : fma(Lam1, a1, Lmod1 * b1);  // :348-351
-	}
-	tv = empty ? tau_r : fma(d_r, g_jt, tau_r);  // tau += Jh^T g
-	}
+	}  // GJ != 0
 	STAMP(14);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {

@@ -74,4 +74,20 @@ __device__ __forceinline__ void oct_solve_unit(const double (&L)[R][R], const do
 	}
 }
 
+// x = (L L^T)^-1 b for any right-hand side held by the lane
+template <int R>
+__device__ __forceinline__ void oct_solve(const double (&L)[R][R], const double (&dinv)[R], const double (&b)[R], double (&x)[R]) {
+	double y[R];
+	UNR for (int i = 0; i < R; i++) {
+		double s = b[i];
+		UNR for (int k = 0; k < i; k++) s = fma(-L[i][k], y[k], s);
+		y[i] = s * dinv[i];
+	}
+	UNR for (int i = R - 1; i >= 0; i--) {
+		double s = y[i];
+		UNR for (int k = i + 1; k < R; k++) s = fma(-L[k][i], x[k], s);
+		x[i] = s * dinv[i];
+	}
+}
+
 }  // namespace saip
