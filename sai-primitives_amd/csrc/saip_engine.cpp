@@ -1412,7 +1412,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	if (!diag && b->kernel_choice == 2) return fail(SAIP_ERR_UNSUPPORTED, "the lane-per-instance kernel does not cover this robot/task stack");
 	hipError_t e = saip::launch_cycle_wg(P, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
-	b->kernel_name = P.n <= 8 ? "saip_cycle_wg<8,64>" : "saip_cycle_wg<32,256>";
+	b->kernel_name = P.n <= 8 ? "saip_cycle_wg<8,64>" : "saip_cycle_wg<32,512>";
 	return SAIP_OK;
 }
 

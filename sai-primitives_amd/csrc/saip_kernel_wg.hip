@@ -23,6 +23,7 @@
 //     orthonormal basis of range(Jp), so the basis of range(P) is used directly.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "saip_device.h"
 #include "saip_law.h"
@@ -360,18 +361,25 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 					for (int j = 0; j < k; j++) t8 = fma(Ga[i * LD + j], Ga[i * LD + j], t8);
 				const double u = sqrt(sqrt(sqrt(t8)));
 				const bool ok_s0 = (u * tk.cert_kroot * tr >= tk.s_abs_tol * tk.s_abs_tol);
-				if (tid == 0) {  // LDL^T of Gs - shift I, in place in Gb (k <= 6: serial)
+				if (tid == 0) {  // LDL^T of Gs - shift I (k <= 6: one thread, in registers; rows >= k padded with the identity)
 					const double shift = tk.s_max * tk.s_max * u;
-					for (int i = 0; i < k; i++)
-						for (int j = 0; j <= i; j++) Gb[i * LD + j] = sm.W[1][i * LD + j] * itr - (i == j ? shift : 0.0);
+					double Gs[6][6];
+#pragma unroll
+					for (int i = 0; i < 6; i++)
+#pragma unroll
+						for (int j = 0; j <= i; j++)
+							Gs[i][j] = (i < k) ? sm.W[1][i * LD + j] * itr - (i == j ? shift : 0.0) : (i == j ? 1.0 : 0.0);
 					int pos = 1;
-					for (int kk = 0; kk < k; kk++) {
-						const double d = Gb[kk * LD + kk];
+#pragma unroll
+					for (int kk = 0; kk < 6; kk++) {
+						const double d = Gs[kk][kk];
 						if (!(d > 1e-13)) pos = 0;
 						const double id = 1.0 / d;
-						for (int i = kk + 1; i < k; i++) {
-							const double lik = Gb[i * LD + kk] * id;
-							for (int j = kk + 1; j <= i; j++) Gb[i * LD + j] = fma(-lik, Gb[j * LD + kk], Gb[i * LD + j]);
+#pragma unroll
+						for (int i = kk + 1; i < 6; i++) {
+							const double lik = Gs[i][kk] * id;
+#pragma unroll
+							for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
 						}
 					}
 					sm.flag = (pos && ok_s0 && tr > 0.0) ? 1 : 0;
@@ -925,7 +933,9 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Np2, Np);
 			}  // !too_small
 		} else if (!empty && !singular) {
-			osm(Jh, r, true);
+			// the nullspace of the last task of a hierarchy feeds nothing (unless somebody asked to see it)
+			const bool need_N = (t + 1 < t_last) || (P.diag && tk.diag_N) || P.out_N || P.out_Ntot;
+			osm(Jh, r, need_N);
 			if (P.diag && tk.diag_N) {
 				for (int e = tid; e < n * n; e += T) {
 					int i = e / n, j = e - i * n;
@@ -1033,11 +1043,13 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 					sm.tau[j] += s;
 				}
 			// N_prec <- N N_prec   (getTaskAndPreviousNullspace)
-			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);
-			SYNC();
-			double* t_ = Np;
-			Np = Np2;
-			Np2 = t_;
+			if (need_N) {
+				gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);
+				SYNC();
+				double* t_ = Np;
+				Np = Np2;
+				Np2 = t_;
+			}
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Nt, Np);
 		} else if (empty && passthrough) {
 			// SingularityHandler.cpp:149-151: _N = N_prec, so the next task is updated with N_prec N_prec (= N_prec up to rounding for the
@@ -1228,7 +1240,7 @@ hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream) {
 	if (P.n <= 8) {
 		hipLaunchKernelGGL((saip_cycle_wg_list<8, 64>), dim3(grid), dim3(64), 0, stream, P);
 	} else {
-		hipLaunchKernelGGL((saip_cycle_wg_list<32, 256>), dim3(grid < 256 ? grid : 256), dim3(256), 0, stream, P);
+		hipLaunchKernelGGL((saip_cycle_wg_list<32, 512>), dim3(grid < 256 ? grid : 256), dim3(512), 0, stream, P);
 	}
 	return hipGetLastError();
 }
@@ -1236,7 +1248,11 @@ hipError_t launch_cycle_wg(const CycleParams& P, hipStream_t stream) {
 	if (P.n <= 8) {
 		hipLaunchKernelGGL((saip_cycle_wg<8, 64>), dim3(P.B), dim3(64), 0, stream, P);
 	} else {
-		hipLaunchKernelGGL((saip_cycle_wg<32, 256>), dim3(P.B), dim3(256), 0, stream, P);
+		// eight wavefronts per instance (two per SIMD: the LDS block allows one workgroup per CU, so the second wavefront of a SIMD is
+		// the only latency hiding there is): 2.33 ms per 4096-instance launch of config 5 against 2.47 ms with four (SAIP_WG_T256=1)
+		static const bool t256 = getenv("SAIP_WG_T256") != nullptr;
+		if (t256) hipLaunchKernelGGL((saip_cycle_wg<32, 256>), dim3(P.B), dim3(256), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_wg<32, 512>), dim3(P.B), dim3(512), 0, stream, P);
 	}
 	return hipGetLastError();
 }

@@ -19,10 +19,10 @@ typedef double saip_f64x4 __attribute__((ext_vector_type(4)));
 template <int T>
 __device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ars, int acs, const double* Bm, int brs, int bcs,
 									 int m, int k, int p, int tid, int mode = GEMM_SET) {
-	if (T == 256 && m * p >= 128) {
+	if (T >= 256 && m * p >= 128) {
 		const int wave = tid >> 6, lane = tid & 63;
 		const int r0 = 16 * (wave >> 1), c0 = 16 * (wave & 1);
-		if (r0 < m && c0 < p) {  // wave-uniform
+		if (wave < 4 && r0 < m && c0 < p) {  // wave-uniform
 			saip_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 			const int ar = r0 + (lane & 15), bc = c0 + (lane & 15), kq = lane >> 4;
 			for (int kk = 0; kk < k; kk += 4) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ar
 // fixed across pivots and computed once.
 template <int T>
 __device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double* WX, double* /*dv*/, int n, int ld, int tid) {
-	constexpr int EPT = (T == 64) ? 1 : 4;
+	constexpr int EPT = (T == 64) ? 1 : (T == 256 ? 4 : 2);
 	int ei[EPT], ej[EPT];
 	for (int r = 0; r < EPT; r++) {
 		const int e = tid + r * T;

@@ -62,7 +62,7 @@ def test_engine_matches_golden(path, kernel):
     assert err < TOL
 
 
-@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 4096), (5, 512), (6, 256), (9, 1024), (10, 1024)])
+@pytest.mark.parametrize("cfg,B", [(2, 4096), (3, 4096), (5, 4096), (6, 256), (9, 1024), (10, 1024)])
 def test_engine_matches_oracle_full_size(cfg, B):
     from oracle import Oracle
     d = W.make_inputs(cfg, B)
