@@ -101,17 +101,40 @@ def main():
     robot.updateModel()
     ctrl.setGoals(d["goals"])
 
+    # the final gather is the engine's own (C++ on RCCL, csrc/saip_comm.cpp); torch.distributed is the rendezvous (unique id, barrier,
+    # max over ranks) and the fallback if the native communicator cannot be set up
+    native, gather_kind = None, "none (one rank)"
+    if world > 1:
+        ok_native = 1.0
+        try:
+            native = sharding.NativeGather(ctrl, world, rank, local_rank, dev)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: native RCCL gather unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+            ok_native = 0.0
+        if sharding.max_over_ranks(1.0 - ok_native, dev) != 0.0:   # all ranks or none
+            if native is not None:
+                native.close()
+            native = None
+        gather_kind = "engine: ncclAllGather (RCCL) on the engine stream" if native is not None else "torch.distributed all_gather_into_tensor (RCCL)"
+
+    def final_gather():
+        if native is not None:
+            native.gather(gather_out)
+            ctrl.synchronize()
+            return gather_out
+        return sharding.gather_torques(tau_t, world, out=gather_out)
+
     # untimed warmup: W cycles, and one gather so that the collective's first-use costs (communicator setup, lazy kernel loading:
     # 0.2 ms and more) do not land in the timed region
     ctrl.timeSteps(max(args.warmup, 1), 0)
-    sharding.gather_torques(tau_t, world, out=gather_out)
+    final_gather()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_ms = ctrl.timeSteps(args.steps, 0)              # K launches on the engine stream, HIP events around them
-    gathered = sharding.gather_torques(tau_t, world, out=gather_out)   # the final torque gather (RCCL all_gather for world > 1)
+    gathered = final_gather()                          # the final torque gather (one RCCL all-gather for world > 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,7 +194,7 @@ def main():
             "config": {"workload": f"config {args.config}: {W.CONFIGS[args.config]['desc']}", "batch_per_gpu": B,
                        "global_batch": B * world, "robot": d["model"].name, "dof": n,
                        "tasks": [t["name"] for t in d["tasks"]], "parallelism": f"instances sharded x{world}, no data-path collective, "
-                       "one final torque all_gather", "kernel": ctrl.kernelName()},
+                       "one final torque all_gather", "gather": gather_kind, "kernel": ctrl.kernelName()},
             "roofline": {"bound": "mfma", "note": "FP64 compute bound (FP64 vector pipe; its peak equals the FP64 MFMA peak on MI355X); HBM never binds",
                          "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_cycle": flops, "units_per_launch": B,

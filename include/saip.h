@@ -96,6 +96,7 @@ saip_status saip_batch_create(const saip_model* model, int batch_size, int devic
 void saip_batch_destroy(saip_batch* batch);
 int saip_batch_size(const saip_batch* batch);
 int saip_batch_ld(const saip_batch* batch); /* leading dimension (instances) of device SoA arrays */
+int saip_batch_dof(const saip_batch* batch);
 
 /* MotionForceTask constructors, MotionForceTask.h:96-110 / MotionForceTask.cpp:16-89.
  * n_trans < 0 && n_rot < 0: full 6-dof task; otherwise dirs_* hold n_* controlled direction vectors (3 doubles
@@ -331,6 +332,35 @@ const char* saip_batch_kernel_name(saip_batch*);
 /* HIP-event timing of `steps` back-to-back cycles on the engine stream (after `warmup` untimed ones):
  * total elapsed ms over the timed region.  Used by bench.py for the live roofline figure. */
 saip_status saip_batch_time_steps(saip_batch*, int steps, int warmup, double* elapsed_ms);
+
+/* ---- multi-GPU (the reference is single-robot / single-thread, /root/reference/src/RobotController.cpp:68-118 has nothing to
+ * shard): instances shard embarrassingly across the GPUs of a node, one batch per device, NO data-path collective; the only exchange is the
+ * final gather of the [dof][ld] torque slabs, one ncclAllGather over xGMI.  C++ on RCCL, loaded on first use -- no PyTorch.
+ * (a) one process per GPU: rank 0 draws a unique id, the 128 bytes reach the other ranks by the launcher's rendezvous, every rank creates its
+ *     communicator; saip_batch_all_gather_torques enqueues the all-gather on the batch's stream: gathered_dev = [world][dof][ld]. */
+#define SAIP_COMM_ID_BYTES 128
+typedef struct saip_comm saip_comm;
+saip_status saip_comm_unique_id(void* id128);
+saip_status saip_comm_create(int device, int world, int rank, const void* id128, saip_comm** out);
+void saip_comm_destroy(saip_comm* comm);
+int saip_comm_world(const saip_comm* comm);
+int saip_comm_rank(const saip_comm* comm);
+saip_status saip_batch_all_gather_torques(saip_batch* batch, saip_comm* comm, double* gathered_dev);
+/* (b) one process, n devices: one batch + stream + communicator per device.  saip_multi_create makes the (unfinalized) batches -- add the same
+ *     tasks to every saip_multi_batch(m, i) -- saip_multi_finalize finalizes them, runs ncclCommInitAll and allocates the gather buffers;
+ *     saip_multi_step_async = saip_batch_step_async on every device, saip_multi_all_gather_torques = one grouped ncclAllGather, after which
+ *     every device holds [n_devices][dof][ld] at saip_multi_gathered_device(m, i). */
+typedef struct saip_multi saip_multi;
+saip_status saip_multi_create(const saip_model* model, int batch_per_device, const int* devices, int n_devices, saip_multi** out);
+int saip_multi_size(const saip_multi* m);
+saip_batch* saip_multi_batch(saip_multi* m, int i);
+saip_status saip_multi_finalize(saip_multi* m);
+saip_status saip_multi_step_async(saip_multi* m);
+saip_status saip_multi_all_gather_torques(saip_multi* m);
+saip_status saip_multi_synchronize(saip_multi* m);
+double* saip_multi_gathered_device(saip_multi* m, int i);
+saip_status saip_multi_get_gathered_host(saip_multi* m, int i, double* out /*[n_devices][dof][B]*/);
+void saip_multi_destroy(saip_multi* m);
 
 const char* saip_last_error(void);
 const char* saip_version(void);

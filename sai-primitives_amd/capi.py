@@ -7,7 +7,7 @@ import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libsaip.so")
-SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip", "csrc/saip_kernel_lane_lean.hip", "csrc/saip_kernel_oct.hip", "csrc/saip_otg.hip", "csrc/saip_dynamics.hip", "csrc/saip_dynamics_oct.hip"]
+SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_comm.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip", "csrc/saip_kernel_lane_lean.hip", "csrc/saip_kernel_oct.hip", "csrc/saip_otg.hip", "csrc/saip_dynamics.hip", "csrc/saip_dynamics_oct.hip"]
 HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "csrc/saip_fk.h", "csrc/saip_oct_common.h", "../include/saip.h"]
 
 SAIP_OK, SAIP_ERR_INVALID_ARGUMENT, SAIP_ERR_UNSUPPORTED, SAIP_ERR_NO_DEVICE, SAIP_ERR_DEVICE, SAIP_ERR_ORDER = range(6)
@@ -178,6 +178,23 @@ def lib():
         "saip_batch_set_kernel": (C.c_int, [vp, C.c_int]),
         "saip_batch_kernel_name": (C.c_char_p, [vp]),
         "saip_batch_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp]),
+        "saip_batch_dof": (C.c_int, [vp]),
+        "saip_comm_unique_id": (C.c_int, [vp]),
+        "saip_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+        "saip_comm_destroy": (None, [vp]),
+        "saip_comm_world": (C.c_int, [vp]),
+        "saip_comm_rank": (C.c_int, [vp]),
+        "saip_batch_all_gather_torques": (C.c_int, [vp, vp, vp]),
+        "saip_multi_create": (C.c_int, [vp, C.c_int, ip, C.c_int, C.POINTER(vp)]),
+        "saip_multi_size": (C.c_int, [vp]),
+        "saip_multi_batch": (vp, [vp, C.c_int]),
+        "saip_multi_finalize": (C.c_int, [vp]),
+        "saip_multi_step_async": (C.c_int, [vp]),
+        "saip_multi_all_gather_torques": (C.c_int, [vp]),
+        "saip_multi_synchronize": (C.c_int, [vp]),
+        "saip_multi_gathered_device": (vp, [vp, C.c_int]),
+        "saip_multi_get_gathered_host": (C.c_int, [vp, C.c_int, dp]),
+        "saip_multi_destroy": (None, [vp]),
         "saip_last_error": (C.c_char_p, []),
         "saip_version": (C.c_char_p, []),
         "saip_device_count": (C.c_int, []),

@@ -43,6 +43,17 @@ static saip_status fail(saip_status st, const char* fmt, ...) {
 	g_err = buf;
 	return st;
 }
+namespace saip {
+saip_status fail_external(saip_status st, const char* fmt, ...) {  // for the other translation units of the library (saip_comm.cpp)
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return st;
+}
+}  // namespace saip
 #define HIP_TRY(expr)                                                                                        \
 	do {                                                                                                     \
 		hipError_t e_ = (expr);                                                                              \
@@ -405,6 +416,7 @@ extern "C" void saip_batch_destroy(saip_batch* b) {
 }
 extern "C" int saip_batch_size(const saip_batch* b) { return b ? b->B : 0; }
 extern "C" int saip_batch_ld(const saip_batch* b) { return b ? b->ld : 0; }
+extern "C" int saip_batch_dof(const saip_batch* b) { return (b && b->model) ? b->model->n : 0; }
 
 static saip_status check_batch(const saip_batch* b, int task, const char* fn) {
 	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "%s: null batch", fn);

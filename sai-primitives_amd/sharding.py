@@ -51,6 +51,42 @@ def gather_torques(tau_local, world: int, out=None):
     return out
 
 
+class NativeGather:
+    """the final torque gather done by the engine itself: C++ on RCCL (csrc/saip_comm.cpp), ncclAllGather on the batch's stream.
+    torch.distributed only carries the 128-byte unique id from rank 0 to the other ranks (the launcher's rendezvous)."""
+
+    def __init__(self, ctrl, world: int, rank: int, local_rank: int, device):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        L = capi.lib()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            capi.check(L.saip_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            t = ident.to(device) if dist.get_backend() == "nccl" else ident
+            dist.broadcast(t, src=0)
+            ident = t.cpu()
+        buf = (C.c_ubyte * 128)(*ident.tolist())
+        self._comm = C.c_void_p()
+        capi.check(L.saip_comm_create(int(local_rank), int(world), int(rank), buf, C.byref(self._comm)))
+        self._ctrl, self._L = ctrl, L
+
+    def gather(self, out):
+        """out: torch tensor [world, dof, ld] on this rank's GPU; asynchronous on the engine stream"""
+        from . import capi
+        capi.check(self._L.saip_batch_all_gather_torques(self._ctrl._h, self._comm, out.data_ptr()))
+        return out
+
+    def close(self):
+        if self._comm:
+            self._L.saip_comm_destroy(self._comm)
+            self._comm = None
+
+
 def max_over_ranks(value: float, device) -> float:
     import torch
     import torch.distributed as dist
