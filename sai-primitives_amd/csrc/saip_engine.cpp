@@ -1320,7 +1320,9 @@ static bool lane_eligible(const saip_batch* b) {
 	double thr = -1.0;
 	for (auto& T : b->tasks) {
 		if (T.dev.type == saip::TASK_MOTION_FORCE) nmf++;
-		if (T.dev.type == saip::TASK_MOTION_FORCE && (T.dev.cl_force || T.dev.cl_moment)) return false;  // closed-loop force control: general kernel
+		// closed-loop force / moment control runs in the lane kernel's general-law instantiations; with the passivity controller around
+		// the force loop (per-instance energy window in HBM) the stack stays with the general kernel
+		if (T.dev.type == saip::TASK_MOTION_FORCE && (T.dev.cl_force || T.dev.cl_moment) && T.dev.popc_enabled) return false;
 		if (T.dev.decoupling == SAIP_BOUNDED_INERTIA_ESTIMATES) {
 			if (thr >= 0.0 && thr != T.dev.bie_threshold) return false;
 			thr = T.dev.bie_threshold;

@@ -480,7 +480,7 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off)
 	double g[6];
 	{
-		double xp[3], Rc[9], G24[30];
+		double xp[3], Rc[9], G24[36];  // 36: the closed-loop branch of the general law reads the sensed force / moment (entries 30..35)
 		UNR for (int e = 0; e < 3; e++) xp[e] = pw[e];
 		UNR for (int e = 0; e < 9; e++) Rc[e] = sm.park[cbase + 3 + e][lane];
 		UNR for (int e = 0; e < 24; e++) G24[e] = PF ? sm.pf[2 * N + e][lane] : tk->goal[(size_t)e * ld + b];
@@ -492,10 +492,19 @@ __device__ __forceinline__ void lane_motion_force_task(const CycleParams& P, SMT
 			}
 		}
 		if (GL) {
-			// velocity saturation and/or force & moment spaces (open-loop force control); reduces to the short law for the defaults
+			// velocity saturation, force & moment spaces with open- or closed-loop force / moment control (the passivity controller around
+			// the force loop stays with the general kernel: lane_eligible in the engine); reduces to the short law for the defaults
 			UNR for (int e = 24; e < 30; e++) G24[e] = tk->goal[(size_t)e * ld + b];
-			// closed-loop force / moment control is left to the general kernel (lane_eligible in the engine)
-			law_motion_force_general<false>(tk, vw, xp, Rc, G24, ip, io, (double*)nullptr, Fum, Ff);
+			const bool closed = tk->cl_force || tk->cl_moment;  // batch-uniform
+			double ifm[6] = {0, 0, 0, 0, 0, 0};
+			UNR for (int e = 30; e < 36; e++) G24[e] = closed ? tk->goal[(size_t)e * ld + b] : 0.0;  // sensed force / moment, sensor frame
+			if (closed) {
+				UNR for (int i = 0; i < 6; i++) ifm[i] = tk->integ[(size_t)(6 + i) * ld + b];
+			}
+			law_motion_force_general<true>(tk, vw, xp, Rc, G24, ip, io, ifm, Fum, Ff);
+			if (closed && live) {  // shadow rows, committed in the epilogue like the others
+				UNR for (int i = 0; i < 6; i++) tk->integ_new[(size_t)(6 + i) * ld + b] = ifm[i];
+			}
 		} else {
 			double v[3], w[3], e3[3], tmp[3];
 			UNR for (int i = 0; i < 3; i++) {
@@ -1175,6 +1184,9 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 		if (!singular) {
 			_Pragma("unroll 1") for (int t = 0; t < P.nt; t++) {
 				const TaskCPtr tk = tasks + t;
+				if (tk->type == TASK_MOTION_FORCE && (tk->cl_force || tk->cl_moment)) {  // force / moment integrators (rows 6..11)
+					_Pragma("unroll 1") for (int i = 6; i < 12; i++) tk->integ[(size_t)i * ld + b] = tk->integ_new[(size_t)i * ld + b];
+				}
 				if (!(tk->has_ki || P.integ_always)) continue;
 				const int rows = tk->type == TASK_MOTION_FORCE ? 6 : tk->m;
 				_Pragma("unroll 1") for (int i = 0; i < rows; i++) tk->integ[(size_t)i * ld + b] = tk->integ_new[(size_t)i * ld + b];

@@ -662,7 +662,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 		// MotionForceTask::computeTorques up to the task forces: F_um -> sm.Fum, F_f -> sm.Ff, their range(P) coordinates -> v0, v1
 		auto mf_law = [&]() {
 			if (tid == 0) {
-				const double* G = sm.goal;  // x3, R9, v3, w3, a3, alpha3, f3, m3
+				const auto& G = sm.goal;  // x3, R9, v3, w3, a3, alpha3, f3, m3, sensed f3, sensed m3
 				double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
 				if (track)
 					for (int i = 0; i < 3; i++) {

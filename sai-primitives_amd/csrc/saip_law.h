@@ -107,12 +107,17 @@ __device__ inline double law_popc(double* st, int ld, int cap, double dt, double
 	return Rc;
 }
 
-// CL = false compiles the closed-loop force / moment branch out (the lane kernel leaves such task stacks to the general kernel;
-// G then only needs 30 entries and ifm may be null).
-template <bool CL, typename TK>
-__device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw, const double* xp, const double* Rc, const double* G,
+// CL = false compiles the closed-loop force / moment branch out (G then only needs 30 entries and ifm may be null).
+// The goal block is taken by array reference so that its size is checked at compile time: the closed-loop branch reads entries 30..35
+// (sensed force / moment).  A caller that handed in a 30-entry private array with CL = true made those reads run past its stack frame --
+// the compiler may hoist such loads above the branch, so even instances that never take it read beyond the wavefront's scratch
+// segment: the "memory aperture violation" of round 1.
+template <bool CL, typename TK, int NG>
+__device__ __forceinline__ void law_motion_force_general(TK tk, const double* vw, const double* xp, const double* Rc, const double (&G)[NG],
 														 double* ip, double* io, double* ifm, double* Fum, double* Ff, double* popc_state = nullptr, int ld = 0,
 														 bool* popc_overflow = nullptr) {
+	static_assert(NG >= 30, "goal block: x3 R9 v3 w3 a3 alpha3 f3 m3");
+	static_assert(!CL || NG >= 36, "closed-loop force / moment control reads the sensed force and moment: goal entries 30..35");
 	const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	const double* rot = tk->param_in_compliant_frame ? Rc : I3;
 	double sig_f[9], sig_m[9], sig_p[9], sig_o[9], T[9], ImS[9];

@@ -265,6 +265,8 @@ def test_closed_loop_force_control_over_cycles():
             err = W.torque_error(tau, ref)
             print("closed-loop force control, kernel", ctrl.kernelName(), "cycle", k, "err", err)
             assert err < TOL
+            if kernel == 0:   # closed-loop stacks (without the passivity controller) run in the lane kernel's general-law instantiations
+                assert ctrl.kernelName() == "saip_cycle_lane"
         # toggling closed-loop force control resets the linear integrators: the next cycle equals a fresh oracle's first cycle
         tasks[0].setClosedLoopForceControl(False)
         tasks[0].setClosedLoopForceControl(True)
