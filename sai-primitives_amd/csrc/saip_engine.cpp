@@ -1411,6 +1411,12 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
 		const int oct_max = oct_env ? atoi(oct_env) : 8192;  // four wavefronts per CU (35 KB of LDS each): beyond that the lane kernel wins (measured)
 		const bool oct = oct_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
+		// the eight-lane kernel runs the blended singularity strategies of the headline stack itself (and passes a fully singular task
+		// through): with the handling enforced nothing is left for a slow path, and what it still refuses the general kernel would too
+		if (oct && P.oct_general_joint == 0 && b->tasks[0].dev.sing_handling) {
+			slow = false;
+			P.flag_count = P.flag_count_next = P.flag_list = nullptr;
+		}
 		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
 		if (oct) lane_ok = true;
 		if (lane_ok) {

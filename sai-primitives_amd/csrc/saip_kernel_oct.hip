@@ -42,17 +42,14 @@ __device__ unsigned long long saip_stamps_oct[64];
 #endif
 
 struct OctInst {
-	union {  // the kinematics / inertia scratch is dead before the task matrices are written
-		struct {
-			double X[8][12];     // world frame per joint: R (9, row-major) + o (3)
-			double M[8][8];
-		};
+	union {  // the kinematics scratch is dead before the task matrices are written
+		double X[8][12];     // world frame per joint: R (9, row-major) + o (3)
 		struct {
 			double T1[6][8], A[8][8], Am[8][8], Lam[8][8];  // Lam also carries J M_BIE^-1 until Lambda exists; rows 6, 7: padding lanes' scratch
 			double N1[8][8];
-			double Gx[8][8];     // Gram matrix of the exact range-basis path (its eigenvectors go to T1.., dead by then)
 		};
 	};
+	double M[8][8];      // lower triangle of M(q), row r by lane r; kept to the end (the blended singularity strategies want M z)
 	double zo[8][6];     // world joint axis z (3), joint origin o (3)
 	double J[6][8];
 	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3 / 4 row and scalar exchanges, 5 goal force + moment (general laws), 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
@@ -161,6 +158,48 @@ __device__ __forceinline__ void oct_spd_inverse_n(const double (&A)[R][R], doubl
 	}
 }
 __device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) { oct_spd_inverse_n<4>(A, Ainv); }
+
+
+// world frame of this lane's joint for posture q (one joint angle per lane of the instance): local transform, then the three-step
+// prefix product over the chain by DPP row_shr (the same arithmetic as the kernel's own kinematics; used by the singularity
+// classification, which looks at the control frame of two perturbed postures per singular direction)
+__device__ __forceinline__ void oct_fk_frame(const ModelDev& md, const int rr, const int r, const double q, double (&Tw)[12]) {
+	const double* R0 = md.R0[rr];
+	const double ax = md.axis[rr][0], ay = md.axis[rr][1], az = md.axis[rr][2];
+	if (md.jtype[rr] == 1) {
+		double s, c;
+		sincos_joint(q, &s, &c);
+		const double v = 1.0 - c;
+		const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+							  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+							  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+		UNR for (int i = 0; i < 3; i++)
+			UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+		UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
+	} else {
+		UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
+		const double a[3] = {ax, ay, az};
+		double d[3];
+		oct_mat3_vec(R0, a, d);
+		UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q;
+	}
+#define OCT_FK_STEP(D)                                                                                                              \
+	{                                                                                                                               \
+		double Xa[12], Tn[12];                                                                                                      \
+		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
+		UNR for (int i = 0; i < 3; i++) {                                                                                           \
+			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
+			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
+		}                                                                                                                           \
+		const bool take = r >= D;                                                                                                   \
+		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
+	}
+	OCT_FK_STEP(1)
+	OCT_FK_STEP(2)
+	OCT_FK_STEP(4)
+#undef OCT_FK_STEP
+}
+
 
 // FULL: general control laws, partial motion-force tasks and the joint-limit-avoidance wrap compiled in; GJ: general joint task (<= 4 rows); the lean instantiation is the benchmarked default stack
 // (their mere presence costs it 1.7 % through register allocation)
@@ -410,7 +449,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	STAMP(5);
 	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
-	bool singular = false, truncated = false;
+	bool singular = false, truncated = false, blended_i = false;
 	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
@@ -877,6 +916,393 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			}
 		}
 		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
+
+		// ------------------------------------------------------------------------------------------------------------------------------
+		// Blended singularity strategies, in this kernel (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367; the reference's default
+		// whenever the task is inside its singularity bounds).  Only wavefronts that hold such an instance come here.  Everything happens
+		// in the eigenbasis of G = J J^T (register Jacobi solve; no sorting needed: the non-singular set K = { c : sigma_c >= s_max
+		// sigma_max } is a prefix of the sorted spectrum, and everything else is invariant to the order inside K and inside S):
+		//   J_u = U^T J,  A_u = U^T (J M^-1 J^T) U,  B = blockdiag(A_u[K,K], A_u[S,S]) -> one Cholesky gives Lambda_ns and Lambda_s,
+		//   posture Jacobian V_s^T N_ns = D^-1 (J_S - A_SK Lambda_ns J_K), its op-space inertia = D^-1 (Schur complement of A_u) D^-1,
+		//   N = N_js N_ns projects onto null(J) again, so the joint task behind keeps its closed rank-one form with z from U.
+		// ------------------------------------------------------------------------------------------------------------------------------
+		// Blended singularity strategies, in this kernel (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367; the reference's default
+		// whenever the task is inside its singularity bounds).  Only wavefronts that hold such an instance come here.  Everything happens
+		// in the eigenbasis of G = J J^T (register Jacobi solve; no sorting needed: the non-singular set K = { c : sigma_c >= s_max
+		// sigma_max } is a prefix of the sorted spectrum, and everything else is invariant to the order inside K and inside S):
+		//   J_u = U^T J,  A_u = U^T (J M^-1 J^T) U,  B = blockdiag(A_u[K,K], A_u[S,S]) -> one Cholesky gives Lambda_ns and Lambda_s,
+		//   posture Jacobian V_s^T N_ns = D^-1 (J_S - A_SK Lambda_ns J_K), its op-space inertia = D^-1 (Schur complement of A_u) D^-1,
+		//   N = N_js N_ns projects onto null(J) again, so the joint task behind keeps its closed rank-one form with z from U.
+		const bool strategies_on = mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform
+		if (__builtin_expect(strategies_on && __any(singular), 0)) {
+			double Ue[6][6], sig[6], ju[6];
+			bool keep[6];
+			double smax = 0.0;
+			double trg = 0.0;
+			{
+				// (G = J J^T is formed again here rather than kept alive from the branch predicate: 72 registers less across the ordinary path)
+				double E[6][6];
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) {
+						double sacc = 0.0;
+						UNR for (int j = 0; j < N; j++) sacc = fma(Jf[a][j], Jf[c][j], sacc);
+						E[a][c] = sacc;
+						E[c][a] = sacc;
+						if (a == c) trg += sacc;
+					}
+				oct_jacobi_n<6>(E, Ue);
+			}
+			double Ju[6][N];
+			UNR for (int c = 0; c < 6; c++) {
+				double s2 = 0.0;
+				UNR for (int j = 0; j < N; j++) {
+					double acc = 0.0;
+					UNR for (int i = 0; i < 6; i++) acc = fma(Ue[i][c], Jf[i][j], acc);
+					Ju[c][j] = acc;
+					s2 = fma(acc, acc, s2);
+				}
+				sig[c] = sqrt(s2);  // singular values from the rows themselves: accurate down to ~1e-10 sigma_max (the Gram eigenvalue is not)
+				smax = fmax(smax, sig[c]);
+				double own = 0.0;
+				UNR for (int j = 0; j < N; j++) own = (j == rr) ? Ju[c][j] : own;
+				ju[c] = own;
+			}
+			int ns = 0, cstar = 0;
+			double sstar = -1.0;
+			bool tiny = false;
+			UNR for (int c = 0; c < 6; c++) {
+				keep[c] = sig[c] >= mf.s_max * smax;
+				ns += keep[c] ? 1 : 0;
+				if (!keep[c] && sig[c] > sstar) {
+					sstar = sig[c];
+					cstar = c;
+				}
+				tiny = tiny || (!keep[c] && !(sig[c] >= 1e-10 * smax));
+			}
+			const bool finite_state = (trg - trg == 0.0);  // a NaN or infinite state / goal never passes for "fully singular": refused
+			const bool fully = finite_state && !(smax >= mf.s_abs_tol);             // fully singular task: passed through (:149-151, 316-317)
+			const bool blend = singular && finite_state && !fully && ns < 6 && !tiny;  // (tiny: the direction of V_s is not resolved: refused)
+			const bool clear = singular && finite_state && !fully && ns == 6;        // the eigen-solve overrules a borderline certificate: the ordinary result stands
+			if (clear) singular = false;
+			if (__any(singular && fully)) {
+				// zero task torques, N = N_prec = I: the full joint task behind sees the whole joint space -- U = I, Lambda = M,
+				// Lambda_mod = M_BIE / M / I (JointTask.cpp:241-267): tau_r = sum_j M_rj a_j + Mmod_rj f_j
+				double acc = 0.0;
+				const double af = jg_ddq, ff = fi;  // tau_prec = 0: no disturbance compensation
+				UNR for (int j = 0; j < N; j++) {
+					const int src = (lane & ~7) | j;
+					const double aj = __shfl(af, src), fj = __shfl(ff, src);
+					const double mrj = (j <= rr) ? sm.M[rr][j] : sm.M[j][rr];
+					double mmod = mrj;
+					if (jt.decoupling == DEC_IMPEDANCE) mmod = (j == rr) ? 1.0 : 0.0;
+					else if (jt.decoupling == DEC_BIE) mmod = (j == rr) ? fmax(mrj, jt.bie_threshold) : mrj;
+					acc = fma(mrj, aj, fma(mmod, fj, acc));
+				}
+				if (singular && fully) {
+					tv = acc;
+					singular = false;
+					truncated = true;
+				}
+			}
+			if (__any(blend)) {
+				ShState* st = mf.sh + b;
+				const int cycle = P.task_cycle[0];
+				// ---- handler state of the previous cycle (void unless that cycle was blended too, :238-244), entering posture (:232-235)
+				const bool fresh = st->last_cycle != cycle - 1;
+				int ntypes = fresh ? 0 : st->ntypes, c1 = fresh ? 0 : st->c1, c2 = fresh ? 0 : st->c2, head = fresh ? 0 : st->head, hsize = fresh ? 0 : st->size;
+				double q_prior = st->q_prior[rr];
+				if (ntypes == 0 || c2 > c1) q_prior = q_r;
+				// ---- classification (:246-294): motion of the control frame along u_c at q +- 5 v_c, the larger of the two
+				// (the unperturbed control frame is evaluated again here, the same way, rather than kept alive across the ordinary path)
+				double pw0[3], Rc0[9];
+				{
+					double T0[12], Rb[12];
+					oct_fk_frame(md, rr, r, q_r, T0);
+					const int srcb = (lane & ~7) | mf.body;
+					UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T0[e2], srcb);
+					oct_mat3_vec(Rb, mf.pos, pw0);
+					UNR for (int i = 0; i < 3; i++) pw0[i] += Rb[9 + i];
+					UNR for (int i = 0; i < 3; i++)
+						UNR for (int j = 0; j < 3; j++) Rc0[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
+				}
+				bool any1 = false;
+				UNR for (int c = 0; c < 6; c++) {
+					if (__any(blend && !keep[c])) {  // wave-uniform
+						const double vc = ju[c] * oct_rcp(sig[c]);
+						double motion = 0.0;
+						UNR for (int sg = 0; sg < 2; sg++) {
+							double T1w[12], Rb[12], x1[3], R1[9];
+							oct_fk_frame(md, rr, r, q_r + (sg ? -5.0 : 5.0) * vc, T1w);
+							const int srcb = (lane & ~7) | mf.body;
+							UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T1w[e2], srcb);
+							oct_mat3_vec(Rb, mf.pos, x1);
+							UNR for (int i = 0; i < 3; i++) x1[i] += Rb[9 + i];
+							UNR for (int i = 0; i < 3; i++)
+								UNR for (int j = 0; j < 3; j++) R1[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
+							double w6[6] = {x1[0] - pw0[0], x1[1] - pw0[1], x1[2] - pw0[2], 0.0, 0.0, 0.0};
+							UNR for (int col = 0; col < 3; col++) {  // orientationError(R1, Rc)
+								const double a0 = Rc0[col], a1 = Rc0[3 + col], a2 = Rc0[6 + col], b0 = R1[col], b1 = R1[3 + col], b2 = R1[6 + col];
+								w6[3] -= 0.5 * (a1 * b2 - a2 * b1);
+								w6[4] -= 0.5 * (a2 * b0 - a0 * b2);
+								w6[5] -= 0.5 * (a0 * b1 - a1 * b0);
+							}
+							double d = 0.0;
+							UNR for (int i = 0; i < 6; i++) d = fma(w6[i], Ue[i][c], d);
+							motion = fmax(motion, fabs(d));
+						}
+						any1 = any1 || (!keep[c] && motion > 0.5);  // _type_1_tol
+					}
+				}
+				if (hsize == SH_BUFFER) {  // :285-292
+					if (st->hist[head] == 1) c1--;
+					else c2--;
+					head = (head + 1) % SH_BUFFER;
+					hsize--;
+				}
+				const int slot = (head + hsize) % SH_BUFFER;
+				hsize++;
+				if (any1) c1++;
+				else c2++;
+				const bool type1 = (c1 > c2) || mf.sh_force_type1;  // :329
+				// type-2 direction memory (:339-345): joints that take part in the first singular direction flip near their limits
+				unsigned dir_neg = st->dir_neg;
+				{
+					double jstar = 0.0;
+					UNR for (int c = 0; c < 6; c++) jstar = (c == cstar) ? ju[c] : jstar;
+					const bool part = act && jstar != 0.0;
+					const bool setb = part && fabs(q_r - md.q_upper[rr]) < 5.0 * M_PI / 180.0;
+					const bool clrb = part && !setb && fabs(q_r - md.q_lower[rr]) < 5.0 * M_PI / 180.0;
+					const unsigned sets = (unsigned)((__ballot(setb) >> (grp * 8)) & 0x7full), clrs = (unsigned)((__ballot(clrb) >> (grp * 8)) & 0x7full);
+					if (!type1) dir_neg = (dir_neg | sets) & ~clrs;
+				}
+				if (blend && live) {
+					if (act) st->q_prior[r] = q_prior;
+					if (r == 0) {
+						st->hist[slot] = any1 ? 1 : 2;
+						st->ntypes = 6 - ns;
+						st->c1 = c1;
+						st->c2 = c2;
+						st->head = head;
+						st->size = hsize;
+						st->dir_neg = dir_neg;
+						st->last_cycle = cycle;
+					}
+				}
+				// ---- A_u = U^T A U and its bounded-inertia version (A from LDS: the ordinary path left it there)
+				double Au[6][6], Amu[6][6];
+				{
+					double Af[6][6], W[6][6];
+					UNR for (int i = 0; i < 6; i++)
+						UNR for (int j = 0; j <= i; j++) {
+							Af[i][j] = sm.A[i][j];
+							Af[j][i] = Af[i][j];
+						}
+					UNR for (int i = 0; i < 6; i++)
+						UNR for (int c = 0; c < 6; c++) {
+							double acc = 0.0;
+							UNR for (int k = 0; k < 6; k++) acc = fma(Af[i][k], Ue[k][c], acc);
+							W[i][c] = acc;
+						}
+					UNR for (int c = 0; c < 6; c++)
+						UNR for (int d = 0; d <= c; d++) {
+							double acc = 0.0;
+							UNR for (int i = 0; i < 6; i++) acc = fma(Ue[i][c], W[i][d], acc);
+							Au[c][d] = acc;
+							Au[d][c] = acc;
+						}
+					if (mf.decoupling == DEC_BIE && general_bie) {
+						UNR for (int i = 0; i < 6; i++)
+							UNR for (int j = 0; j <= i; j++) {
+								Af[i][j] = sm.Am[i][j];
+								Af[j][i] = Af[i][j];
+							}
+						UNR for (int i = 0; i < 6; i++)
+							UNR for (int c = 0; c < 6; c++) {
+								double acc = 0.0;
+								UNR for (int k = 0; k < 6; k++) acc = fma(Af[i][k], Ue[k][c], acc);
+								W[i][c] = acc;
+							}
+						UNR for (int c = 0; c < 6; c++)
+							UNR for (int d = 0; d <= c; d++) {
+								double acc = 0.0;
+								UNR for (int i = 0; i < 6; i++) acc = fma(Ue[i][c], W[i][d], acc);
+								Amu[c][d] = acc;
+								Amu[d][c] = acc;
+							}
+					} else {
+						double tu[6];
+						UNR for (int c = 0; c < 6; c++) {
+							double acc = 0.0;
+							UNR for (int l = 0; l < N; l++) acc = fma(Ju[c][l], mcol[l], acc);
+							tu[c] = acc;
+						}
+						const double bb = (mf.decoupling == DEC_BIE) ? beta : 0.0;  // rank-one form: A_mod = A - beta t t^T (beta = 0: nothing clamped)
+						UNR for (int c = 0; c < 6; c++)
+							UNR for (int d = 0; d < 6; d++) Amu[c][d] = fma(-bb * tu[c], tu[d], Au[c][d]);
+					}
+				}
+				// ---- block-diagonal factors: Lambda_ns / Lambda_s and their modified versions in one Cholesky each
+				double LB[6][6], dB[6], LM[6][6], dM[6];
+				UNR for (int c = 0; c < 6; c++)
+					UNR for (int d = 0; d <= c; d++) {
+						const bool same = keep[c] == keep[d];
+						LB[c][d] = same ? Au[c][d] : 0.0;
+						LM[c][d] = same ? Amu[c][d] : 0.0;
+					}
+				oct_cholesky<6>(LB, dB);
+				oct_cholesky<6>(LM, dM);
+				// ---- task forces in the eigenbasis, tau_ns and the clamped tau_s (:321-322, 358-366)
+				double fu[6], ffu[6], gu[6], fn2 = 0.0;
+				UNR for (int c = 0; c < 6; c++) {
+					double a = 0.0, bq = 0.0;
+					UNR for (int i = 0; i < 6; i++) {
+						a = fma(Ue[i][c], Fum6[i], a);
+						bq = fma(Ue[i][c], Ff6[i], bq);
+					}
+					fu[c] = a;
+					ffu[c] = bq;
+				}
+				UNR for (int i = 0; i < 6; i++) fn2 = fma(Fum6[i] + Ff6[i], Fum6[i] + Ff6[i], fn2);
+				if (mf.decoupling == DEC_IMPEDANCE) {
+					UNR for (int c = 0; c < 6; c++) gu[c] = fu[c] + ffu[c];
+				} else {
+					oct_solve<6>(LM, dM, fu, gu);
+					UNR for (int c = 0; c < 6; c++) gu[c] += ffu[c];
+				}
+				double tns = 0.0, ts = 0.0;
+				UNR for (int c = 0; c < 6; c++) {
+					tns = fma(keep[c] ? ju[c] : 0.0, gu[c], tns);
+					ts = fma(keep[c] ? 0.0 : ju[c], gu[c], ts);
+				}
+				{
+					const double lim = md.effort[rr];
+					ts = (ts != ts) ? 0.0 : fmin(fmax(ts, -lim), lim);
+				}
+				double sstar_v = 0.0, fstar = 0.0;
+				UNR for (int c = 0; c < 6; c++) {
+					sstar_v = (c == cstar) ? sig[c] : sstar_v;
+					fstar = (c == cstar) ? fu[c] + ffu[c] : fstar;
+				}
+				const double alpha = fmin(fmax((sstar_v * oct_rcp(smax) - mf.s_min) * oct_rcp(mf.s_max - mf.s_min), 0.0), 1.0);  // :114-115
+				const double fTd = fstar * oct_rsqrt(fn2);  // :346-347
+				// ---- joint strategy: posture Jacobian rows (own column), its op-space inertia from the Schur complement of A_u
+				double X[6][6], jpp[6], Pj[6][6], Pm[6][6];
+				UNR for (int c = 0; c < 6; c++) {
+					double rhs[6];
+					UNR for (int d = 0; d < 6; d++) rhs[d] = (keep[d] && !keep[c]) ? Au[d][c] : 0.0;
+					oct_solve<6>(LB, dB, rhs, X[c]);  // x_c = Lambda_ns A_u[K, c], supported on K (zero for c in K)
+				}
+				UNR for (int c = 0; c < 6; c++) {
+					const double isg = keep[c] ? 0.0 : oct_rcp(sig[c]);
+					double acc = ju[c];
+					UNR for (int d = 0; d < 6; d++) acc = fma(-X[c][d], ju[d], acc);
+					jpp[c] = acc * isg;
+				}
+				UNR for (int c = 0; c < 6; c++) {
+					double yc[6];  // y_c = A_mod,u x_c
+					UNR for (int d2 = 0; d2 < 6; d2++) {
+						double acc = 0.0;
+						UNR for (int d = 0; d < 6; d++) acc = fma(Amu[d2][d], X[c][d], acc);
+						yc[d2] = acc;
+					}
+					UNR for (int e2 = 0; e2 <= c; e2++) {
+						const bool both = !keep[c] && !keep[e2];
+						const double isg = both ? oct_rcp(sig[c]) * oct_rcp(sig[e2]) : 0.0;
+						double sch = Au[c][e2], schm = Amu[c][e2] - yc[e2], xy = 0.0, ye = 0.0;
+						UNR for (int d = 0; d < 6; d++) {
+							sch = fma(-X[c][d], Au[d][e2], sch);
+							xy = fma(X[e2][d], yc[d], xy);
+							ye = fma(Amu[c][d], X[e2][d], ye);  // (y_e)_c
+						}
+						schm = schm - ye + xy;
+						Pj[c][e2] = both ? sch * isg : ((c == e2) ? 1.0 : 0.0);
+						Pm[c][e2] = both ? schm * isg : ((c == e2) ? 1.0 : 0.0);
+					}
+				}
+				if (mf.decoupling == DEC_FULL) {
+					UNR for (int c = 0; c < 6; c++)
+						UNR for (int e2 = 0; e2 <= c; e2++) Pm[c][e2] = Pj[c][e2];
+				}
+				double dPm[6];
+				oct_cholesky<6>(Pm, dPm);
+				// unit torques (:333-336 type 1: hold the entering posture; :346-354 type 2) and V_s^T of them (sums over the lanes)
+				const double u1 = type1 ? (-mf.sh_kp1 * (q_r - q_prior) - mf.sh_kv1 * dq_r)
+										: ((((dir_neg >> rr) & 1u) ? -1.0 : 1.0) * (fabs(fTd) * 1e-2 * md.effort[rr]));
+				const double u2 = -mf.sh_kv2 * dq_r;
+				double w1[6], w2[6], lw[6];
+				UNR for (int c = 0; c < 6; c++) {
+					const double vc = (keep[c] || !act) ? 0.0 : ju[c] * oct_rcp(sig[c]);
+					w1[c] = oct_group_sum(vc * u1);
+					w2[c] = type1 ? 0.0 : oct_group_sum(vc * u2);
+				}
+				double tjs = 0.0, wsel[6];
+				UNR for (int c = 0; c < 6; c++) wsel[c] = type1 ? w1[c] : w2[c];  // (element-wise: never a run-time choice between two private arrays)
+				if (mf.decoupling == DEC_IMPEDANCE) {
+					UNR for (int c = 0; c < 6; c++) lw[c] = wsel[c];
+				} else {
+					oct_solve<6>(Pm, dPm, wsel, lw);
+				}
+				UNR for (int c = 0; c < 6; c++) tjs = fma(jpp[c], type1 ? lw[c] : (w1[c] + lw[c]), tjs);
+				const double tmf = (mf.decoupling == DEC_IMPEDANCE) ? tns : (tns + alpha * ts + (1.0 - alpha) * tjs);  // :311-313, :367
+				// ---- the joint task behind: N = N_js N_ns projects onto null(J) along M^-1 range(J^T), so N = z z^T M / (z^T M z) again;
+				// z from the Euclidean projector I - sum_c v_c v_c^T (pivot row: the lane with the largest diagonal entry)
+				double zn = act ? 1.0 : -1.0;
+				double vown[6];
+				UNR for (int c = 0; c < 6; c++) {
+					vown[c] = ju[c] * oct_rcp(sig[c]);
+					zn = fma(-vown[c], vown[c], zn);
+				}
+				double bestw = zn;
+				int jbw = r;
+	#define OCT_ARGMAX_STEP(CTRL)                                                                                   \
+		{                                                                                                           \
+		const double ob = oct_dpp<CTRL>(bestw);                                                                 \
+		const int oj = __builtin_amdgcn_update_dpp(0, jbw, CTRL, 0xF, 0xF, true);                               \
+		const bool take = ob > bestw || (ob == bestw && oj < jbw);                                              \
+		bestw = take ? ob : bestw;                                                                              \
+		jbw = take ? oj : jbw;                                                                                  \
+		}
+				OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
+				OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
+				OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+	#undef OCT_ARGMAX_STEP
+				const int srcp = (lane & ~7) | jbw;
+				double zb = (r == jbw) ? 1.0 : 0.0;
+				UNR for (int c = 0; c < 6; c++) zb = fma(-vown[c], __shfl(vown[c], srcp), zb);
+				zb = act ? zb : 0.0;
+				double mz = 0.0, wq = 0.0;
+				UNR for (int j = 0; j < N; j++) {
+					const int srcj = (lane & ~7) | j;
+					const double zj = __shfl(zb, srcj), tj = __shfl(tmf, srcj);
+					const double mrj = (j <= rr) ? sm.M[rr][j] : sm.M[j][rr];
+					mz = fma(mrj, zj, mz);   // (M z)_rr
+					wq = fma(mi[j], tj, wq);  // (M^-1 tau_prec)_rr
+				}
+				const double aib = jg_ddq - wq;
+				const double zzb = oct_group_sum(zb * zb), sb = oct_group_sum(act ? zb * mz : 0.0);
+				const double zab = oct_group_sum(zb * aib), zfb = oct_group_sum(zb * fi);
+				double rhob = 1.0;  // rho |z|^2 in the notation above: tau = (M z)_r / |z|^2 (z.a + rho' z.f), rho' = Lambda_mod / Lambda
+				if (jt.decoupling == DEC_IMPEDANCE) {
+					rhob = zzb * oct_rcp(sb);
+				} else if (jt.decoupling == DEC_BIE) {
+					if (general_bie) {
+						double mbv = 0.0;
+						UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], __shfl(mz, (lane & ~7) | j), mbv);
+						const double qb = oct_group_sum(act ? mz * mbv : 0.0);
+						rhob = sb * oct_rcp(qb);
+					} else {
+						const double ze = oct_group_sum((act && r == eclamp) ? zb : 0.0);
+						rhob = sb * oct_rcp(fma(-beta * ze, ze, sb));
+					}
+				}
+				const double tvb = fma(mz * oct_rcp(zzb), fma(rhob, zfb, zab), tmf);
+				if (blend) {
+					tv = tvb;
+					singular = false;
+					blended_i = true;
+				}
+			}
+		}
 	} else {
 	{
 		double g[6], t3[6], jc[6];
@@ -1247,7 +1673,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
 	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
 	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
-	if (live && r == 0) P.status[b] = singular ? 1 : (truncated ? 2 : 0);
+	if (live && r == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (blended_i ? 8 : 0));
 	if (live && r == 0 && singular && P.flag_list) P.flag_list[atomicAdd(P.flag_count, 1)] = b;  // work list of the device-side slow path
 	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;                       // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged (then nothing advances: the slow path
