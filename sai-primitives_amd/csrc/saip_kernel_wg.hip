@@ -1236,7 +1236,7 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 
 // ---------------------------------------------------------------- host-callable launchers
 hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream) {
-	const int grid = P.B < 1024 ? P.B : 1024;
+	const int grid = P.B < 256 ? P.B : 256;  // one workgroup per CU: an empty list (the usual case) costs 256 scalar loads, not 1024 workgroup launches (4.6 us measured)
 	if (P.n <= 8) {
 		hipLaunchKernelGGL((saip_cycle_wg_list<8, 64>), dim3(grid), dim3(64), 0, stream, P);
 	} else {
