@@ -138,7 +138,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dev)
     ev_ms = sharding.max_over_ranks(ev_ms, dev)

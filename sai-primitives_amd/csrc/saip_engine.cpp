@@ -1833,7 +1833,9 @@ extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmu
 	for (int i = 0; i < steps; i++)
 		if ((st = launch_cycle(b, false))) return st;
 	HIP_TRY(hipEventRecord(e1, b->stream));
-	HIP_TRY(hipEventSynchronize(e1));
+	// one wait for the stream (not for the event and then, in the caller, for the stream or the device: each is its own ~15 us
+	// marker round trip, tools/bench_overhead_probe.py)
+	HIP_TRY(hipStreamSynchronize(b->stream));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
 	*elapsed_ms = ms;

@@ -194,3 +194,47 @@ def test_per_task_integrators_and_otg_advance_in_compute_torques_only():
         tau = jt.computeTorques()
         assert W.torque_error(tau, refs[c]) < TOL, c
     assert W.torque_error(refs[0], refs[2]) > 1e-6
+
+
+def test_joint_task_rank_decision_at_the_range_basis_tolerance():
+    """JointTask.cpp:156 -> SaiModel::matrixRangeBasis: directions of S N_prec below 1e-3 of the largest singular value are dropped.
+    N_prec = Q diag(1, ..., 1, s) Q^T puts the smallest singular value of the projected Jacobian of a full joint task at exactly s:
+    the device's rank decision (certificates first, exact eigen-solve when they cannot tell) must agree with the oracle's SVD on both
+    sides of the tolerance, down to one part in 1e9 from it (tests/test_oracle.py pins the oracle's side against LAPACK)."""
+    import sai_primitives_amd as sp
+    from sai_primitives_amd.controller import tasks_from_specs
+    from oracle import Oracle
+    ratios = [1e-3 * (1 + 1e-4), 1e-3 * (1 - 1e-4), 1e-3 * (1 + 1e-9), 1e-3 * (1 - 1e-9), 0.5, 1e-8, 2e-3, 5e-4]
+    B, n = 8 * len(ratios), 7
+    d = W.make_inputs(2, B)
+    specs = [W.joint_task("joint_task", decoupling=W.FULL_DYNAMIC_DECOUPLING)]
+    robot = sp.SaiModel(d["model"].name, B, device=0)
+    (jt,) = tasks_from_specs(robot, specs)
+    orc = Oracle(d["model"], specs)
+    rng = np.random.default_rng(23)
+    Np = np.empty((B, n, n))
+    keep = np.empty(B, bool)
+    for b in range(B):
+        s = ratios[b % len(ratios)]
+        Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        D = np.ones(n)
+        D[rng.integers(n)] = s
+        Np[b] = Q @ np.diag(D) @ Q.T
+        keep[b] = s >= 1e-3
+    robot.setQ(d["q"])
+    robot.setDq(d["dq"])
+    robot.updateModel()
+    goal = d["goals"][1]
+    _set_goal(jt, specs[0], goal)
+    jt.updateTaskModel(Np)
+    tau = jt.computeTorques()
+    N = jt.getTaskNullspace()
+    tau_ref, N_ref, _, st = orc.task_step(0, d["q"], d["dq"], goal, N_prec=Np)
+    assert (st & 1).sum() == 0 and np.array_equal(jt.status, st)
+    rank = np.rint(np.trace(np.eye(n)[None] - N, axis1=1, axis2=2)).astype(int)
+    rank_ref = np.rint(np.trace(np.eye(n)[None] - N_ref, axis1=1, axis2=2)).astype(int)
+    assert np.array_equal(rank_ref, np.where(keep, n, n - 1))
+    assert np.array_equal(rank, rank_ref), (rank, rank_ref)
+    err = W.torque_error(tau, tau_ref)
+    print(f"range-basis straddle: torque err {err:.2e}")
+    assert err < TOL

@@ -244,3 +244,55 @@ def test_singularity_strategy_options_c_vs_numpy():
     assert W.torque_error(to, tn) < 1e-9
     t0, _ = Oracle(d["model"], W.config_tasks(14)).step(d["q"], d["dq"], d["goals"])
     assert W.torque_error(to, t0) > 1e-3
+
+
+# ------------------------------------------------------------------ what an invariant can decide about the [RECALLED] matrixRangeBasis
+def _straddle_nprec(n, ratios, seed=11):
+    """N_prec = Q diag(1, ..., 1, s) Q^T per ratio s: the projected Jacobian of a full joint task (S = I) IS this matrix, so its
+    singular values are exactly {1, ..., 1, s}"""
+    Q = np.linalg.qr(np.random.default_rng(seed).standard_normal((n, n)))[0]
+    out = np.empty((len(ratios), n, n))
+    for i, s in enumerate(ratios):
+        D = np.ones(n)
+        D[-1] = s
+        out[i] = Q @ np.diag(D) @ Q.T
+    return out
+
+
+STRADDLE = [1e-3 * (1 + 1e-4), 1e-3 * (1 - 1e-4), 1e-3 * (1 + 1e-9), 1e-3 * (1 - 1e-9), 0.5, 1e-8]
+
+
+def test_matrix_range_basis_decision_at_the_tolerance():
+    """JointTask.cpp:156 keeps the directions of S N_prec whose singular value is >= 1e-3 of the largest (SaiModel::matrixRangeBasis,
+    strict '<' drops).  The value 1e-3 is [RECALLED] and unpinned; what IS decided here: the comparison is relative to sigma_0, a
+    direction one part in 1e9 above it is kept and one below is dropped, and the model that follows is the reference's
+    (Lambda, Jbar, N of the REDUCED Jacobian U^T S N_prec: JointTask.cpp:233-267) -- against a NumPy evaluation by LAPACK's SVD."""
+    d = W.make_inputs(2, len(STRADDLE))
+    tasks = [W.joint_task("joint_task", decoupling=W.FULL_DYNAMIC_DECOUPLING)]
+    orc = Oracle(d["model"], tasks)
+    n = 7
+    Np = _straddle_nprec(n, STRADDLE)
+    goal = d["goals"][1]
+    tau, N, Nt, st = orc.task_step(0, d["q"], d["dq"], goal, N_prec=Np)
+    assert (st & 1).sum() == 0
+    for b, s in enumerate(STRADDLE):
+        M = orc.details(d["q"][b], d["dq"][b], [goal[b]])["M"]
+        Minv = np.linalg.inv(M)
+        Uf, sv, _ = np.linalg.svd(Np[b])
+        assert abs(sv[-1] / sv[0] - s) < 1e-12 * max(1.0, s / 1e-3)
+        r = n if s >= 1e-3 else n - 1
+        U = np.eye(n) if r == n else Uf[:, :r]
+        pj = U.T @ Np[b]
+        Lam = np.linalg.inv(pj @ Minv @ pj.T)
+        Nref = np.eye(n) - Minv @ pj.T @ Lam @ pj
+        assert round(np.trace(np.eye(n) - N[b])) == r, (s, np.trace(np.eye(n) - N[b]))     # Jbar J is a projector of rank r
+        scale = 1.0 / s if r == n else 1.0       # a kept direction at 1e-3 conditions the inverse at 1e6
+        assert np.abs(N[b] - Nref).max() < 1e-9 * scale * scale, (s, np.abs(N[b] - Nref).max())
+        assert np.abs(Nt[b] - Nref @ Np[b]).max() < 1e-9 * scale * scale
+        # the torque is that of the reduced model: tau = pj^T Lam U^T (a*), a* = -kp (q - q_d) - kv dq  (JointTask.cpp:285-356)
+        m = n
+        astar = -tasks[0]["kp"] * (d["q"][b] - goal[b][:m]) - tasks[0]["kv"] * (d["dq"][b] - goal[b][m:2 * m]) + goal[b][2 * m:3 * m]
+        tref = pj.T @ (Lam @ (U.T @ astar))
+        assert np.abs(tau[b] - tref).max() <= 1e-8 * scale * np.abs(tref).max(), (s, tau[b], tref)
+    # dropping the direction changes the answer by orders of magnitude: the two sides of the tolerance are not confusable
+    assert np.abs(tau[0]).max() > 50 * np.abs(tau[1]).max() or np.abs(tau[0] - tau[1]).max() > 0.5 * np.abs(tau[0]).max()

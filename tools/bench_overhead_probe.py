@@ -25,6 +25,12 @@ for rep in range(4):
     g = sharding.gather_torques(tau_t, 1, out=out); t3 = time.perf_counter()
     torch.cuda.synchronize(); t4 = time.perf_counter()
     print(f"sync {1e6*(t1-t0):.1f} us | timeSteps(20) wall {1e6*(t2-t1):.1f} us (events {ev*1e3:.1f} us) | gather issue {1e6*(t3-t2):.1f} us | sync {1e6*(t4-t3):.1f} us")
+for rep in range(3):
+    t1 = time.perf_counter(); ev = ctrl.timeSteps(20, 0); t2 = time.perf_counter()
+    ctrl.synchronize(); t3 = time.perf_counter()
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    torch.cuda.synchronize(); t5 = time.perf_counter()
+    print(f"timeSteps(20) wall {1e6*(t2-t1):.1f} us | engine stream sync {1e6*(t3-t2):.1f} us | device sync {1e6*(t4-t3):.1f} us | again {1e6*(t5-t4):.1f} us")
 for steps in (1, 20, 200):
     t1 = time.perf_counter(); ev = ctrl.timeSteps(steps, 0); t2 = time.perf_counter()
     print(f"timeSteps({steps}) wall {1e6*(t2-t1):.1f} us, events {ev*1e3:.1f} us")
