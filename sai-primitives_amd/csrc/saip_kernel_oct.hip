@@ -30,11 +30,11 @@ namespace saip {
 
 #if defined(SAIP_STAMP_OCT)
 // diagnostic build only (never shipped): s_memtime of wavefront 0 at the phase boundaries
-__device__ unsigned long long saip_stamps_oct[64];
+__device__ unsigned long long saip_stamps_oct[1024 * 32];  // [workgroup][stamp]
 #define STAMP(i)                                                                              \
 	do {                                                                                      \
 		__builtin_amdgcn_sched_barrier(0);                                                    \
-		if (blockIdx.x == 0 && threadIdx.x == 0) saip_stamps_oct[i] = __builtin_amdgcn_s_memtime(); \
+		if (blockIdx.x < 1024 && threadIdx.x == 0) saip_stamps_oct[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
 		__builtin_amdgcn_sched_barrier(0);                                                    \
 	} while (0)
 #else
@@ -450,6 +450,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false, truncated = false, blended_i = false;
+	const bool strategies_on = GJ == 0 && mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform; the blended branch lives in the headline stack's tail
 	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
@@ -541,6 +542,12 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 #if defined(SAIP_OCT_FORCE_EXACT)
 			need_exact = true;
 #endif
+			if (strategies_on && need_exact) {
+				// undecided by the certificates: the blended branch below runs the eigen-solve anyway and hands the instance back to the
+				// ordinary result when all six directions turn out to be kept ("clear")
+				singular = true;
+				need_exact = false;
+			}
 			if (__any(need_exact)) {  // exact path (rare): singular values from the Gram eigenvalues, one lane per instance (SingularityHandler.cpp:78-121)
 				if (need_exact && r == 0) {
 					for (int a = 0; a < 6; a++)
@@ -933,8 +940,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		//   J_u = U^T J,  A_u = U^T (J M^-1 J^T) U,  B = blockdiag(A_u[K,K], A_u[S,S]) -> one Cholesky gives Lambda_ns and Lambda_s,
 		//   posture Jacobian V_s^T N_ns = D^-1 (J_S - A_SK Lambda_ns J_K), its op-space inertia = D^-1 (Schur complement of A_u) D^-1,
 		//   N = N_js N_ns projects onto null(J) again, so the joint task behind keeps its closed rank-one form with z from U.
-		const bool strategies_on = mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform
 		if (__builtin_expect(strategies_on && __any(singular), 0)) {
+			STAMP(16);
 			double Ue[6][6], sig[6], ju[6];
 			bool keep[6];
 			double smax = 0.0;
@@ -952,6 +959,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 					}
 				oct_jacobi_n<6>(E, Ue);
 			}
+			STAMP(17);
 			double Ju[6][N];
 			UNR for (int c = 0; c < 6; c++) {
 				double s2 = 0.0;
@@ -967,6 +975,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				UNR for (int j = 0; j < N; j++) own = (j == rr) ? Ju[c][j] : own;
 				ju[c] = own;
 			}
+			STAMP(18);
 			int ns = 0, cstar = 0;
 			double sstar = -1.0;
 			bool tiny = false;
@@ -1004,6 +1013,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 					truncated = true;
 				}
 			}
+			STAMP(19);
 			if (__any(blend)) {
 				ShState* st = mf.sh + b;
 				const int cycle = P.task_cycle[0];
@@ -1025,34 +1035,46 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 					UNR for (int i = 0; i < 3; i++)
 						UNR for (int j = 0; j < 3; j++) Rc0[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
 				}
+				STAMP(20);
+				// one pass per singular direction an instance has (its k-th one, whichever eigen-index that is: usually a single pass), not one
+				// per eigen-index that is singular somewhere in the wavefront
 				bool any1 = false;
-				UNR for (int c = 0; c < 6; c++) {
-					if (__any(blend && !keep[c])) {  // wave-uniform
-						const double vc = ju[c] * oct_rcp(sig[c]);
-						double motion = 0.0;
-						UNR for (int sg = 0; sg < 2; sg++) {
-							double T1w[12], Rb[12], x1[3], R1[9];
-							oct_fk_frame(md, rr, r, q_r + (sg ? -5.0 : 5.0) * vc, T1w);
-							const int srcb = (lane & ~7) | mf.body;
-							UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T1w[e2], srcb);
-							oct_mat3_vec(Rb, mf.pos, x1);
-							UNR for (int i = 0; i < 3; i++) x1[i] += Rb[9 + i];
-							UNR for (int i = 0; i < 3; i++)
-								UNR for (int j = 0; j < 3; j++) R1[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
-							double w6[6] = {x1[0] - pw0[0], x1[1] - pw0[1], x1[2] - pw0[2], 0.0, 0.0, 0.0};
-							UNR for (int col = 0; col < 3; col++) {  // orientationError(R1, Rc)
-								const double a0 = Rc0[col], a1 = Rc0[3 + col], a2 = Rc0[6 + col], b0 = R1[col], b1 = R1[3 + col], b2 = R1[6 + col];
-								w6[3] -= 0.5 * (a1 * b2 - a2 * b1);
-								w6[4] -= 0.5 * (a2 * b0 - a0 * b2);
-								w6[5] -= 0.5 * (a0 * b1 - a1 * b0);
-							}
-							double d = 0.0;
-							UNR for (int i = 0; i < 6; i++) d = fma(w6[i], Ue[i][c], d);
-							motion = fmax(motion, fabs(d));
-						}
-						any1 = any1 || (!keep[c] && motion > 0.5);  // _type_1_tol
+				for (int k = 0; k < 6; k++) {
+					if (!__any(blend && k < 6 - ns)) break;  // wave-uniform
+					double vnum = 0.0, sk = 1.0, uk[6] = {0, 0, 0, 0, 0, 0};
+					int cnt = 0;
+					UNR for (int c = 0; c < 6; c++) {
+						const bool sel = !keep[c] && cnt == k;
+						vnum = sel ? ju[c] : vnum;
+						sk = sel ? sig[c] : sk;
+						UNR for (int i = 0; i < 6; i++) uk[i] = sel ? Ue[i][c] : uk[i];
+						cnt += keep[c] ? 0 : 1;
 					}
+					const double vc = vnum * oct_rcp(sk);
+					double motion = 0.0;
+					for (int sg = 0; sg < 2; sg++) {
+						double T1w[12], Rb[12], x1[3], R1[9];
+						oct_fk_frame(md, rr, r, q_r + (sg ? -5.0 : 5.0) * vc, T1w);
+						const int srcb = (lane & ~7) | mf.body;
+						UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T1w[e2], srcb);
+						oct_mat3_vec(Rb, mf.pos, x1);
+						UNR for (int i = 0; i < 3; i++) x1[i] += Rb[9 + i];
+						UNR for (int i = 0; i < 3; i++)
+							UNR for (int j = 0; j < 3; j++) R1[3 * i + j] = Rb[3 * i] * mf.rot[j] + Rb[3 * i + 1] * mf.rot[3 + j] + Rb[3 * i + 2] * mf.rot[6 + j];
+						double w6[6] = {x1[0] - pw0[0], x1[1] - pw0[1], x1[2] - pw0[2], 0.0, 0.0, 0.0};
+						UNR for (int col = 0; col < 3; col++) {  // orientationError(R1, Rc)
+							const double a0 = Rc0[col], a1 = Rc0[3 + col], a2 = Rc0[6 + col], b0 = R1[col], b1 = R1[3 + col], b2 = R1[6 + col];
+							w6[3] -= 0.5 * (a1 * b2 - a2 * b1);
+							w6[4] -= 0.5 * (a2 * b0 - a0 * b2);
+							w6[5] -= 0.5 * (a0 * b1 - a1 * b0);
+						}
+						double d = 0.0;
+						UNR for (int i = 0; i < 6; i++) d = fma(w6[i], uk[i], d);
+						motion = fmax(motion, fabs(d));
+					}
+					any1 = any1 || (k < 6 - ns && motion > 0.5);  // _type_1_tol
 				}
+				STAMP(21);
 				if (hsize == SH_BUFFER) {  // :285-292
 					if (st->hist[head] == 1) c1--;
 					else c2--;
@@ -1088,6 +1110,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 						st->last_cycle = cycle;
 					}
 				}
+				STAMP(22);
 				// ---- A_u = U^T A U and its bounded-inertia version (A from LDS: the ordinary path left it there)
 				double Au[6][6], Amu[6][6];
 				{
@@ -1141,6 +1164,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 							UNR for (int d = 0; d < 6; d++) Amu[c][d] = fma(-bb * tu[c], tu[d], Au[c][d]);
 					}
 				}
+				STAMP(23);
 				// ---- block-diagonal factors: Lambda_ns / Lambda_s and their modified versions in one Cholesky each
 				double LB[6][6], dB[6], LM[6][6], dM[6];
 				UNR for (int c = 0; c < 6; c++)
@@ -1151,6 +1175,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 					}
 				oct_cholesky<6>(LB, dB);
 				oct_cholesky<6>(LM, dM);
+				STAMP(24);
 				// ---- task forces in the eigenbasis, tau_ns and the clamped tau_s (:321-322, 358-366)
 				double fu[6], ffu[6], gu[6], fn2 = 0.0;
 				UNR for (int c = 0; c < 6; c++) {
@@ -1185,6 +1210,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				}
 				const double alpha = fmin(fmax((sstar_v * oct_rcp(smax) - mf.s_min) * oct_rcp(mf.s_max - mf.s_min), 0.0), 1.0);  // :114-115
 				const double fTd = fstar * oct_rsqrt(fn2);  // :346-347
+				STAMP(25);
 				// ---- joint strategy: posture Jacobian rows (own column), its op-space inertia from the Schur complement of A_u
 				double X[6][6], jpp[6], Pj[6][6], Pm[6][6];
 				UNR for (int c = 0; c < 6; c++) {
@@ -1223,6 +1249,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 					UNR for (int c = 0; c < 6; c++)
 						UNR for (int e2 = 0; e2 <= c; e2++) Pm[c][e2] = Pj[c][e2];
 				}
+				STAMP(26);
 				double dPm[6];
 				oct_cholesky<6>(Pm, dPm);
 				// unit torques (:333-336 type 1: hold the entering posture; :346-354 type 2) and V_s^T of them (sums over the lanes)
@@ -1244,6 +1271,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				}
 				UNR for (int c = 0; c < 6; c++) tjs = fma(jpp[c], type1 ? lw[c] : (w1[c] + lw[c]), tjs);
 				const double tmf = (mf.decoupling == DEC_IMPEDANCE) ? tns : (tns + alpha * ts + (1.0 - alpha) * tjs);  // :311-313, :367
+				STAMP(27);
 				// ---- the joint task behind: N = N_js N_ns projects onto null(J) along M^-1 range(J^T), so N = z z^T M / (z^T M z) again;
 				// z from the Euclidean projector I - sum_c v_c v_c^T (pivot row: the lane with the largest diagonal entry)
 				double zn = act ? 1.0 : -1.0;
@@ -1295,6 +1323,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 						rhob = sb * oct_rcp(fma(-beta * ze, ze, sb));
 					}
 				}
+				STAMP(28);
 				const double tvb = fma(mz * oct_rcp(zzb), fma(rhob, zfb, zab), tmf);
 				if (blend) {
 					tv = tvb;
@@ -1705,7 +1734,7 @@ hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 
 #if defined(SAIP_STAMP_OCT)
 extern "C" int saip_debug_stamps_oct(unsigned long long* out, int n) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_oct), sizeof(unsigned long long) * (n < 64 ? n : 64));
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_oct), sizeof(unsigned long long) * (n < 1024 * 32 ? n : 1024 * 32));
 }
 #endif
 }  // namespace saip

@@ -1,22 +1,39 @@
-"""diagnostic: phase timing of saip_cycle_oct (build with SAIP_EXTRA_HIPCC_FLAGS=-DSAIP_STAMP_OCT into another library, run with SAIP_LIB)"""
+"""diagnostic: phase timing of saip_cycle_oct, every workgroup (build the variant with tools/oct_variant.sh stamp -DSAIP_STAMP_OCT, run with
+SAIP_LIB=sai-primitives_amd/libsaip_var_stamp.so python tools/oct_stamps.py [config])"""
 import ctypes as C, sys
 sys.path.insert(0, ".")
 import numpy as np
 import workloads as W
 from sai_primitives_amd import capi
 from sai_primitives_amd.controller import controller_from_specs
-d = W.make_inputs(2, 4096)
-robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], 4096, device=0)
+CFG = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+B = 4096
+d = W.make_inputs(CFG, B)
+robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
 ctrl.setKernel(3)
 robot.setQ(d["q"]); robot.setDq(d["dq"]); robot.updateModel(); ctrl.setGoals(d["goals"])
-acc = None
-for rep in range(20):
-    ctrl.updateControllerTaskModels(); ctrl.computeControlTorques()
-    buf = (C.c_ulonglong * 64)()
-    capi.lib().saip_debug_stamps_oct(buf, 64)
-    s = np.array(buf[:16], dtype=np.float64)
-    dlt = np.diff(s)
-    acc = dlt if acc is None else np.minimum(acc, dlt)
-names = ["inputs", "kinematics+inertia+Ic", "M row + J column", "chol7 + solve", "Jf/vw", "-", "G + certificate", "T1/A", "chol6 + Lambda_mod", "law + g", "tau / N1 column", "range: norms", "range: pivot/deflate", "joint law + Lambda", "post"]
-for n_, c in zip(names, acc): print(f"{n_:14s} {c:8.0f}")
-print("total", acc.sum(), "clocks (100 MHz s_memtime ticks x ?)")
+NB = B // 8
+runs = []
+for rep in range(12):
+    ctrl.stepAsync(); ctrl.synchronize()
+    buf = (C.c_ulonglong * (1024 * 32))()
+    capi.lib().saip_debug_stamps_oct(buf, 1024 * 32)
+    runs.append(np.array(buf[:], dtype=np.float64).reshape(1024, 32)[:NB])
+s = runs[-1]
+idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15]               # stamp 11 sits in the general joint task (not run by the headline stack); 12, 13 are not placed
+names = ["input requests", "kinematics + Ic", "M column", "chol7 + M^-1 column", "Jf / vw", "-", "G + certificate",
+         "T1 / A", "chol6 + solves", "law + g", "tau, row of N1, joint task (+ blended block)", "post + stores"]
+dl = np.diff(s[:, idx], axis=1)
+print(f"{'phase':48s} {'min':>8s} {'median':>8s} {'max':>8s}   (shader clocks, {NB} workgroups, last of 12 runs)")
+for i, n_ in enumerate(names): print(f"{n_:48s} {dl[:, i].min():8.0f} {np.median(dl[:, i]):8.0f} {dl[:, i].max():8.0f}")
+tot = s[:, 15] - s[:, 0]
+print(f"{'workgroup total':48s} {tot.min():8.0f} {np.median(tot):8.0f} {tot.max():8.0f}")
+print(f"first start -> last end: {s[:, 15].max() - s[:, 0].min():.0f}; start spread {s[:, 0].max() - s[:, 0].min():.0f}")
+bl = s[:, 16:29]
+has = bl[:, 0] > 0
+if has.any() and (bl[has][:, -1] > bl[has][:, 0]).all():
+    db = np.diff(bl[has], axis=1)
+    print(f"blended block, {int(has.sum())} workgroups:")
+    for i, n_ in enumerate(["G + Jacobi", "Ju / sigma", "decisions + pass-through", "state + control frame", "classification", "state update", "A_u / A_mod,u",
+                            "block Cholesky x2", "forces", "solves + Schur", "Cholesky Pm + unit torques + tjs", "joint task behind"]):
+        print(f"  {n_:46s} {db[:, i].min():8.0f} {np.median(db[:, i]):8.0f} {db[:, i].max():8.0f}")
