@@ -30,11 +30,11 @@ namespace saip {
 
 #if defined(SAIP_STAMP_OCT)
 // diagnostic build only (never shipped): s_memtime of wavefront 0 at the phase boundaries
-__device__ unsigned long long saip_stamps_oct[1024 * 32];  // [workgroup][stamp]
+__device__ unsigned long long saip_stamps_oct[1024 * 64];  // [workgroup][wavefront][stamp]
 #define STAMP(i)                                                                              \
 	do {                                                                                      \
 		__builtin_amdgcn_sched_barrier(0);                                                    \
-		if (blockIdx.x < 1024 && threadIdx.x == 0) saip_stamps_oct[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+		if (blockIdx.x < 1024 && (threadIdx.x & 63) == 0) saip_stamps_oct[blockIdx.x * 64 + (threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
 		__builtin_amdgcn_sched_barrier(0);                                                    \
 	} while (0)
 #else
@@ -56,7 +56,7 @@ struct OctInst {
 	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
-static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
+static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU (one LDS block each, also with two wavefronts per instance group)");
 
 // cyclic Jacobi eigen-solve of a symmetric n x n matrix in LDS by ONE lane (rare exact path): eigenvalues on the diagonal of A,
 // eigenvectors in the columns of V (optional)
@@ -203,15 +203,36 @@ __device__ __forceinline__ void oct_fk_frame(const ModelDev& md, const int rr, c
 
 // FULL: general control laws, partial motion-force tasks and the joint-limit-avoidance wrap compiled in; GJ: general joint task (<= 4 rows); the lean instantiation is the benchmarked default stack
 // (their mere presence costs it 1.7 % through register allocation)
-template <bool FULL, int GJ>
-__global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
+// DUO (the lean instantiation only): TWO wavefronts per group of eight instances, on two SIMDs of the CU.  Wavefront A (0) runs the inertia
+// chain -- composite inertias, M(q), its factor, M^-1, T1, A, the factor of A -- and then the tail; wavefront B (1) runs, at the same
+// time, what does not need M: the branch predicate on G = J J^T and the motion-force control law, hands (singular, F) over through LDS
+// at the one workgroup barrier of the kernel and exits.  Each has its own LDS block; every other synchronisation point is
+// wavefront-local (LDS operations of one wavefront execute in order).
+template <bool DUO>
+__device__ __forceinline__ void oct_sync() {
+	if (DUO) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	} else {
+		__syncthreads();
+	}
+}
+
+// ROLE 0: the whole cycle in one wavefront; 1 / 2: wavefront A / B of the two-wavefront form (compile-time, so that neither carries the
+// other's registers: as run-time branches of one body the merged live ranges spilled)
+template <bool FULL, int GJ, int ROLE>
+__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemB) {
+	constexpr bool DUO = ROLE != 0;
+	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
+	static_assert(!DUO || (!FULL && GJ == 0), "two wavefronts per instance group: lean headline stack only");
 	constexpr int N = 7;
-	__shared__ OctInst smem[8];
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
 	const int r = lane & 7, grp = lane >> 3;
 	const int rr = r < N ? r : N - 1;  // padding lane mirrors joint 6 and never writes
 	const bool act = r < N;
 	OctInst& sm = smem[grp];
+	OctInst& smB = smemB[grp];  // where wavefront B leaves its results
 	const int b_raw = blockIdx.x * 8 + grp;
 	const bool live = b_raw < P.B;
 	const int b = live ? b_raw : P.B - 1;
@@ -225,11 +246,21 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
-	const double gl0 = mf.goal[(size_t)r * ld + b], gl1 = mf.goal[(size_t)(8 + r) * ld + b], gl2 = mf.goal[(size_t)(16 + r) * ld + b];  // 24 goal rows, 3 per lane
+	double gl0 = 0.0, gl1 = 0.0, gl2 = 0.0;  // 24 goal rows, 3 per lane
+	if (roleB) {
+		gl0 = mf.goal[(size_t)r * ld + b];
+		gl1 = mf.goal[(size_t)(8 + r) * ld + b];
+		gl2 = mf.goal[(size_t)(16 + r) * ld + b];
+	}
 	const double gl3 = (FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
 	const int mj = GJ == 1 ? jt.m : N;                 // rows of the joint task (Gram path: <= 4)
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
-	const double jg_q = jt.goal[(size_t)rj * ld + b], jg_dq = jt.goal[(size_t)(mj + rj) * ld + b], jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
+	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
+	if (roleA) {
+		jg_q = jt.goal[(size_t)rj * ld + b];
+		jg_dq = jt.goal[(size_t)(mj + rj) * ld + b];
+		jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
+	}
 
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -285,8 +316,12 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	}
 	const bool rev = md.jtype[rr] == 1;
 	// per-body spatial inertia about the world origin
-	double Ic[10];
-	{
+	double Ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	UNR for (int e = 0; e < 3; e++) {  // (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
+		sm.zo[r][e] = z[e];
+		sm.zo[r][3 + e] = o[e];
+	}
+	if (roleA) {
 		double c[3], Bd[10];
 		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
 		oct_mat3_vec(Tw, cl, c);
@@ -310,13 +345,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		Bd[8] = Iw[2] - m * c[0] * c[2];
 		Bd[9] = Iw[5] - m * c[1] * c[2];
 		UNR for (int e = 0; e < 10; e++) Ic[e] = act ? Bd[e] : 0.0;
-		UNR for (int e = 0; e < 3; e++) {  // (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
-			sm.zo[r][e] = z[e];
-			sm.zo[r][3 + e] = o[e];
-		}
 	}
 	// composite inertia of the subtree of joint r (serial chain: bodies r..6): suffix sums over the instance's lanes by DPP row_shl
-	{
+	if (roleA) {
 		// (selects, not multiplications by 0: a neighbouring instance with non-finite state must not leak in)
 		UNR for (int e = 0; e < 10; e++) {
 			const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
@@ -331,10 +362,10 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			Ic[e] += (r + 4 < 8) ? up : 0.0;
 		}
 	}
-	__syncthreads();
+	oct_sync<DUO>();
 	STAMP(2);
 	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
-	{
+	if (roleA) {
 		double w[3], v[3];
 		w[0] = rev ? z[0] : 0.0; w[1] = rev ? z[1] : 0.0; w[2] = rev ? z[2] : 0.0;
 		v[0] = rev ? (o[1] * z[2] - o[2] * z[1]) : z[0];
@@ -383,7 +414,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
 		}
 	}
-	__syncthreads();
+	oct_sync<DUO>();
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
 	// M_BIE = M + sum_e c_e e e^T, the diagonal clamped from below (SingularityHandler.cpp:176-182).  Usual case (at most one clamped
@@ -391,11 +422,11 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	// beta = c / (1 + c m_e), M_BIE^-1 = M^-1 - beta m m^T, hence J M_BIE^-1 J^T = A - beta t t^T (t = J m) and, by Sherman-Morrison,
 	// Lambda_mod = Lambda + gamma (Lambda t)(Lambda t)^T with gamma = beta / (1 - beta t^T Lambda t).  Several clamped entries in some
 	// instance of the wavefront (wave-uniform): M_BIE is factored alongside M and everything is formed twice.
-	double mi[N], mb[N];
+	double mi[N] = {0, 0, 0, 0, 0, 0, 0}, mb[N] = {0, 0, 0, 0, 0, 0, 0};
 	int eclamp = 0;
 	double cclamp = 0.0;
 	bool general_bie = false;
-	{
+	if (roleA) {
 		double L[N][N], dinv[N];
 		UNR for (int i = 0; i < N; i++)
 			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.M[i][j];
@@ -426,15 +457,15 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 	}
 	const bool rank1_bie = P.any_bie && !general_bie;
-	if (rank1_bie && r == eclamp) {
+	if (roleA && rank1_bie && r == eclamp) {
 		UNR for (int j = 0; j < N; j++) sm.vec[3][j] = mi[j];  // column e of M^-1 for the whole instance (read after the next barrier)
 	}
 	STAMP(4);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
-	double vw[6];
-	{
+	double vw[6] = {0, 0, 0, 0, 0, 0};
+	if (roleB) {
 		double dqa[N];
 		UNR for (int j = 0; j < N; j++) dqa[j] = sm.vec[0][j];
 		UNR for (int a = 0; a < 6; a++) {
@@ -454,7 +485,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
-	{
+	if (roleB) {
 		double tr = 0.0;
 		UNR for (int a = 0; a < 6; a++)
 			UNR for (int c = 0; c <= a; c++) {
@@ -561,9 +592,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 						if (sqrt(fmax(sm.A[i][i], 0.0)) / s0 < mf.s_max) sing = true;
 					sm.vec[9][0] = sing ? 1.0 : 0.0;
 				}
-				__syncthreads();
+				oct_sync<DUO>();
 				if (need_exact) singular = sm.vec[9][0] != 0.0;
-				__syncthreads();
+				oct_sync<DUO>();
 			}
 		}
 	}
@@ -604,9 +635,9 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int i = 0; i < 6; i++) sj = fma(U6[i][a], jc6[i], sj);
 			jn[a] = keepm[a] ? sj : 0.0;
 		}
-		__syncthreads();
+		oct_sync<DUO>();
 		UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jn[a];
-		__syncthreads();
+		oct_sync<DUO>();
 		UNR for (int a = 0; a < 6; a++)
 			UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
 	}
@@ -618,8 +649,8 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	UNR for (int j = 0; j < N; j++) mcol[j] = 0.0;
 	const int ra = r < 6 ? r : 5;
 	UNR for (int a = 0; a < 6; a++) keep_ra = (a == ra) ? (keepm[a] && a < kmf) : keep_ra;
-	double t1c[6];
-	{
+	double t1c[6] = {0, 0, 0, 0, 0, 0};
+	if (roleA) {
 		double tbc[6];
 		UNR for (int a = 0; a < 6; a++) {
 			double s1 = 0.0, s2 = 0.0;
@@ -634,7 +665,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.T1[a][r] = t1c[a];
 			if (general_bie) sm.Lam[a][r] = tbc[a];
 		}
-		__syncthreads();
+		oct_sync<DUO>();
 		if (rank1_bie) {
 			double mee = 0.0;
 			UNR for (int j = 0; j < N; j++) {
@@ -658,17 +689,19 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.A[r][c] = padrow ? 1.0 : s;
 			if (general_bie) sm.Am[r][c] = padrow ? 1.0 : s2;
 		}
+		oct_sync<DUO>();
 	}
-	__syncthreads();
 	STAMP(8);
 	double lam[6], lmod[6];
 	// headline stack (GJ == 0): nobody needs Lambda itself, only its action on three vectors -- every lane keeps the Cholesky factor of
 	// A = J M^-1 J^T and solves (no row of the inverse, no exchange of Lambda between the lanes)
 	double L6[6][6], dinv6[6];
 	if (GJ == 0) {
-		UNR for (int i = 0; i < 6; i++)
-			UNR for (int j = 0; j <= i; j++) L6[i][j] = sm.A[i][j];
-		oct_cholesky<6>(L6, dinv6);
+		if (roleA) {
+			UNR for (int i = 0; i < 6; i++)
+				UNR for (int j = 0; j <= i; j++) L6[i][j] = sm.A[i][j];
+			oct_cholesky<6>(L6, dinv6);
+		}
 	} else {
 		double L[6][6], dinv[6];
 		UNR for (int i = 0; i < 6; i++)
@@ -693,7 +726,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 				lt_own = fma(lam[a], sacc, lt_own);  // (Lambda t)_ra: Lambda symmetric, lam = its row ra
 			}
 			sm.vec[4][r] = lt_own;
-			__syncthreads();
+			oct_sync<DUO>();
 			double lt[6], q = 0.0;
 			UNR for (int a = 0; a < 6; a++) {
 				lt[a] = sm.vec[4][a];
@@ -710,7 +743,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	double Fum6[6], Ff6[6] = {0, 0, 0, 0, 0, 0};  // GJ == 0: the task forces, identical in every lane of the instance
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
 	const bool track_mf = (mf.has_ki || P.integ_always);
-	{
+	if (roleB) {
 		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6], G24[24];
 		UNR for (int e = 0; e < 24; e++) G24[e] = sm.vec[10 + (e >> 3)][e & 7];
 		if (track_mf) {
@@ -797,7 +830,24 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			sm.vec[2][r] = s;
 		}
 	}
-	if (GJ != 0) __syncthreads();
+	if (GJ != 0) oct_sync<DUO>();
+	if (DUO) {
+		// the one workgroup barrier: B publishes the branch predicate and the task force, A picks them up
+		if (ROLE == 2) {
+			if (r < 6) {
+				double fo = 0.0;
+				UNR for (int a = 0; a < 6; a++) fo = (a == r) ? Fum6[a] : fo;
+				sm.vec[6][r] = fo;
+			}
+			if (r == 6) sm.vec[6][6] = singular ? 1.0 : 0.0;
+		}
+		STAMP(29);
+		__syncthreads();
+		STAMP(30);
+		if (ROLE == 2) return;
+		UNR for (int a = 0; a < 6; a++) Fum6[a] = smB.vec[6][a];
+		singular = smB.vec[6][6] != 0.0;
+	}
 	STAMP(10);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
 	// basis works on), N1[i][rr] = d_i,rr - sum_a T1[a][i] (Lambda J[:, rr])_a, and parks it as a row of the transposed matrix
@@ -924,14 +974,6 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		}
 		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
 
-		// ------------------------------------------------------------------------------------------------------------------------------
-		// Blended singularity strategies, in this kernel (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367; the reference's default
-		// whenever the task is inside its singularity bounds).  Only wavefronts that hold such an instance come here.  Everything happens
-		// in the eigenbasis of G = J J^T (register Jacobi solve; no sorting needed: the non-singular set K = { c : sigma_c >= s_max
-		// sigma_max } is a prefix of the sorted spectrum, and everything else is invariant to the order inside K and inside S):
-		//   J_u = U^T J,  A_u = U^T (J M^-1 J^T) U,  B = blockdiag(A_u[K,K], A_u[S,S]) -> one Cholesky gives Lambda_ns and Lambda_s,
-		//   posture Jacobian V_s^T N_ns = D^-1 (J_S - A_SK Lambda_ns J_K), its op-space inertia = D^-1 (Schur complement of A_u) D^-1,
-		//   N = N_js N_ns projects onto null(J) again, so the joint task behind keeps its closed rank-one form with z from U.
 		// ------------------------------------------------------------------------------------------------------------------------------
 		// Blended singularity strategies, in this kernel (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367; the reference's default
 		// whenever the task is inside its singularity bounds).  Only wavefronts that hold such an instance come here.  Everything happens
@@ -1399,7 +1441,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		sm.vec[7][r] = jg_q;
 		sm.vec[8][r] = jg_dq;
 		sm.vec[3][r] = jg_ddq;
-		__syncthreads();
+		oct_sync<DUO>();
 		double Jh[4][N];
 		UNR for (int c = 0; c < 4; c++)
 			UNR for (int j = 0; j < N; j++) Jh[c][j] = sm.T1[c][j];
@@ -1558,7 +1600,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		double tauv[N];
 		UNR for (int j = 0; j < N; j++) tauv[j] = sm.vec[1][j];
 		UNR for (int c = 0; c < 5; c++) sm.T1[c][r] = jh[c];
-		__syncthreads();
+		oct_sync<DUO>();
 		double Jh[5][N];
 		UNR for (int c = 0; c < 5; c++)
 			UNR for (int j = 0; j < N; j++) Jh[c][j] = sm.T1[c][j];
@@ -1657,7 +1699,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 		if (__any(in_zone)) {
 			sm.vec[1][r] = tv;
 			sm.vec[3][r] = in_zone ? 1.0 : 0.0;
-			__syncthreads();
+			oct_sync<DUO>();
 			double tall[N], zall[N];
 			UNR for (int j = 0; j < N; j++) {
 				tall[j] = sm.vec[1][j];
@@ -1667,7 +1709,7 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 			UNR for (int j = 0; j < N; j++) sacc = fma(mi[j], tall[j], sacc);  // (M^-1 tau)_rr
 			sm.vec[4][r] = in_zone ? sacc : 0.0;
 			UNR for (int j = 0; j < N; j++) sm.N1[r][j] = (in_zone && zall[j] != 0.0) ? mi[j] : ((j == rr) ? 1.0 : 0.0);  // N1 is dead: masked M^-1
-			__syncthreads();
+			oct_sync<DUO>();
 			double L[N][N], dinv[N], y[N], x[N];
 			UNR for (int i = 0; i < N; i++)
 				UNR for (int j = 0; j <= i; j++) L[i][j] = sm.N1[i][j];
@@ -1723,18 +1765,36 @@ __global__ void __launch_bounds__(64) saip_cycle_oct(const CycleParams P) {
 	STAMP(15);
 }
 
+template <bool FULL, int GJ, bool DUO = false>
+__global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CycleParams P) {
+	__shared__ OctInst smem[DUO ? 16 : 8];
+	if (DUO) {
+		if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem + 8);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0>(P, smem, smem + 8);
+	} else {
+		oct_cycle_body<FULL, GJ, 0>(P, smem, smem);
+	}
+}
+
+// two wavefronts per instance group for the lean stack (SAIP_OCT_NO_DUO=1: the one-wavefront form, for A/B measurements)
+static bool oct_duo_enabled() {
+	static const bool on = getenv("SAIP_OCT_NO_DUO") == nullptr;
+	return on;
+}
+
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
 	if (P.oct_general_joint == 1) hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
 	else if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
 	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
+	else if (oct_duo_enabled()) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
 	else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
 	return hipGetLastError();
 }
 
 #if defined(SAIP_STAMP_OCT)
 extern "C" int saip_debug_stamps_oct(unsigned long long* out, int n) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_oct), sizeof(unsigned long long) * (n < 1024 * 32 ? n : 1024 * 32));
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_oct), sizeof(unsigned long long) * (n < 1024 * 64 ? n : 1024 * 64));
 }
 #endif
 }  // namespace saip

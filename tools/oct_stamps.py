@@ -16,10 +16,11 @@ NB = B // 8
 runs = []
 for rep in range(12):
     ctrl.stepAsync(); ctrl.synchronize()
-    buf = (C.c_ulonglong * (1024 * 32))()
-    capi.lib().saip_debug_stamps_oct(buf, 1024 * 32)
-    runs.append(np.array(buf[:], dtype=np.float64).reshape(1024, 32)[:NB])
-s = runs[-1]
+    buf = (C.c_ulonglong * (1024 * 64))()
+    capi.lib().saip_debug_stamps_oct(buf, 1024 * 64)
+    full = np.array(buf[:], dtype=np.float64).reshape(1024, 2, 32)[:NB]
+    runs.append(full)
+s, sB = runs[-1][:, 0], runs[-1][:, 1]
 idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15]               # stamp 11 sits in the general joint task (not run by the headline stack); 12, 13 are not placed
 names = ["input requests", "kinematics + Ic", "M column", "chol7 + M^-1 column", "Jf / vw", "-", "G + certificate",
          "T1 / A", "chol6 + solves", "law + g", "tau, row of N1, joint task (+ blended block)", "post + stores"]
@@ -37,3 +38,10 @@ if has.any() and (bl[has][:, -1] > bl[has][:, 0]).all():
     for i, n_ in enumerate(["G + Jacobi", "Ju / sigma", "decisions + pass-through", "state + control frame", "classification", "state update", "A_u / A_mod,u",
                             "block Cholesky x2", "forces", "solves + Schur", "Cholesky Pm + unit torques + tjs", "joint task behind"]):
         print(f"  {n_:46s} {db[:, i].min():8.0f} {np.median(db[:, i]):8.0f} {db[:, i].max():8.0f}")
+if (sB[:, 29] > 0).all():
+    print("two-wavefront form: wavefront B (shader clocks relative to its own start; A's clock is the same counter)")
+    for lab, i0, i1 in [("B inputs", 0, 1), ("B kinematics", 1, 2), ("B Jacobian column", 2, 3), ("B Jf / vw", 4, 5), ("B G + certificate", 6, 7), ("B law", 9, 29)]:
+        dd = sB[:, i1] - sB[:, i0]
+        print(f"  {lab:46s} {dd.min():8.0f} {np.median(dd):8.0f} {dd.max():8.0f}")
+    print(f"  B start -> barrier: median {np.median(sB[:, 29] - sB[:, 0]):.0f};  A start -> barrier passed: median {np.median(s[:, 30] - s[:, 0]):.0f};"
+          f"  A waits at the barrier (stamp 9 -> 30): median {np.median(s[:, 30] - s[:, 9]):.0f};  B start - A start: median {np.median(sB[:, 0] - s[:, 0]):.0f}")
