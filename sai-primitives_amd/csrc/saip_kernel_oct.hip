@@ -222,7 +222,7 @@ __device__ __forceinline__ void oct_sync() {
 // ROLE 0: the whole cycle in one wavefront; 1 / 2: wavefront A / B of the two-wavefront form (compile-time, so that neither carries the
 // other's registers: as run-time branches of one body the merged live ranges spilled)
 template <bool FULL, int GJ, int ROLE>
-__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemB) {
+__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	static_assert(!DUO || (!FULL && GJ == 0), "two wavefronts per instance group: lean headline stack only");
@@ -232,6 +232,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	const int rr = r < N ? r : N - 1;  // padding lane mirrors joint 6 and never writes
 	const bool act = r < N;
 	OctInst& sm = smem[grp];
+	OctInst& smA = smemA[grp];  // wavefront A's block (B reads A = J M^-1 J^T, T1 and M^-1 from it after the first barrier)
 	OctInst& smB = smemB[grp];  // where wavefront B leaves its results
 	const int b_raw = blockIdx.x * 8 + grp;
 	const bool live = b_raw < P.B;
@@ -455,6 +456,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			oct_solve_unit<N>(L, dinv, rr, mi);
 			UNR for (int j = 0; j < N; j++) mb[j] = mi[j];
 		}
+	}
+	if (ROLE == 1) {
+		UNR for (int j = 0; j < N; j++) sm.N1[r][j] = mi[j];
 	}
 	const bool rank1_bie = P.any_bie && !general_bie;
 	if (roleA && rank1_bie && r == eclamp) {
@@ -697,7 +701,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	// A = J M^-1 J^T and solves (no row of the inverse, no exchange of Lambda between the lanes)
 	double L6[6][6], dinv6[6];
 	if (GJ == 0) {
-		if (roleA) {
+		if (!DUO) {
 			UNR for (int i = 0; i < 6; i++)
 				UNR for (int j = 0; j <= i; j++) L6[i][j] = sm.A[i][j];
 			oct_cholesky<6>(L6, dinv6);
@@ -832,7 +836,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}
 	if (GJ != 0) oct_sync<DUO>();
 	if (DUO) {
-		// the one workgroup barrier: B publishes the branch predicate and the task force, A picks them up
+		// first workgroup barrier: B publishes the branch predicate and the task force; A has left A = J M^-1 J^T, T1 and M^-1 in its block
 		if (ROLE == 2) {
 			if (r < 6) {
 				double fo = 0.0;
@@ -844,9 +848,18 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		STAMP(29);
 		__syncthreads();
 		STAMP(30);
-		if (ROLE == 2) return;
-		UNR for (int a = 0; a < 6; a++) Fum6[a] = smB.vec[6][a];
-		singular = smB.vec[6][6] != 0.0;
+		if (ROLE == 1) {
+			UNR for (int a = 0; a < 6; a++) Fum6[a] = smB.vec[6][a];
+			singular = smB.vec[6][6] != 0.0;
+		}
+		// both factor A (B cannot wait for A's factor: the tail is split between them from here)
+		UNR for (int i = 0; i < 6; i++)
+			UNR for (int j = 0; j <= i; j++) L6[i][j] = smA.A[i][j];
+		oct_cholesky<6>(L6, dinv6);
+		if (ROLE == 2) {
+			UNR for (int a = 0; a < 6; a++) t1c[a] = smA.T1[a][r];
+			UNR for (int j = 0; j < N; j++) mi[j] = smA.N1[r][j];
+		}
 	}
 	STAMP(10);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
@@ -861,6 +874,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		// g = y1 + gamma y2 (t . y1), y1 = A^-1 F, y2 = A^-1 t, gamma = beta / (1 - beta t . y2); several clamped entries: A_mod is
 		// factored too.  tau_1 = J^T g in full in every lane (the joint task's disturbance compensation wants M^-1 tau_1).
 		double g[6];
+		double wr = 0.0;
+		tau_r = 0.0;
+		if (roleA) {
 		if (mf.decoupling == DEC_IMPEDANCE) {
 			UNR for (int a = 0; a < 6; a++) g[a] = Fum6[a] + Ff6[a];
 		} else if (mf.decoupling == DEC_BIE && general_bie) {
@@ -891,15 +907,15 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				UNR for (int a = 0; a < 6; a++) g[a] = y1[a] + Ff6[a];
 			}
 		}
-		double tau1[N], wr = 0.0;
+		double tau1[N];
 		UNR for (int j = 0; j < N; j++) {
 			double s = 0.0;
 			UNR for (int a = 0; a < 6; a++) s = fma(Jf[a][j], g[a], s);
 			tau1[j] = s;
 			wr = fma(mi[j], s, wr);  // (M^-1 tau_prec)_rr: M^-1 symmetric, mi = its column rr
 		}
-		tau_r = 0.0;
 		UNR for (int j = 0; j < N; j++) tau_r = (j == rr) ? tau1[j] : tau_r;
+		}  // roleA
 		// ---- JointTask (S = I) in the nullspace of the 6-dof task, JointTask.cpp:218-356.  N_1 = I - M^-1 J^T Lambda J has rank one:
 		// N_1 = z z^T M / (z^T M z), z spanning null(J).  Its ROW rr, e_rr - J^T (A^-1 t1c) with t1c = this lane's column of T1 = J M^-1,
 		// needs nothing from the other lanes and is z_rr (M z)^T / (z^T M z).  The row of largest norm (largest |z_rr|) is broadcast:
@@ -908,6 +924,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		//   tau_joint = Jh^T (Lambda a1 + Lambda_mod b1) = v / |z'|^2 (z'.a + rho z'.f),   a = ddq_d - M^-1 tau_prec, f = the PD(I) force,
 		// rho = Lambda_mod / Lambda: 1 (full decoupling), |z'|^2 / z'.v (impedance), z'.v / (z'.v - beta z'_e^2) (bounded inertia, one
 		// clamped entry e: M_BIE^-1 = M^-1 - beta m m^T and m^T M z' = z'_e), z'.v / (v^T M_BIE^-1 v) (several clamped entries).
+		double v[N] = {0, 0, 0, 0, 0, 0, 0}, zr = 0.0, v_own = 0.0, zz = 0.0, zv = 0.0;
+		if (roleB) {
 		double x6[6], rowv[N], nr = 0.0;
 		oct_solve<6>(L6, dinv6, t1c, x6);
 		UNR for (int j = 0; j < N; j++) {
@@ -931,13 +949,17 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
 #undef OCT_ARGMAX_STEP
 		const int src = (lane & ~7) | jbw;
-		double v[N], zr = 0.0, v_own = 0.0;
 		UNR for (int j = 0; j < N; j++) {
 			v[j] = __shfl(rowv[j], src);
 			zr = fma(mi[j], v[j], zr);
 			v_own = (j == rr) ? v[j] : v_own;
 		}
 		zr = act ? zr : 0.0;
+		zz = oct_group_sum(zr * zr);
+		zv = oct_group_sum(zr * v_own);
+		}  // roleB
+		double fi = 0.0;
+		if (roleA) {
 		// control law of this lane's joint (JointTask.cpp:299-345)
 		const bool track = (jt.has_ki || P.integ_always);
 		const double e = q_r - jg_q;
@@ -945,7 +967,6 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		if (track) ie = jt.integ[(size_t)rr * ld + b];
 		ie += e * jt.dt;  // :323-324
 		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
-		double fi;
 		if (jt.vel_sat) {  // :327-341
 			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
 			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
@@ -953,9 +974,27 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		} else {
 			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
 		}
+		}
+		if (DUO) {
+			// second workgroup barrier: B hands over the nullspace direction (z', v = M z up to scale, |z'|^2, z'.v) and exits
+			if (ROLE == 2) {
+				sm.vec[7][r] = zr;
+				sm.vec[8][r] = v_own;
+				if (r == 0) {
+					sm.vec[3][0] = zz;
+					sm.vec[3][1] = zv;
+					UNR for (int j = 0; j < N; j++) sm.vec[4][j] = v[j];
+				}
+			}
+			STAMP(31);
+			__syncthreads();
+			if (ROLE == 2) return;
+			zr = smB.vec[7][r];
+			v_own = smB.vec[8][r];
+			zz = smB.vec[3][0];
+			zv = smB.vec[3][1];
+		}
 		const double ai = jg_ddq - wr;
-		const double zz = oct_group_sum(zr * zr);
-		const double zv = oct_group_sum(zr * v_own);
 		const double za = oct_group_sum(zr * ai);
 		const double zf = oct_group_sum(zr * fi);
 		double rho = 1.0;
@@ -963,6 +1002,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			rho = zz * oct_rcp(zv);
 		} else if (jt.decoupling == DEC_BIE) {
 			if (general_bie) {
+				if (DUO) {
+					UNR for (int j = 0; j < N; j++) v[j] = smB.vec[4][j];
+				}
 				double mbv = 0.0;
 				UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], v[j], mbv);  // (M_BIE^-1 v)_rr
 				const double qb = oct_group_sum(act ? v_own * mbv : 0.0);
@@ -1002,19 +1044,19 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				oct_jacobi_n<6>(E, Ue);
 			}
 			STAMP(17);
-			double Ju[6][N];
+			double tu[6];  // J_u m: the rank-one bounded-inertia form needs it (rows of J_u = U^T J are used on the fly, not kept: 84 registers)
 			UNR for (int c = 0; c < 6; c++) {
-				double s2 = 0.0;
+				double s2 = 0.0, own = 0.0, tacc = 0.0;
 				UNR for (int j = 0; j < N; j++) {
 					double acc = 0.0;
 					UNR for (int i = 0; i < 6; i++) acc = fma(Ue[i][c], Jf[i][j], acc);
-					Ju[c][j] = acc;
 					s2 = fma(acc, acc, s2);
+					own = (j == rr) ? acc : own;
+					tacc = fma(acc, mcol[j], tacc);
 				}
+				tu[c] = tacc;
 				sig[c] = sqrt(s2);  // singular values from the rows themselves: accurate down to ~1e-10 sigma_max (the Gram eigenvalue is not)
 				smax = fmax(smax, sig[c]);
-				double own = 0.0;
-				UNR for (int j = 0; j < N; j++) own = (j == rr) ? Ju[c][j] : own;
 				ju[c] = own;
 			}
 			STAMP(18);
@@ -1195,12 +1237,6 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 								Amu[d][c] = acc;
 							}
 					} else {
-						double tu[6];
-						UNR for (int c = 0; c < 6; c++) {
-							double acc = 0.0;
-							UNR for (int l = 0; l < N; l++) acc = fma(Ju[c][l], mcol[l], acc);
-							tu[c] = acc;
-						}
 						const double bb = (mf.decoupling == DEC_BIE) ? beta : 0.0;  // rank-one form: A_mod = A - beta t t^T (beta = 0: nothing clamped)
 						UNR for (int c = 0; c < 6; c++)
 							UNR for (int d = 0; d < 6; d++) Amu[c][d] = fma(-bb * tu[c], tu[d], Au[c][d]);
@@ -1769,10 +1805,10 @@ template <bool FULL, int GJ, bool DUO = false>
 __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CycleParams P) {
 	__shared__ OctInst smem[DUO ? 16 : 8];
 	if (DUO) {
-		if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem + 8);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0>(P, smem, smem + 8);
+		if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem, smem + 8);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0>(P, smem, smem, smem + 8);
 	} else {
-		oct_cycle_body<FULL, GJ, 0>(P, smem, smem);
+		oct_cycle_body<FULL, GJ, 0>(P, smem, smem, smem);
 	}
 }
 

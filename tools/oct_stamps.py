@@ -45,3 +45,5 @@ if (sB[:, 29] > 0).all():
         print(f"  {lab:46s} {dd.min():8.0f} {np.median(dd):8.0f} {dd.max():8.0f}")
     print(f"  B start -> barrier: median {np.median(sB[:, 29] - sB[:, 0]):.0f};  A start -> barrier passed: median {np.median(s[:, 30] - s[:, 0]):.0f};"
           f"  A waits at the barrier (stamp 9 -> 30): median {np.median(s[:, 30] - s[:, 9]):.0f};  B start - A start: median {np.median(sB[:, 0] - s[:, 0]):.0f}")
+    if (s[:, 31] > 0).all():
+        print(f"  second barrier: A arrives {np.median(s[:, 31] - s[:, 30]):.0f} after the first one, B {np.median(sB[:, 31] - s[:, 30]):.0f};  A: second barrier -> end of the tail {np.median(s[:, 14] - s[:, 31]):.0f}")
