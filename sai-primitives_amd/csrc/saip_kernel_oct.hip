@@ -1454,17 +1454,54 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				Gp[k][i] = gs;
 				if (i == k) trp += gs;
 			}
-		oct_jacobi4(Gp, V4);
-		double lmaxp = 0.0;
-		UNR for (int c = 0; c < 4; c++) lmaxp = fmax(lmaxp, Gp[c][c]);
-		const bool any_range = (sqrt(fmax(trp, 0.0)) >= 1e-3) && (sqrt(lmaxp) >= 1e-3);
+		// Usual case: Jp has full row rank, matrixRangeBasis returns the identity (sai-model: task_dof == rows) and no eigen-solve is needed.
+		// Certificate (the one of the motion-force branch predicate): lambda_max <= trace, so a positive definite  Gp - 1e-6 trace I  on
+		// the m task rows proves sigma_min / sigma_max > 1e-3; trace / m >= 1e-6 proves sigma_max >= 1e-3.  Only wavefronts that hold an
+		// instance it cannot decide run the register Jacobi solve (measured, config 3: 19 k of 40 k clocks per wavefront were this solve).
+		bool full_rank = trp * 0.25 >= 1e-6;
+		{
+			double Gs[4][4];
+			const double sh = 1e-6 * trp;
+			UNR for (int i = 0; i < 4; i++)
+				UNR for (int k = 0; k <= i; k++) Gs[i][k] = Gp[i][k];
+			UNR for (int i = 0; i < 4; i++) Gs[i][i] = (i < mj) ? Gs[i][i] - sh : 1.0;
+			UNR for (int kk = 0; kk < 4; kk++) {
+				const double d = Gs[kk][kk];
+				full_rank = full_rank && (d > 1e-13 * trp);
+				const double id = oct_rcp(d);
+				UNR for (int i = kk + 1; i < 4; i++) {
+					const double lik = Gs[i][kk] * id;
+					UNR for (int k = kk + 1; k <= i; k++) Gs[i][k] = fma(-lik, Gs[k][kk], Gs[i][k]);
+				}
+			}
+		}
+#if defined(SAIP_OCT_FORCE_EXACT)
+		full_rank = false;
+#endif
 		bool keep[4];
 		double jh[4];
+		UNR for (int i = 0; i < 4; i++)
+			UNR for (int k = 0; k < 4; k++) V4[i][k] = (i == k) ? 1.0 : 0.0;
 		UNR for (int c = 0; c < 4; c++) {
-			keep[c] = any_range && (sqrt(fmax(Gp[c][c], 0.0) / lmaxp) >= 1e-3);
-			double sj = 0.0;
-			UNR for (int i = 0; i < 4; i++) sj = fma(V4[i][c], cp[i], sj);
-			jh[c] = keep[c] ? sj : 0.0;  // own column of Jh = U^T Jp
+			keep[c] = c < mj;
+			jh[c] = keep[c] ? cp[c] : 0.0;
+		}
+		if (__any(!full_rank)) {
+			double Ve[4][4];
+			oct_jacobi4(Gp, Ve);
+			double lmaxp = 0.0;
+			UNR for (int c = 0; c < 4; c++) lmaxp = fmax(lmaxp, Gp[c][c]);
+			const bool any_range = (sqrt(fmax(trp, 0.0)) >= 1e-3) && (sqrt(lmaxp) >= 1e-3);
+			UNR for (int c = 0; c < 4; c++) {
+				const bool kc = any_range && (sqrt(fmax(Gp[c][c], 0.0) / lmaxp) >= 1e-3);
+				double sj = 0.0;
+				UNR for (int i = 0; i < 4; i++) sj = fma(Ve[i][c], cp[i], sj);
+				if (!full_rank) {
+					keep[c] = kc;
+					jh[c] = kc ? sj : 0.0;  // own column of Jh = U^T Jp
+					UNR for (int i = 0; i < 4; i++) V4[i][c] = Ve[i][c];
+				}
+			}
 		}
 		// gather Jh, q, the joint-task goal rows and w = M^-1 tau_prec for the whole instance
 		double tauv[N];
@@ -1812,10 +1849,18 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CyclePara
 	}
 }
 
-// two wavefronts per instance group for the lean stack (SAIP_OCT_NO_DUO=1: the one-wavefront form, for A/B measurements)
-static bool oct_duo_enabled() {
+// two wavefronts per instance group for the lean stack while the launch still fits the chip in one round (two workgroups per CU = one
+// wavefront per SIMD: 4096 instances on 256 CUs); beyond that the second wavefront only competes for issue slots (measured, B = 6144:
+// 14.3 us against 10.8 us).  SAIP_OCT_NO_DUO=1: the one-wavefront form, for A/B measurements.
+static bool oct_duo_enabled(const int workgroups) {
 	static const bool on = getenv("SAIP_OCT_NO_DUO") == nullptr;
-	return on;
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0, n = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+		cus = n;
+	}
+	return on && workgroups <= 2 * cus;
 }
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
@@ -1823,7 +1868,7 @@ hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	if (P.oct_general_joint == 1) hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
 	else if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
 	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
-	else if (oct_duo_enabled()) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
+	else if (oct_duo_enabled((int)grid.x)) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
 	else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
 	return hipGetLastError();
 }

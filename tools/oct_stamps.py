@@ -7,7 +7,7 @@ import workloads as W
 from sai_primitives_amd import capi
 from sai_primitives_amd.controller import controller_from_specs
 CFG = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-B = 4096
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 d = W.make_inputs(CFG, B)
 robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
 ctrl.setKernel(3)
