@@ -390,8 +390,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 	}
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint
-	double pw[3], Rc[9], jwc[6];  // control point, control frame, this joint's column of the world Jacobian [Jv; Jw]
-	{
+	// (two-wavefront form: B alone forms it, A takes the Jacobian from B's block behind the barrier below -- B gets there first)
+	double pw[3] = {0, 0, 0}, Rc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, jwc[6] = {0, 0, 0, 0, 0, 0};  // control point, control frame, this joint's column of the world Jacobian [Jv; Jw]
+	if (ROLE != 1) {
 		const int bd = mf.body;
 		double Rb[12];
 		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[bd][e];
@@ -415,7 +416,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
 		}
 	}
-	oct_sync<DUO>();
+	if (DUO) __syncthreads();  // workgroup barrier: B's Jacobian is complete (A arrives ~1 k clocks after B)
+	else oct_sync<DUO>();
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
 	// M_BIE = M + sum_e c_e e e^T, the diagonal clamped from below (SingularityHandler.cpp:176-182).  Usual case (at most one clamped
@@ -467,7 +469,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	STAMP(4);
 	double Jf[6][N];
 	UNR for (int a = 0; a < 6; a++)
-		UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
+		UNR for (int j = 0; j < N; j++) Jf[a][j] = (ROLE == 1 ? smB : sm).J[a][j];
 	double vw[6] = {0, 0, 0, 0, 0, 0};
 	if (roleB) {
 		double dqa[N];
@@ -485,7 +487,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	STAMP(6);
 	// ---- SingularityHandler branch predicate on G = J J^T (N_prec = I for the first task), every lane of the instance alike
 	bool singular = false, truncated = false, blended_i = false;
+#if defined(SAIP_OCT_EXP_NO_BLEND)  // diagnostic build only: what the blended block costs the ordinary path
+	const bool strategies_on = false;
+#else
 	const bool strategies_on = GJ == 0 && mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform; the blended branch lives in the headline stack's tail
+#endif
 	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
