@@ -699,6 +699,16 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			sm.A[r][c] = padrow ? 1.0 : s;
 			if (general_bie) sm.Am[r][c] = padrow ? 1.0 : s2;
 		}
+		if (ROLE == 1) {  // what the blended block (run by B) wants from this wavefront besides A, T1, M and the columns of M^-1
+			if (general_bie) {
+				UNR for (int j = 0; j < N; j++) sm.Lam[r][j] = mb[j];  // (its rows were consumed above)
+			}
+			if (r == 0) {
+				sm.vec[9][0] = beta;
+				sm.vec[9][1] = (double)eclamp;
+				sm.vec[9][2] = general_bie ? 1.0 : 0.0;
+			}
+		}
 		oct_sync<DUO>();
 	}
 	STAMP(8);
@@ -849,14 +859,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				UNR for (int a = 0; a < 6; a++) fo = (a == r) ? Fum6[a] : fo;
 				sm.vec[6][r] = fo;
 			}
-			if (r == 6) sm.vec[6][6] = singular ? 1.0 : 0.0;
 		}
 		STAMP(29);
 		__syncthreads();
 		STAMP(30);
 		if (ROLE == 1) {
 			UNR for (int a = 0; a < 6; a++) Fum6[a] = smB.vec[6][a];
-			singular = smB.vec[6][6] != 0.0;
 		}
 		// both factor A (B cannot wait for A's factor: the tail is split between them from here)
 		UNR for (int i = 0; i < 6; i++)
@@ -981,25 +989,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
 		}
 		}
-		if (DUO) {
-			// second workgroup barrier: B hands over the nullspace direction (z', v = M z up to scale, |z'|^2, z'.v) and exits
-			if (ROLE == 2) {
-				sm.vec[7][r] = zr;
-				sm.vec[8][r] = v_own;
-				if (r == 0) {
-					sm.vec[3][0] = zz;
-					sm.vec[3][1] = zv;
-					UNR for (int j = 0; j < N; j++) sm.vec[4][j] = v[j];
-				}
-			}
-			STAMP(31);
-			__syncthreads();
-			if (ROLE == 2) return;
-			zr = smB.vec[7][r];
-			v_own = smB.vec[8][r];
-			zz = smB.vec[3][0];
-			zv = smB.vec[3][1];
-		}
+		double tvo = 0.0;
+		bool ovr = false;
+		if (ROLE == 0) {
 		const double ai = jg_ddq - wr;
 		const double za = oct_group_sum(zr * ai);
 		const double zf = oct_group_sum(zr * fi);
@@ -1021,7 +1013,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 		}
 		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
-
+		}
 		// ------------------------------------------------------------------------------------------------------------------------------
 		// Blended singularity strategies, in this kernel (SingularityHandler.cpp:100-121, 146-228, 230-295, 310-367; the reference's default
 		// whenever the task is inside its singularity bounds).  Only wavefronts that hold such an instance come here.  Everything happens
@@ -1030,7 +1022,31 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		//   J_u = U^T J,  A_u = U^T (J M^-1 J^T) U,  B = blockdiag(A_u[K,K], A_u[S,S]) -> one Cholesky gives Lambda_ns and Lambda_s,
 		//   posture Jacobian V_s^T N_ns = D^-1 (J_S - A_SK Lambda_ns J_K), its op-space inertia = D^-1 (Schur complement of A_u) D^-1,
 		//   N = N_js N_ns projects onto null(J) again, so the joint task behind keeps its closed rank-one form with z from U.
-		if (__builtin_expect(strategies_on && __any(singular), 0)) {
+		if (ROLE != 1 && __builtin_expect(strategies_on && __any(singular), 0)) {
+			if (ROLE == 2) {
+				// wavefront B runs the block in the two-wavefront form (it is off A's critical path and A's registers stay out of it): what the
+				// ordinary path left in A's block, and the joint task's goal and control law once more (no shadow integrator store here: A's)
+				eclamp = (int)smA.vec[9][1];
+				general_bie = smA.vec[9][2] != 0.0;
+				beta = smA.vec[9][0];
+				const bool r1b = P.any_bie && !general_bie;
+				UNR for (int j = 0; j < N; j++) mcol[j] = r1b ? smA.vec[3][j] : 0.0;
+				UNR for (int j = 0; j < N; j++) mb[j] = general_bie ? smA.Lam[r][j] : mi[j];
+				jg_q = jt.goal[(size_t)rr * ld + b];
+				jg_dq = jt.goal[(size_t)(N + rr) * ld + b];
+				jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
+				const double e = q_r - jg_q;
+				double ie = 0.0;
+				if (jt.has_ki || P.integ_always) ie = jt.integ[(size_t)rr * ld + b];
+				ie += e * jt.dt;
+				if (jt.vel_sat) {
+					double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
+					vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
+					fi = -jt.kv[rr] * (dq_r - vdes);
+				} else {
+					fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;
+				}
+			}
 			STAMP(16);
 			double Ue[6][6], sig[6], ju[6];
 			bool keep[6];
@@ -1091,14 +1107,15 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				UNR for (int j = 0; j < N; j++) {
 					const int src = (lane & ~7) | j;
 					const double aj = __shfl(af, src), fj = __shfl(ff, src);
-					const double mrj = (j <= rr) ? sm.M[rr][j] : sm.M[j][rr];
+					const double mrj = (j <= rr) ? smA.M[rr][j] : smA.M[j][rr];
 					double mmod = mrj;
 					if (jt.decoupling == DEC_IMPEDANCE) mmod = (j == rr) ? 1.0 : 0.0;
 					else if (jt.decoupling == DEC_BIE) mmod = (j == rr) ? fmax(mrj, jt.bie_threshold) : mrj;
 					acc = fma(mrj, aj, fma(mmod, fj, acc));
 				}
 				if (singular && fully) {
-					tv = acc;
+					tvo = acc;
+					ovr = true;
 					singular = false;
 					truncated = true;
 				}
@@ -1207,7 +1224,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					double Af[6][6], W[6][6];
 					UNR for (int i = 0; i < 6; i++)
 						UNR for (int j = 0; j <= i; j++) {
-							Af[i][j] = sm.A[i][j];
+							Af[i][j] = smA.A[i][j];
 							Af[j][i] = Af[i][j];
 						}
 					UNR for (int i = 0; i < 6; i++)
@@ -1226,7 +1243,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					if (mf.decoupling == DEC_BIE && general_bie) {
 						UNR for (int i = 0; i < 6; i++)
 							UNR for (int j = 0; j <= i; j++) {
-								Af[i][j] = sm.Am[i][j];
+								Af[i][j] = smA.Am[i][j];
 								Af[j][i] = Af[i][j];
 							}
 						UNR for (int i = 0; i < 6; i++)
@@ -1386,7 +1403,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				UNR for (int j = 0; j < N; j++) {
 					const int srcj = (lane & ~7) | j;
 					const double zj = __shfl(zb, srcj), tj = __shfl(tmf, srcj);
-					const double mrj = (j <= rr) ? sm.M[rr][j] : sm.M[j][rr];
+					const double mrj = (j <= rr) ? smA.M[rr][j] : smA.M[j][rr];
 					mz = fma(mrj, zj, mz);   // (M z)_rr
 					wq = fma(mi[j], tj, wq);  // (M^-1 tau_prec)_rr
 				}
@@ -1410,12 +1427,67 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				STAMP(28);
 				const double tvb = fma(mz * oct_rcp(zzb), fma(rhob, zfb, zab), tmf);
 				if (blend) {
-					tv = tvb;
+					tvo = tvb;
+					ovr = true;
 					singular = false;
 					blended_i = true;
 				}
 			}
 		}
+		if (DUO) {
+			// second workgroup barrier: B hands over the nullspace direction (z', v = M z up to scale, |z'|^2, z'.v) and exits
+			if (ROLE == 2) {
+				sm.vec[7][r] = zr;
+				sm.vec[8][r] = v_own;
+				sm.vec[1][r] = tvo;
+				sm.vec[2][r] = (ovr ? 1.0 : 0.0) + (singular ? 2.0 : 0.0) + (truncated ? 4.0 : 0.0) + (blended_i ? 8.0 : 0.0);
+				if (r == 0) {
+					sm.vec[3][0] = zz;
+					sm.vec[3][1] = zv;
+					UNR for (int j = 0; j < N; j++) sm.vec[4][j] = v[j];
+				}
+			}
+			STAMP(31);
+			__syncthreads();
+			if (ROLE == 2) return;
+			zr = smB.vec[7][r];
+			v_own = smB.vec[8][r];
+			zz = smB.vec[3][0];
+			zv = smB.vec[3][1];
+			{
+				tvo = smB.vec[1][r];
+				const int fl = (int)smB.vec[2][r];
+				ovr = (fl & 1) != 0;
+				singular = (fl & 2) != 0;
+				truncated = (fl & 4) != 0;
+				blended_i = (fl & 8) != 0;
+			}
+		}
+		if (ROLE == 1) {
+		const double ai = jg_ddq - wr;
+		const double za = oct_group_sum(zr * ai);
+		const double zf = oct_group_sum(zr * fi);
+		double rho = 1.0;
+		if (jt.decoupling == DEC_IMPEDANCE) {
+			rho = zz * oct_rcp(zv);
+		} else if (jt.decoupling == DEC_BIE) {
+			if (general_bie) {
+				if (DUO) {
+					UNR for (int j = 0; j < N; j++) v[j] = smB.vec[4][j];
+				}
+				double mbv = 0.0;
+				UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], v[j], mbv);  // (M_BIE^-1 v)_rr
+				const double qb = oct_group_sum(act ? v_own * mbv : 0.0);
+				rho = zv * oct_rcp(qb);
+			} else {
+				const double ze = oct_group_sum((act && r == eclamp) ? zr : 0.0);
+				rho = zv * oct_rcp(fma(-beta * ze, ze, zv));
+			}
+		}
+		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
+		}
+		if (ovr) tv = tvo;  // the blended strategies / the pass-through of a fully singular task decided this instance's torque
+
 	} else {
 	{
 		double g[6], t3[6], jc[6];
@@ -1763,6 +1835,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}
 	}  // GJ != 0
 	STAMP(14);
+#if defined(SAIP_OCT_EXP_FORCE_SCRATCH)  // diagnostic build only: does the mere use of scratch memory by a kernel cost launch time?
+	if (P.B < 0) {
+		volatile double spill[16];
+		spill[lane & 15] = tv;
+		tv += spill[(lane + 3) & 15];
+	}
+#endif
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	if (P.torque_sat) {
 		const double lim = md.effort[rr];
