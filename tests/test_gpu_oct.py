@@ -344,3 +344,48 @@ def test_oct_general_paths_with_every_controller_option(cfg):
         q = q + 1e-3 * rng.standard_normal(q.shape)
     print("oct general paths + options, cfg", cfg, "worst err", worst, "last statuses", np.unique(st, return_counts=True))
     assert worst < TOL
+
+
+@pytest.mark.parametrize("variant", ["default", "gravity_saturation", "full_decoupling", "impedance", "integrators_velsat", "several_clamped_entries"])
+@pytest.mark.parametrize("B", [768, 4099])
+def test_oct_options_on_blended_postures(variant, B):
+    """config 14's postures (a third type-1, a third type-2 singular: SingularityHandler's blended strategies) with every option of the
+    headline stack.  B = 768 runs the two-wavefront form, in which wavefront B evaluates the blended block from what wavefront A left
+    in LDS (beta, the clamped entry, columns of M^-1 and of M_BIE^-1) and hands torque and flags back; B = 4099 the one-wavefront form."""
+    from oracle import Oracle
+    d = W.make_inputs(14, B)
+    spec = W.config_tasks(14)
+    opts = {}
+    cycles = 2
+    if variant == "gravity_saturation":
+        opts = dict(gravity_comp=True, torque_saturation=True)
+    elif variant == "full_decoupling":
+        spec[0]["decoupling"] = W.FULL_DYNAMIC_DECOUPLING
+        spec[1]["decoupling"] = W.FULL_DYNAMIC_DECOUPLING
+    elif variant == "impedance":
+        spec[0]["decoupling"] = W.IMPEDANCE
+        spec[1]["decoupling"] = W.IMPEDANCE
+    elif variant == "integrators_velsat":
+        spec[0].update(ki_pos=5.0, ki_ori=7.0)
+        spec[1].update(ki=3.0, vel_sat=True, sat=0.4)
+        cycles = 4
+    elif variant == "several_clamped_entries":
+        spec[0]["bie_threshold"] = 0.5
+        spec[1]["bie_threshold"] = 0.5
+    orc = Oracle(d["model"], spec, **opts)
+    robot, ctrl, _ = _engine(d["model"].name, spec, B)
+    ctrl.setKernel(OCT)
+    ctrl.enableGravityCompensation(opts.get("gravity_comp", False))
+    ctrl.enableTorqueSaturation(opts.get("torque_saturation", False))
+    rng = np.random.default_rng(18)
+    q = d["q"].copy()
+    for c in range(cycles):
+        tau = _cycle(robot, ctrl, q, d["dq"], d["goals"])
+        assert ctrl.kernelName() == "saip_cycle_oct"
+        ref, st = orc.step(q, d["dq"], d["goals"], nthreads=8)
+        assert np.array_equal(ctrl.status, st), (variant, c, np.flatnonzero(ctrl.status != st)[:8])
+        assert (st == 8).sum() > B // 3 and (st == 1).sum() == 0
+        err = W.torque_error(tau, ref)
+        print("oct blended", variant, "B", B, "cycle", c, "err", err)
+        assert err < TOL
+        q = q + 1e-3 * rng.standard_normal(q.shape)
