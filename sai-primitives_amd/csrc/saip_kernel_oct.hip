@@ -98,53 +98,79 @@ __device__ void oct_serial_jacobi(double* A, double* V, const int n, const int l
 	}
 }
 
-// eigen-decomposition of a symmetric R x R matrix in registers: cyclic Jacobi, wave-uniform convergence test per sweep (rotations of
-// an already diagonal matrix degenerate to the identity); eigenvalues on the diagonal of A, eigenvectors in the columns of V
+// eigen-decomposition of a symmetric R x R matrix (R = 4, 6) held, identically, by all eight lanes of an instance: round-robin Jacobi.
+// The R/2 rotations of a round touch disjoint index pairs, so they are computed at the same time in different lanes (lane m of each
+// quad takes pair m; the reciprocal / rsqrt chains are most of a rotation's cost), broadcast inside the quad by DPP quad_perm and applied
+// by every lane to its copy of A; the eigenvector matrix is distributed (lane i < R keeps row i: 4 instead of 4 R operations per
+// rotation) and gathered at the end.  Wave-uniform convergence test per sweep.  Eigenvalues on the diagonal of A, eigenvectors in the
+// columns of V (all lanes alike).  (The row-cyclic form this replaces computed every rotation in every lane: 92 instructions per pair
+// against ~49 now; config 14: 37 k clocks of the blended block's 100 k.)
 template <int R>
-__device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R]) {
-	UNR for (int i = 0; i < R; i++)
-		UNR for (int j = 0; j < R; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+__device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R], const int lane) {
+	static_assert(R == 4 || R == 6, "even sizes with at most three pairs per round");
+	constexpr int NP = R / 2, RM = R - 1;
+	const int r = lane & 7, m = (lane & 3) < NP ? (lane & 3) : 0;
+	double vrow[R];
+	UNR for (int j = 0; j < R; j++) vrow[j] = (j == r) ? 1.0 : 0.0;
 	for (int sweep = 0; sweep < 12; sweep++) {
 		double off = 0.0, dg = 0.0;
 		UNR for (int p = 0; p < R; p++) {
 			dg = fma(A[p][p], A[p][p], dg);
 			UNR for (int q = p + 1; q < R; q++) off = fma(A[p][q], A[p][q], off);
 		}
-		if (!__any(off > 1e-32 * dg)) break;  // every instance of the wavefront has converged (quadratic convergence: 3 - 5 sweeps)
-		UNR for (int p = 0; p < R - 1; p++)
-			UNR for (int q = p + 1; q < R; q++) {
-				// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
-				// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
-				const double apq = A[p][q], d = A[q][q] - A[p][p], b2 = 2.0 * apq;
-				const double x = fma(d, d, b2 * b2);
-				const bool rot = x > 1e-300;
-				const double h = rot ? x * oct_rsqrt(x) : 1.0;
-				const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
-				const double t = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
-				const double c = oct_rsqrt(fma(t, t, 1.0)), sn = t * c;
+		if (!__any(off > 1e-32 * dg)) break;  // every instance of the wavefront has converged (quadratic convergence: 3 - 6 sweeps)
+		UNR for (int t = 0; t < RM; t++) {
+			// tournament round t: (t, R-1) and ((t + j) mod (R-1), (t - j) mod (R-1)), j = 1 .. R/2 - 1
+			double apq = 0.0, app = 0.0, aqq = 0.0;
+			UNR for (int j = 0; j < NP; j++) {
+				const int a_ = j == 0 ? t : (t + j) % RM, b_ = j == 0 ? RM : (t + RM - j) % RM;
+				const int p = a_ < b_ ? a_ : b_, q = a_ < b_ ? b_ : a_;
+				const bool mine = m == j;
+				apq = mine ? A[p][q] : apq;
+				app = mine ? A[p][p] : app;
+				aqq = mine ? A[q][q] : aqq;
+			}
+			// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
+			// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
+			const double d = aqq - app, b2 = 2.0 * apq;
+			const double x = fma(d, d, b2 * b2);
+			const bool rot = x > 1e-300;
+			const double h = rot ? x * oct_rsqrt(x) : 1.0;
+			const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
+			const double tn = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
+			const double cs = oct_rsqrt(fma(tn, tn, 1.0)), sn = tn * cs;
+			UNR for (int j = 0; j < NP; j++) {
+				const int a_ = j == 0 ? t : (t + j) % RM, b_ = j == 0 ? RM : (t + RM - j) % RM;
+				const int p = a_ < b_ ? a_ : b_, q = a_ < b_ ? b_ : a_;
+				double c, s_, tj;
+				if (j == 0) { c = oct_dpp<0x00>(cs); s_ = oct_dpp<0x00>(sn); tj = oct_dpp<0x00>(tn); }
+				else if (j == 1) { c = oct_dpp<0x55>(cs); s_ = oct_dpp<0x55>(sn); tj = oct_dpp<0x55>(tn); }
+				else { c = oct_dpp<0xAA>(cs); s_ = oct_dpp<0xAA>(sn); tj = oct_dpp<0xAA>(tn); }
+				const double apq_j = A[p][q];
 				UNR for (int k = 0; k < R; k++) {
 					if (k != p && k != q) {
 						const double akp = A[k][p], akq = A[k][q];
-						const double np_ = c * akp - sn * akq, nq_ = sn * akp + c * akq;
+						const double np_ = c * akp - s_ * akq, nq_ = s_ * akp + c * akq;
 						A[k][p] = np_;
 						A[p][k] = np_;
 						A[k][q] = nq_;
 						A[q][k] = nq_;
 					}
 				}
-				A[p][p] = fma(-t, apq, A[p][p]);
-				A[q][q] = fma(t, apq, A[q][q]);
+				A[p][p] = fma(-tj, apq_j, A[p][p]);
+				A[q][q] = fma(tj, apq_j, A[q][q]);
 				A[p][q] = 0.0;
 				A[q][p] = 0.0;
-				UNR for (int k = 0; k < R; k++) {
-					const double vkp = V[k][p], vkq = V[k][q];
-					V[k][p] = c * vkp - sn * vkq;
-					V[k][q] = sn * vkp + c * vkq;
-				}
+				const double vp = vrow[p], vq = vrow[q];
+				vrow[p] = c * vp - s_ * vq;
+				vrow[q] = s_ * vp + c * vq;
 			}
+		}
 	}
+	UNR for (int i = 0; i < R; i++)
+		UNR for (int c = 0; c < R; c++) V[i][c] = __shfl(vrow[c], (lane & ~7) | i);
 }
-__device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4]) { oct_jacobi_n<4>(A, V); }
+__device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4], const int lane) { oct_jacobi_n<4>(A, V, lane); }
 // inverse of an SPD R x R matrix given by its lower triangle
 template <int R>
 __device__ __forceinline__ void oct_spd_inverse_n(const double (&A)[R][R], double (&Ainv)[R][R]) {
@@ -619,7 +645,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		double E[6][6], Ue[6][6];
 		UNR for (int i = 0; i < 6; i++)
 			UNR for (int j = 0; j < 6; j++) E[i][j] = G[i][j];
-		oct_jacobi_n<6>(E, Ue);
+		oct_jacobi_n<6>(E, Ue, lane);
 		double lmax = 0.0;
 		UNR for (int c = 0; c < 6; c++) lmax = fmax(lmax, E[c][c]);
 		const double s0 = sqrt(lmax);
@@ -1063,7 +1089,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 						E[c][a] = sacc;
 						if (a == c) trg += sacc;
 					}
-				oct_jacobi_n<6>(E, Ue);
+				oct_jacobi_n<6>(E, Ue, lane);
 			}
 			STAMP(17);
 			double tu[6];  // J_u m: the rank-one bounded-inertia form needs it (rows of J_u = U^T J are used on the fly, not kept: 84 registers)
@@ -1566,7 +1592,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}
 		if (__any(!full_rank)) {
 			double Ve[4][4];
-			oct_jacobi4(Gp, Ve);
+			oct_jacobi4(Gp, Ve, lane);
 			double lmaxp = 0.0;
 			UNR for (int c = 0; c < 4; c++) lmaxp = fmax(lmaxp, Gp[c][c]);
 			const bool any_range = (sqrt(fmax(trp, 0.0)) >= 1e-3) && (sqrt(lmaxp) >= 1e-3);
