@@ -251,7 +251,7 @@ template <bool FULL, int GJ, int ROLE>
 __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
-	static_assert(!DUO || (!FULL && GJ == 0), "two wavefronts per instance group: lean headline stack only");
+	static_assert(!DUO || GJ != 2, "two wavefronts per instance group: not for the reduced (truncated) motion-force task, whose predicate rewrites the Jacobian");
 	constexpr int N = 7;
 	const int lane = threadIdx.x & 63;
 	const int r = lane & 7, grp = lane >> 3;
@@ -279,7 +279,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		gl1 = mf.goal[(size_t)(8 + r) * ld + b];
 		gl2 = mf.goal[(size_t)(16 + r) * ld + b];
 	}
-	const double gl3 = (FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
+	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
 	const int mj = GJ == 1 ? jt.m : N;                 // rows of the joint task (Gram path: <= 4)
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
@@ -867,39 +867,52 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 			UNR for (int a = 0; a < 6; a++) Fum[a] = fh[a];
 		}
-		if (GJ == 0) {
-			UNR for (int a = 0; a < 6; a++) Fum6[a] = Fum[a];
-		} else {
-			// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
-			double s = Ffa;
-			UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum[c], s);
-			sm.vec[2][r] = s;
-		}
+		UNR for (int a = 0; a < 6; a++) Fum6[a] = Fum[a];
 	}
-	if (GJ != 0) oct_sync<DUO>();
 	if (DUO) {
-		// first workgroup barrier: B publishes the branch predicate and the task force; A has left A = J M^-1 J^T, T1 and M^-1 in its block
+		// first workgroup barrier: B publishes the task force (and, for the stacks whose tail it does not share, the branch predicate); A has
+		// left A = J M^-1 J^T, T1 and M^-1 in its block
 		if (ROLE == 2) {
 			if (r < 6) {
-				double fo = 0.0;
-				UNR for (int a = 0; a < 6; a++) fo = (a == r) ? Fum6[a] : fo;
+				double fo = 0.0, ffo = 0.0;
+				UNR for (int a = 0; a < 6; a++) {
+					fo = (a == r) ? Fum6[a] : fo;
+					ffo = (a == r) ? Ff6[a] : ffo;
+				}
 				sm.vec[6][r] = fo;
+				sm.vec[5][r] = ffo;
 			}
+			if (r == 6) sm.vec[6][6] = singular ? 1.0 : 0.0;
 		}
 		STAMP(29);
 		__syncthreads();
 		STAMP(30);
+		if (ROLE == 2 && GJ != 0) return;
 		if (ROLE == 1) {
-			UNR for (int a = 0; a < 6; a++) Fum6[a] = smB.vec[6][a];
+			UNR for (int a = 0; a < 6; a++) {
+				Fum6[a] = smB.vec[6][a];
+				Ff6[a] = smB.vec[5][a];
+			}
+			if (GJ != 0) singular = smB.vec[6][6] != 0.0;  // (headline stack: the final flags arrive at the second barrier)
 		}
-		// both factor A (B cannot wait for A's factor: the tail is split between them from here)
-		UNR for (int i = 0; i < 6; i++)
-			UNR for (int j = 0; j <= i; j++) L6[i][j] = smA.A[i][j];
-		oct_cholesky<6>(L6, dinv6);
-		if (ROLE == 2) {
-			UNR for (int a = 0; a < 6; a++) t1c[a] = smA.T1[a][r];
-			UNR for (int j = 0; j < N; j++) mi[j] = smA.N1[r][j];
+		if (GJ == 0) {
+			// both factor A (B cannot wait for A's factor: the tail is split between them from here)
+			UNR for (int i = 0; i < 6; i++)
+				UNR for (int j = 0; j <= i; j++) L6[i][j] = smA.A[i][j];
+			oct_cholesky<6>(L6, dinv6);
+			if (ROLE == 2) {
+				UNR for (int a = 0; a < 6; a++) t1c[a] = smA.T1[a][r];
+				UNR for (int j = 0; j < N; j++) mi[j] = smA.N1[r][j];
+			}
 		}
+	}
+	if (GJ != 0) {
+		// g_a = (Lambda_mod F_um)_a + (F_f)_a  (SingularityHandler.cpp:307-309); Bm = I for the full task
+		double s = 0.0;
+		UNR for (int a = 0; a < 6; a++) s = (a == ra) ? Ff6[a] : s;
+		UNR for (int c = 0; c < 6; c++) s = fma(lmod[c], Fum6[c], s);
+		sm.vec[2][r] = s;
+		oct_sync<DUO>();
 	}
 	STAMP(10);
 	// ---- tau_r = (J^T g)_r;  N_1 = I - M^-1 J^T Lambda J = I - T1^T Lambda J: this lane forms COLUMN rr (what the joint task's range
@@ -1519,7 +1532,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		double g[6], t3[6], jc[6];
 		UNR for (int a = 0; a < 6; a++) {
 			g[a] = sm.vec[2][a];
-			jc[a] = sm.J[a][rr];
+			jc[a] = (ROLE == 1 ? smB : sm).J[a][rr];
 		}
 		double s = 0.0;
 		UNR for (int a = 0; a < 6; a++) s = fma(jc[a], g[a], s);
@@ -1976,11 +1989,18 @@ static bool oct_duo_enabled(const int workgroups) {
 
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
-	if (P.oct_general_joint == 1) hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
-	else if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
-	else if (P.jla || P.lane_general || P.oct_partial_mf) hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
-	else if (oct_duo_enabled((int)grid.x)) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
-	else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
+	const bool duo = oct_duo_enabled((int)grid.x);
+	if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
+	else if (P.oct_general_joint == 1) {
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
+	} else if (P.jla || P.lane_general || P.oct_partial_mf) {
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
+	} else {
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
+	}
 	return hipGetLastError();
 }
 
