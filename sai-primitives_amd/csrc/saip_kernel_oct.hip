@@ -5,14 +5,18 @@
 // an instance are spread over eight lanes (lane r owns joint r / row r; lane 7 is padding), operands the other lanes need travel
 // by DPP (scans along the chain, reductions) or through a small LDS block per instance, and the inherently serial factorisations
 // are done redundantly (a Cholesky factor per lane, then each lane solves for its own column of the inverse).  4096 instances
-// become 512 wavefronts of 2 500 instructions each.  One wavefront per workgroup: __syncthreads() is a wave-local ordering point.
+// become 512 wavefronts of 2 500 instructions each -- and, while the launch fits the chip in one round, 1024: a second wavefront per
+// group of eight instances (oct_cycle_body<..., ROLE>) runs what does not need the mass matrix next to the inertia
+// chain.  Synchronisation inside a wavefront is a wavefront-scope fence (oct_sync); the two wavefronts of a group meet at two or three
+// workgroup barriers.
 //
 // Covers { MotionForceTask, JointTask } stacks on a 7-dof chain (engine: oct_eligible): the headline stack of BASELINE config 2 (full
 // 6-dof task + full joint task; <false, 0> is its lean instantiation), partial motion-force tasks with a joint task of <= 4 rows
 // (config 3, GJ = 1) or a full joint task (GJ = 2), default or general control laws (no closed-loop force control), joint limit
-// avoidance, gravity compensation, torque saturation, and disableSingularityHandling() (near-singular instances reduced in the
-// kernel).  Instances outside the non-singular branch are otherwise flagged and, with the blended strategies on, recomputed by the
-// general kernel launched behind.
+// avoidance, gravity compensation, torque saturation, disableSingularityHandling() (near-singular instances reduced in the kernel)
+// and, for the headline stack, SingularityHandler's blended type-1 / type-2 strategies with their per-instance state.  Instances
+// outside the non-singular branch of the other stacks are flagged and, with the blended strategies on, recomputed by the general
+// kernel launched behind over the flag list.
 //   SaiModel::updateModel()                       -> prefix-product kinematics, composite inertias, M, M^-1, M_BIE^-1
 //   RobotController::updateControllerTaskModels() -> /root/reference/src/RobotController.cpp:68-77, tasks/MotionForceTask.cpp:247-268,
 //       tasks/SingularityHandler.cpp:75-228 (non-singular branch; others flagged -> slow path), tasks/JointTask.cpp:218-283
@@ -798,14 +802,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
 			}
 		}
-		double Ffa = 0.0;
 		if (FULL && mf.general_law) {
 			// velocity saturation and / or force & moment spaces (open-loop force control): the shared general law, MotionForceTask.cpp:306-487
 			double G30[30], Ff[6] = {0, 0, 0, 0, 0, 0};
 			UNR for (int e = 0; e < 24; e++) G30[e] = G24[e];
 			UNR for (int e = 0; e < 6; e++) G30[24 + e] = sm.vec[5][e];
 			law_motion_force_general<false>(&mf, vw, pw, Rc, G30, ip, io, (double*)nullptr, Fum, Ff);
-			UNR for (int a = 0; a < 6; a++) Ffa = (a == ra) ? Ff[a] : Ffa;
 			UNR for (int a = 0; a < 6; a++) Ff6[a] = Ff[a];
 		} else if (FULL && !mf.bm_identity) {
 			// partial task: the short law with its projections (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0), then
