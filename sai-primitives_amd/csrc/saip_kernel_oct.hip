@@ -255,7 +255,6 @@ template <bool FULL, int GJ, int ROLE>
 __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
-	static_assert(!DUO || GJ != 2, "two wavefronts per instance group: not for the reduced (truncated) motion-force task, whose predicate rewrites the Jacobian");
 	constexpr int N = 7;
 	const int lane = threadIdx.x & 63;
 	const int r = lane & 7, grp = lane >> 3;
@@ -522,7 +521,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #else
 	const bool strategies_on = GJ == 0 && mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform; the blended branch lives in the headline stack's tail
 #endif
-	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;  // disableSingularityHandling(): reduce the task instead of flagging
+	// disableSingularityHandling(): reduce the task instead of flagging.  (Never in the two-wavefront form: the reduction rewrites the
+	// Jacobian the inertia chain is waiting for; the launcher keeps such batches on the one-wavefront form.)
+	const bool trunc_mode = FULL && GJ == 2 && !DUO && P.oct_truncate;
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
 	if (roleB) {
@@ -1992,8 +1993,10 @@ static bool oct_duo_enabled(const int workgroups) {
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
 	const bool duo = oct_duo_enabled((int)grid.x);
-	if (P.oct_general_joint == 2) hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
-	else if (P.oct_general_joint == 1) {
+	if (P.oct_general_joint == 2) {
+		if (duo && !P.oct_truncate) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
+	} else if (P.oct_general_joint == 1) {
 		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
 	} else if (P.jla || P.lane_general || P.oct_partial_mf) {
