@@ -65,6 +65,8 @@ struct WgSmem {
 	int colidx[NMAX];
 	int flag, rank;
 	int flag2;  // passivity-observer window overflow (status bit 2)
+	double bieK[64];  // bie_inverse_lowrank: the c x c Woodbury matrix and the clamped indices (+ their count)
+	int bieIdx[9];
 };
 
 // one control cycle (or one task's model / torque half, CycleParams::single_task) of instance b by the calling workgroup
@@ -224,14 +226,16 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	spd_inverse<T>(Mm, sm.Minv, sm.W[2], sm.W[3], sm.dv, n, LD, tid);
 	double cur_bie_thr = -1.0;
 	if (any_bie) {
-		for (int e = tid; e < n * n; e += T) {
-			int i = e / n, j = e - i * n;
-			double v = Mm[i * LD + j];
-			if (i == j && v < bie_thr) v = bie_thr;
-			MB[i * LD + j] = v;
+		if (!bie_inverse_lowrank<T>(Mm, sm.Minv, sm.MBinv, sm.bieK, sm.bieIdx, sm.W[2], bie_thr, n, LD, tid)) {
+			for (int e = tid; e < n * n; e += T) {
+				int i = e / n, j = e - i * n;
+				double v = Mm[i * LD + j];
+				if (i == j && v < bie_thr) v = bie_thr;
+				MB[i * LD + j] = v;
+			}
+			SYNC();
+			spd_inverse<T>(MB, sm.MBinv, sm.W[2], sm.W[3], sm.dv, n, LD, tid);
 		}
-		SYNC();
-		spd_inverse<T>(MB, sm.MBinv, sm.W[2], sm.W[3], sm.dv, n, LD, tid);
 		cur_bie_thr = bie_thr;
 	}
 	// keep M for per-task BIE thresholds that differ from cur_bie_thr: W[8] is reserved for it
@@ -641,14 +645,16 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 				SYNC();
 			} else {
 				if (tk.bie_threshold != cur_bie_thr) {  // another threshold than the cached one: rebuild M_BIE^-1
-					for (int e = tid; e < n * n; e += T) {
-						int i = e / n, j = e - i * n;
-						double v = Mkeep[i * LD + j];
-						if (i == j && v < tk.bie_threshold) v = tk.bie_threshold;
-						sm.W[1][i * LD + j] = v;
+					if (!bie_inverse_lowrank<T>(Mkeep, sm.Minv, sm.MBinv, sm.bieK, sm.bieIdx, sm.W[0], tk.bie_threshold, n, LD, tid)) {
+						for (int e = tid; e < n * n; e += T) {
+							int i = e / n, j = e - i * n;
+							double v = Mkeep[i * LD + j];
+							if (i == j && v < tk.bie_threshold) v = tk.bie_threshold;
+							sm.W[1][i * LD + j] = v;
+						}
+						SYNC();
+						spd_inverse<T>(sm.W[1], sm.MBinv, sm.W[0], sm.W[5], sm.dv, n, LD, tid);
 					}
-					SYNC();
-					spd_inverse<T>(sm.W[1], sm.MBinv, sm.W[0], sm.W[5], sm.dv, n, LD, tid);
 					cur_bie_thr = tk.bie_threshold;
 				}
 				gemm<T>(sm.W[0], LD, J, LD, 1, sm.MBinv, LD, 1, rows, n, n, tid);

@@ -94,6 +94,64 @@ __device__ void spd_inverse(const double* Ain, double* Aout, double* WL, double*
 	}
 }
 
+// M_BIE^-1 from M^-1 when only a few diagonal entries of M are clamped (SingularityHandler.cpp:176-182: M_BIE = M + sum_e c_e e e^T,
+// c_e = thr - M_ee > 0): Woodbury, M_BIE^-1 = M^-1 - Y K^-1 Y^T with Y = the clamped columns of M^-1 and K = C^-1 + Y[idx, :] (c x c, SPD).
+// One thread inverts K (c <= 8); everything else is two small passes over the matrix -- five barriers instead of the n pivots of a
+// second full inverse (30-dof chain: 3 clamped entries, 37 k clocks -> 3 k).  Returns false (nothing written) when more than 8 entries
+// are clamped: the caller then inverts M_BIE in full.  K: >= 64 doubles, idx: >= 9 ints, Z: n x 8 work (ld), all in LDS.
+template <int T>
+__device__ bool bie_inverse_lowrank(const double* Mm, const double* Minv, double* MBinv, double* K, int* idx, double* Z, const double thr,
+									 int n, int ld, int tid) {
+	if (tid == 0) {
+		int c = 0;
+		for (int i = 0; i < n; i++)
+			if (Mm[i * ld + i] < thr) {
+				if (c < 8) idx[c] = i;
+				c++;
+			}
+		idx[8] = c;
+	}
+	SYNC();
+	const int c = idx[8];
+	if (c > 8) return false;
+	if (c > 0) {
+		if (tid < c * c) {
+			const int a = tid / c, b2 = tid - a * c;
+			const int ia = idx[a], ib = idx[b2];
+			K[a * 8 + b2] = Minv[ia * ld + ib] + ((a == b2) ? 1.0 / (thr - Mm[ia * ld + ia]) : 0.0);
+		}
+		SYNC();
+		if (tid == 0) {  // in-place Gauss-Jordan inverse of the SPD c x c matrix (no pivoting needed)
+			for (int k = 0; k < c; k++) {
+				const double rd = 1.0 / K[k * 8 + k];
+				for (int j = 0; j < c; j++) K[k * 8 + j] = (j == k) ? rd : K[k * 8 + j] * rd;
+				for (int i = 0; i < c; i++) {
+					if (i == k) continue;
+					const double f = K[i * 8 + k];
+					for (int j = 0; j < c; j++) K[i * 8 + j] = (j == k) ? -f * rd : fma(-f, K[k * 8 + j], K[i * 8 + j]);
+				}
+			}
+		}
+		SYNC();
+		for (int e = tid; e < n * c; e += T) {  // Z = Y K^-1
+			const int i = e / c, a = e - i * c;
+			double sacc = 0.0;
+			for (int b2 = 0; b2 < c; b2++) sacc = fma(Minv[i * ld + idx[b2]], 0.5 * (K[b2 * 8 + a] + K[a * 8 + b2]), sacc);
+			Z[i * ld + a] = sacc;
+		}
+		SYNC();
+	}
+	for (int e = tid; e < n * n; e += T) {
+		const int i = e / n, j = e - i * n;
+		const int lo = i < j ? i : j, hi = i < j ? j : i;  // the same expression for (i, j) and (j, i): bitwise symmetric like the sweep inverse
+		double v = Minv[lo * ld + hi];
+		for (int a = 0; a < c; a++) v = fma(-Z[lo * ld + a], Minv[hi * ld + idx[a]], v);
+		MBinv[i * ld + j] = v;
+	}
+	SYNC();
+	return true;
+}
+
 // Symmetric eigen-decomposition by parallel-ordered (round-robin) Jacobi: A -> diag (eigenvalues), V (optional) <- eigenvectors.
 // cs: 4*(NMAX/2+1) doubles scratch, flag: one int in LDS.  3 barriers per round, n-1 (n even) or n rounds per sweep.
 template <int T>
