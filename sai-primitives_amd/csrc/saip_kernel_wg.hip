@@ -31,17 +31,33 @@
 #include "saip_fk.h"
 
 #if defined(SAIP_STAMP_WG)
-// diagnostic build only (never shipped): s_memtime stamp of block 0 / thread 0 after every barrier of the kernel body
-__device__ unsigned long long saip_stamps_wg[512];
+// diagnostic build only (never shipped): s_memtime log of block 0 / thread 0 after every barrier of the kernel body (time, source line)
+__device__ unsigned long long saip_stamps_wg[4096];
+__device__ int saip_stamps_wg_pos;
 #undef SYNC
 #define SYNC()                                                                 \
 	do {                                                                       \
 		__syncthreads();                                                       \
 		if (blockIdx.x == 0 && threadIdx.x == 0) {                             \
-			saip_stamps_wg[2 * __COUNTER__] = __builtin_amdgcn_s_memtime();    \
-			saip_stamps_wg[2 * (__COUNTER__ - 1) + 1] = __LINE__;              \
+			const int p_ = saip_stamps_wg_pos++;                               \
+			if (p_ < 2047) {                                                   \
+				saip_stamps_wg[2 * p_] = __builtin_amdgcn_s_memtime();         \
+				saip_stamps_wg[2 * p_ + 1] = __LINE__;                         \
+			}                                                                  \
 		}                                                                      \
 	} while (0)
+#define MARK()                                                                 \
+	do {                                                                       \
+		if (blockIdx.x == 0 && threadIdx.x == 0) {                             \
+			const int p_ = saip_stamps_wg_pos++;                               \
+			if (p_ < 2047) {                                                   \
+				saip_stamps_wg[2 * p_] = __builtin_amdgcn_s_memtime();         \
+				saip_stamps_wg[2 * p_ + 1] = 100000 + __LINE__;                \
+			}                                                                  \
+		}                                                                      \
+	} while (0)
+#else
+#define MARK()
 #endif
 
 namespace saip {
@@ -279,9 +295,11 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	bool singular = false;
 	bool truncated = false;  // some motion-force task was reduced to its non-singular subspace (singularity handling disabled)
 	bool blended = false;    // some motion-force task ran the blended type-1 / type-2 singularity strategies
+	MARK();
 	// ---------------------------------------------------------------- task hierarchy
 	for (int t = t_first; t < t_last; t++) {
 		const TaskDev& tk = P.tasks[t];
+		MARK();
 		double* Jh = sm.W[4];
 		int r = 0;           // rank of the task in its range basis
 		bool empty = false;  // JointTask with no controllable dof left
@@ -292,6 +310,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 		const bool strategies = tk.type == TASK_MOTION_FORCE && tk.sing_handling && tk.sing_strategies && tk.sh;
 		const int gs = tk.goal_comps;
 		for (int e = tid; e < gs; e += T) sm.goal[e] = tk.goal[(size_t)e * P.ld + b];
+		MARK();
 
 		if (tk.type == TASK_MOTION_FORCE) {
 			const int k = tk.k, bd = tk.body;
@@ -1283,8 +1302,13 @@ hipError_t launch_reinit(const CycleParams& P, hipStream_t stream) {
 }
 
 #if defined(SAIP_STAMP_WG)
+// returns the number of log entries of the last launch and rewinds the log
 extern "C" int saip_debug_stamps_wg(unsigned long long* out, int n) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_wg), sizeof(unsigned long long) * (n < 512 ? n : 512));
+	int pos = 0, zero = 0;
+	if (hipMemcpyFromSymbol(&pos, HIP_SYMBOL(saip_stamps_wg_pos), sizeof(int)) != hipSuccess) return -1;
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_wg), sizeof(unsigned long long) * (n < 4096 ? n : 4096)) != hipSuccess) return -1;
+	if (hipMemcpyToSymbol(HIP_SYMBOL(saip_stamps_wg_pos), &zero, sizeof(int)) != hipSuccess) return -1;
+	return pos < 2047 ? pos : 2047;
 }
 #endif
 }  // namespace saip

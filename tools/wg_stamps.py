@@ -1,6 +1,7 @@
-"""diagnostic: where one workgroup of the general kernel spends its clocks (build saip_kernel_wg.hip with -DSAIP_STAMP_WG into another
-library, run with SAIP_LIB): s_memtime after every barrier of block 0, printed as clocks per source-line interval.
-   SAIP_LIB=... python tools/wg_stamps.py [config] [batch]"""
+"""diagnostic: where one workgroup of the general kernel spends its clocks (build the variant with
+SAIP_VARIANT_KERNEL=wg tools/oct_variant.sh wgstamp -DSAIP_STAMP_WG): s_memtime after every barrier of block 0, as a running log, so task
+iterations are told apart.  Barriers inside saip_wg_linalg.h routines are not stamped: their time lands on the next kernel-file line.
+   SAIP_LIB=sai-primitives_amd/libsaip_var_wgstamp.so python tools/wg_stamps.py [config] [batch]"""
 import ctypes as C, sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -13,23 +14,21 @@ d = W.make_inputs(cfg, B)
 robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
 ctrl.setKernel(1)
 robot.setQ(d["q"]); robot.setDq(d["dq"]); robot.updateModel(); ctrl.setGoals(d["goals"])
-for rep in range(3):
-    ctrl.updateControllerTaskModels(); ctrl.computeControlTorques()
-buf = (C.c_ulonglong * 512)()
 L = capi.lib()
 L.saip_debug_stamps_wg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-L.saip_debug_stamps_wg(buf, 512)
-a = np.array(buf[:], dtype=np.uint64).reshape(256, 2)
-a = a[a[:, 0] > 0]
-a = a[np.argsort(a[:, 0])]
-t0 = a[0, 0]
-prev_t, prev_l = t0, int(a[0, 1])
-acc = {}
-for t, l in a[1:]:
-    key = (prev_l, int(l))
-    acc[key] = acc.get(key, 0) + int(t - prev_t)
-    prev_t, prev_l = t, int(l)
-tot = int(a[-1, 0] - t0)
-for (l0, l1), c in sorted(acc.items(), key=lambda kv: -kv[1])[:40]:
-    print(f"lines {l0:5d} -> {l1:5d}: {c:9d} clk  {100.0 * c / tot:5.1f} %")
-print("total", tot, "clk; static stamp sites hit:", len(a))
+buf = (C.c_ulonglong * 4096)()
+for rep in range(3):
+    ctrl.stepAsync(); ctrl.synchronize()
+    n = L.saip_debug_stamps_wg(buf, 4096)
+a = np.array(buf[:2 * n], dtype=np.uint64).reshape(n, 2)
+t = a[:, 0].astype(np.float64); ln = a[:, 1].astype(int)
+tot = t[-1] - t[0]
+print(f"{n} barriers of the kernel file, {tot:.0f} clocks")
+acc = 0.0
+for i in range(1, n):
+    dt = t[i] - t[i - 1]
+    if dt >= 0.004 * tot:
+        print(f"  t = {t[i - 1] - t[0]:8.0f}  lines {ln[i - 1]:5d} -> {ln[i]:5d}: {dt:8.0f} clk  {100.0 * dt / tot:5.1f} %")
+    else:
+        acc += dt
+print(f"  (intervals below 0.4 % each: {acc:.0f} clk, {100.0 * acc / tot:.1f} %)")
