@@ -93,6 +93,10 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	const int tid = threadIdx.x;
 	const int n = P.n;
 	const ModelDev& md = *P.model;
+	// e / n for the element loops (0 <= e < 2048, n <= 32) without the ~40-instruction integer division of the hardware-less path:
+	// multiply by ceil(2^18 / n) and shift (exact while e (n ceil(2^18 / n) - 2^18) < 2^18, i.e. for e < 4096)
+	const unsigned divn_m = ((1u << 18) + (unsigned)n - 1u) / (unsigned)n;
+	auto divn = [divn_m](const int e) { return (int)(((unsigned)e * divn_m) >> 18); };
 
 	// ---------------------------------------------------------------- state
 	if (tid == 0) sm.flag2 = 0;
@@ -198,7 +202,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	double* Mm = sm.W[0];
 	double* MB = sm.W[1];
 	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
+		int i = divn(e), j = e - i * n;
 		if (i > j) continue;
 		const double* Ic = sm.comp + 10 * j;
 		const double* zj = sm.zax + 3 * j;
@@ -244,7 +248,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	if (any_bie) {
 		if (!bie_inverse_lowrank<T>(Mm, sm.Minv, sm.MBinv, sm.bieK, sm.bieIdx, sm.W[2], bie_thr, n, LD, tid)) {
 			for (int e = tid; e < n * n; e += T) {
-				int i = e / n, j = e - i * n;
+				int i = divn(e), j = e - i * n;
 				double v = Mm[i * LD + j];
 				if (i == j && v < bie_thr) v = bie_thr;
 				MB[i * LD + j] = v;
@@ -257,14 +261,14 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	// keep M for per-task BIE thresholds that differ from cur_bie_thr: W[8] is reserved for it
 	double* Mkeep = sm.W[8];
 	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
+		int i = divn(e), j = e - i * n;
 		Mkeep[i * LD + j] = Mm[i * LD + j];
 	}
 	// N_prec = I
 	double* Np = sm.NpA;
 	double* Np2 = sm.NpB;
 	for (int e = tid; e < n * n; e += T) {
-		int i = e / n, j = e - i * n;
+		int i = divn(e), j = e - i * n;
 		Np[i * LD + j] = P.ext_nprec ? P.ext_nprec[(size_t)e * P.ld + b] : ((i == j) ? 1.0 : 0.0);  // updateTaskModel(N_prec), TemplateTask.h:43
 	}
 	SYNC();
@@ -275,7 +279,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 	const bool do_state = P.phase != 2 && !P.diag;  // computeTorques does not classify (SingularityHandler::classifySingularity runs in updateTaskModel, .cpp:227)
 	auto dump_nullspaces = [&](const double* Ntask, const double* Ntotal) {  // [n*n][ld] row-major per instance
 		for (int e = tid; e < n * n; e += T) {
-			int i = e / n, j = e - i * n;
+			int i = divn(e), j = e - i * n;
 			if (P.out_N) P.out_N[(size_t)e * P.ld + b] = Ntask ? Ntask[i * LD + j] : ((i == j) ? 1.0 : 0.0);
 			if (P.out_Ntot) P.out_Ntot[(size_t)e * P.ld + b] = Ntotal[i * LD + j];
 		}
@@ -483,7 +487,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 								gemm<T>(sm.W[0], LD, sm.W[3], 1, LD, Jh, LD, 1, r, k, n, tid);  // J_ns = U_ns^T Jh
 								SYNC();
 								for (int e = tid; e < r * n; e += T) {
-									int i = e / n, j = e - i * n;
+									int i = divn(e), j = e - i * n;
 									Jh[i * LD + j] = sm.W[0][i * LD + j];
 								}
 							}
@@ -619,7 +623,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			if (!empty) {
 				if (u_identity) {
 					for (int e = tid; e < m * n; e += T) {
-						int i = e / n, j = e - i * n;
+						int i = divn(e), j = e - i * n;
 						Jh[i * LD + j] = Jp[i * LD + j];
 					}
 				} else {
@@ -666,7 +670,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 				if (tk.bie_threshold != cur_bie_thr) {  // another threshold than the cached one: rebuild M_BIE^-1
 					if (!bie_inverse_lowrank<T>(Mkeep, sm.Minv, sm.MBinv, sm.bieK, sm.bieIdx, sm.W[0], tk.bie_threshold, n, LD, tid)) {
 						for (int e = tid; e < n * n; e += T) {
-							int i = e / n, j = e - i * n;
+							int i = divn(e), j = e - i * n;
 							double v = Mkeep[i * LD + j];
 							if (i == j && v < tk.bie_threshold) v = tk.bie_threshold;
 							sm.W[1][i * LD + j] = v;
@@ -749,7 +753,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			gemm<T>(sm.W[0], LD, sm.W[3], 1, LD, Jh, LD, 1, k, k, n, tid);  // rows 0..ns-1: J_ns = U_ns^T Jh, rows ns..k-1: J_s = U_s^T Jh
 			SYNC();
 			for (int e = tid; e < k * n; e += T) {
-				int i = e / n, j = e - i * n;
+				int i = divn(e), j = e - i * n;
 				Jh[i * LD + j] = sm.W[0][i * LD + j];
 			}
 			SYNC();
@@ -806,7 +810,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			const bool want_task_N = P.out_N || (P.diag && tk.diag_N);
 			if (want_task_N)
 				for (int e = tid; e < n * n; e += T) {
-					int i = e / n, j = e - i * n;
+					int i = divn(e), j = e - i * n;
 					sm.Nx[i * LD + j] = Nt[i * LD + j];  // N_ns, for getTaskNullspace = N_js N_ns
 				}
 			gemm<T>(Np2, LD, Nt, LD, 1, Np, LD, 1, n, n, n, tid);  // X = N_ns N_prec
@@ -830,7 +834,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			// classifySingularity (:230-295): task-space motion along u_c of the control frame at q +- 5 v_c
 			double* qp = sm.W[5];  // [2 nsg][n] perturbed postures (W[5] and W[6] are contiguous)
 			for (int e = tid; e < 2 * nsg * n; e += T) {
-				int pidx = e / n, j = e - pidx * n, c = pidx >> 1;
+				int pidx = divn(e), j = e - pidx * n, c = pidx >> 1;
 				qp[e] = sm.q[j] + ((pidx & 1) ? -5.0 : 5.0) * (Jh[(ns + c) * LD + j] / sm.dv[ns + c]);
 			}
 			if (tid < n) {  // :232-235 with the counters of the previous cycle
@@ -925,7 +929,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			gemm<T>(sm.W[0], LD, Jh + ns * LD, LD, 1, Np2, LD, 1, nsg, n, n, tid);
 			SYNC();
 			for (int e = tid; e < nsg * n; e += T) {
-				int c = e / n, j = e - c * n;
+				int c = divn(e), j = e - c * n;
 				Jh[c * LD + j] = sm.W[0][c * LD + j] / sm.dv[ns + c];
 			}
 			SYNC();
@@ -951,7 +955,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 				SYNC();
 				if (P.diag && tk.diag_N)
 					for (int e = tid; e < n * n; e += T) {
-						int i = e / n, j = e - i * n;
+						int i = divn(e), j = e - i * n;
 						tk.diag_N[(size_t)e * P.ld + b] = Np2[i * LD + j];
 					}
 			}
@@ -963,7 +967,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			osm(Jh, r, need_N);
 			if (P.diag && tk.diag_N) {
 				for (int e = tid; e < n * n; e += T) {
-					int i = e / n, j = e - i * n;
+					int i = divn(e), j = e - i * n;
 					tk.diag_N[(size_t)e * P.ld + b] = Nt[i * LD + j];
 				}
 			}
@@ -1083,7 +1087,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			SYNC();
 			if (P.diag && tk.diag_N)
 				for (int e = tid; e < n * n; e += T) {
-					int i = e / n, j = e - i * n;
+					int i = divn(e), j = e - i * n;
 					tk.diag_N[(size_t)e * P.ld + b] = Np[i * LD + j];
 				}
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(Np, Np2);
@@ -1094,7 +1098,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 			// no controllable direction left: N = I (JointTask.cpp:234-239), a fully singular reduced motion-force task is passed through
 			if (P.diag && tk.diag_N)
 				for (int e = tid; e < n * n; e += T) {
-					int i = e / n, j = e - i * n;
+					int i = divn(e), j = e - i * n;
 					tk.diag_N[(size_t)e * P.ld + b] = (i == j) ? 1.0 : 0.0;
 				}
 			if (P.single_task >= 0 && (P.out_N || P.out_Ntot)) dump_nullspaces(nullptr, Np);
@@ -1145,7 +1149,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 				sm.v2[i] = (sm.v1[i] != 0.0) ? sacc : 0.0;
 			}
 			for (int e = tid; e < n * n; e += T) {
-				int i = e / n, j = e - i * n;
+				int i = divn(e), j = e - i * n;
 				sm.W[0][i * LD + j] = (sm.v1[i] != 0.0 && sm.v1[j] != 0.0) ? sm.Minv[i * LD + j] : ((i == j) ? 1.0 : 0.0);
 			}
 			SYNC();

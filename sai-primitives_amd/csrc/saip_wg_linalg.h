@@ -19,7 +19,7 @@ typedef double saip_f64x4 __attribute__((ext_vector_type(4)));
 template <int T>
 __device__ __forceinline__ void gemm(double* C, int ldc, const double* A, int ars, int acs, const double* Bm, int brs, int bcs,
 									 int m, int k, int p, int tid, int mode = GEMM_SET) {
-	if (T >= 256 && m * p >= 128) {
+	if (T >= 256 && (m * p >= 128 || k >= 8)) {  // (small results with a long inner dimension, e.g. A = T1 J^T: one tile beats k serial LDS round trips per output)
 		const int wave = tid >> 6, lane = tid & 63;
 		const int r0 = 16 * (wave >> 1), c0 = 16 * (wave & 1);
 		if (wave < 4 && r0 < m && c0 < p) {  // wave-uniform
