@@ -23,6 +23,7 @@ hipError_t launch_pose(const CycleParams& P, int task, double* out, hipStream_t 
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream);
+hipError_t launch_integrate_otg_pair(const SimParams& S, const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream);
 int otg_state_fields();
 hipError_t launch_integrate(const SimParams& S, hipStream_t stream);
 }  // namespace saip
@@ -372,6 +373,7 @@ struct saip_batch {
 	bool flag_nan = false;                   // saip_batch_set_flagged_torque_policy
 	int* flag_buf = nullptr;                 // [2 * (32 + ld)]: two { count, list } pairs of the device-side slow path, used alternately (CycleParams::flag_*)
 	unsigned flag_parity = 0;
+	bool otg_prelaunched = false;            // rollouts: the paired OTG step of the coming cycle already ran, fused with the previous integrate
 };
 
 static bool has_device(const saip_batch* b) { return b->device >= 0; }
@@ -1360,6 +1362,21 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 	P.oct_partial_mf = full_mf ? 0 : 1;
 	return true;
 }
+// both OTGs of a { MotionForceTask, JointTask } stack on, initialised and with clean limits: their cycle-mode steps share one launch
+static bool otg_pair_ready(saip_batch* b) {
+	if (!(b->tasks.size() == 2 && b->tasks[0].otg_enabled && b->tasks[1].otg_enabled && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE &&
+		  b->tasks[1].dev.type == saip::TASK_JOINT && b->tasks[1].otg.gs == 8 && !b->tasks[0].otg_limits_dirty && !b->tasks[1].otg_limits_dirty))
+		return false;
+	for (int t = 0; t < 2; t++) {
+		TaskHost& T = b->tasks[t];
+		if (!T.otg_inited) return false;
+		T.otg.goal_comps = T.dev.goal_comps;
+		T.otg.task = b->tasks_dev + t;
+		T.otg.dt = T.dev.dt;
+	}
+	return true;
+}
+
 static saip_status launch_cycle(saip_batch* b, bool diag) {
 	CycleParams P;
 	if (!diag)
@@ -1372,16 +1389,13 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 	}
 	// { MotionForceTask, JointTask } with both OTGs on: one launch for the two cycle-mode kernels
 	bool paired = false;
-	if (!diag && b->tasks.size() == 2 && b->tasks[0].otg_enabled && b->tasks[1].otg_enabled && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE &&
-		b->tasks[1].dev.type == saip::TASK_JOINT && b->tasks[1].otg.gs == 8 && !b->tasks[0].otg_limits_dirty && !b->tasks[1].otg_limits_dirty) {
-		for (int t = 0; t < 2; t++) {
-			TaskHost& T = b->tasks[t];
-			T.otg.goal_comps = T.dev.goal_comps;
-			T.otg.task = b->tasks_dev + t;
-			T.otg.dt = T.dev.dt;
+	if (!diag && otg_pair_ready(b)) {
+		if (b->otg_prelaunched) {  // a rollout ran this step together with the previous period's integration
+			b->otg_prelaunched = false;
+		} else {
+			hipError_t e = saip::launch_otg_pair(b->tasks[0].otg, b->tasks[1].otg, b->B, b->ld, b->stream);
+			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "OTG kernel launch failed: %s", hipGetErrorString(e));
 		}
-		hipError_t e = saip::launch_otg_pair(b->tasks[0].otg, b->tasks[1].otg, b->B, b->ld, b->stream);
-		if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "OTG kernel launch failed: %s", hipGetErrorString(e));
 		paired = true;
 	}
 	for (size_t t = 0; t < b->tasks.size() && !paired; t++) {
@@ -1713,7 +1727,7 @@ extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
 extern "C" const char* saip_batch_kernel_name(saip_batch* b) { return b ? b->kernel_name.c_str() : ""; }
 
 // ---- the step after the path: forward dynamics + semi-implicit Euler on the resident state (saip_dynamics.hip)
-static saip_status enqueue_integrate(saip_batch* b, double dt, int substeps, const double* gravity, double damping) {
+static saip_status enqueue_integrate(saip_batch* b, double dt, int substeps, const double* gravity, double damping, bool with_next_otg = false) {
 	SimParams S;
 	S.B = b->B;
 	S.ld = b->ld;
@@ -1727,7 +1741,15 @@ static saip_status enqueue_integrate(saip_batch* b, double dt, int substeps, con
 	S.dq = b->dq;
 	S.tau = b->tau_bound ? b->tau_bound : b->tau;
 	S.ddq = nullptr;
-	hipError_t e = saip::launch_integrate(S, b->stream);
+	hipError_t e;
+	static const bool no_fuse = getenv("SAIP_ROLLOUT_NO_FUSE") != nullptr;  // A/B measurements
+	if (with_next_otg && !no_fuse && S.n == 7 && otg_pair_ready(b)) {
+		// rollouts: this integration and the NEXT period's trajectory generation in one launch (they are independent)
+		e = saip::launch_integrate_otg_pair(S, b->tasks[0].otg, b->tasks[1].otg, b->B, b->ld, b->stream);
+		b->otg_prelaunched = true;
+	} else {
+		e = saip::launch_integrate(S, b->stream);
+	}
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "integrate launch failed: %s", hipGetErrorString(e));
 	b->models_valid = false;  // the state moved: like after robot->setQ(), updateControllerTaskModels() is due
 	b->state_epoch++;
@@ -1754,9 +1776,9 @@ extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double
 	saip_status st = need_ready(b, "saip_batch_rollout_async");
 	if (st) return st;
 	if (steps < 1 || !(sim_dt > 0) || substeps < 1 || damping < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_rollout_async: bad arguments");
-	auto period = [&]() -> saip_status {
+	auto period = [&](const bool more = false) -> saip_status {  // more: another period follows inside this call
 		saip_status s2 = launch_cycle(b, false);
-		return s2 ? s2 : enqueue_integrate(b, sim_dt, substeps, gravity, damping);
+		return s2 ? s2 : enqueue_integrate(b, sim_dt, substeps, gravity, damping, more);
 	};
 	static const bool use_graph = getenv("SAIP_ROLLOUT_GRAPH") != nullptr;
 	bool cycle_dependent = false;  // the device-side slow path and the blended singularity strategies read per-cycle launch parameters
@@ -1778,7 +1800,7 @@ extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double
 		return SAIP_OK;
 	}
 	for (; done < steps; done++)
-		if ((st = period())) return st;
+		if ((st = period(done + 1 < steps))) return st;
 	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_set_torques_host(saip_batch* b, const double* tau) {

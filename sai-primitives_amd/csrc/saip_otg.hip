@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_dynamics_oct_body.h"
 #include "saip_fk.h"
 
 #pragma clang fp contract(off)
@@ -1088,6 +1089,31 @@ hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hi
 	const int block = 256;
 	const int grid_c = (int)(((long long)Oc.lanes + block - 1) / block), grid_j = (int)(((long long)Oj.lanes + block - 1) / block);
 	hipLaunchKernelGGL(saip_otg_pair, dim3(grid_c + grid_j), dim3(block), 0, stream, Oc, Oj, B, ld, grid_c);
+	return hipGetLastError();
+}
+
+// Closed-loop rollouts (saip_batch_rollout_async): the integration step of period k and the trajectory generation of period k + 1 do not
+// depend on each other (the OTGs evolve their own state, they never read the robot's), and each is a handful of latency-bound
+// wavefronts -- one launch instead of two.  Workgroups [0, grid_i) integrate (four wavefronts = four groups of eight instances each),
+// then the Cartesian OTG, then the joint OTG.
+__global__ void __launch_bounds__(256) saip_integrate_otg_pair(const SimParams S, const OtgDev Oc, const OtgDev Oj, int B, int ld, int grid_i, int grid_c) {
+	__shared__ OctDynInst smem[32];
+	const int blk = (int)blockIdx.x;
+	if (blk < grid_i) {
+		const int wave = (int)(threadIdx.x >> 6);
+		integrate_oct_body(S, smem + 8 * wave, blk * 4 + wave, (int)(threadIdx.x & 63));
+	} else if (blk < grid_i + grid_c) {
+		otg_cartesian_body(Oc, B, ld, 0, blk - grid_i);
+	} else {
+		otg_joints_body<8>(Oj, B, ld, 0, blk - grid_i - grid_c);
+	}
+}
+
+hipError_t launch_integrate_otg_pair(const SimParams& S, const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hipStream_t stream) {
+	const int block = 256;
+	const int grid_i = (S.B + 31) / 32;
+	const int grid_c = (int)(((long long)Oc.lanes + block - 1) / block), grid_j = (int)(((long long)Oj.lanes + block - 1) / block);
+	hipLaunchKernelGGL(saip_integrate_otg_pair, dim3(grid_i + grid_c + grid_j), dim3(block), 0, stream, S, Oc, Oj, B, ld, grid_i, grid_c);
 	return hipGetLastError();
 }
 

@@ -150,3 +150,38 @@ def test_eight_lane_dynamics_substeps_ragged_batch_and_coasting():
     others = np.arange(B) != 42
     assert np.array_equal(dq2[others], dq1[others]) and np.array_equal(q2[others], q1[others])
     assert not np.isfinite(dq2[42]).all()
+
+
+def test_rollout_with_fused_integrate_and_next_otg_equals_stepwise_loop():
+    """saip_batch_rollout_async puts the integration of period k and the internal OTG step of period k + 1 into one launch (they are
+    independent: the OTGs evolve their own state).  The same periods issued one call at a time (stepAsync + integrate: separate OTG,
+    cycle and integrate launches) must give the same robot state, OTG state and torques."""
+    B = 200
+    d = W.make_inputs(2, B)
+    out = []
+    for fused in (True, False):
+        robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], B, disable_otg=False)
+        robot.setQ(d["q"])
+        robot.setDq(np.zeros((B, 7)))
+        robot.updateModel()
+        ctrl.reinitializeTasks()
+        mf, jt = tasks
+        mf.setGoalPosition(mf.getGoalPosition() + np.array([0.04, -0.03, 0.05]))
+        qg = d["q"].copy()
+        qg[:, 0] += 0.3
+        jt.setGoalPosition(qg)
+        ctrl.updateControllerTaskModels()
+        K = 37
+        if fused:
+            ctrl.rolloutAsync(K, 5e-4, 2, gravity=(0.0, 0.0, 0.0))
+        else:
+            for _ in range(K):
+                ctrl.stepAsync()
+                ctrl.integrate(5e-4, 2, gravity=(0.0, 0.0, 0.0))
+        ctrl.synchronize()
+        q, dq = ctrl.pullState()
+        out.append((q.copy(), dq.copy(), ctrl.getTorques(), mf.getDesiredPosition(), jt.getDesiredPosition()))
+        assert (ctrl.status & 1).sum() == 0
+    for a, b in zip(*out):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+    assert np.abs(out[0][0] - d["q"]).max() > 1e-3     # the arm did move
