@@ -401,7 +401,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 					for (int kk = 0; kk < 6; kk++) {
 						const double d = Gs[kk][kk];
 						if (!(d > 1e-13)) pos = 0;
-						const double id = 1.0 / d;
+						const double id = wg_rcp(d);  // (a non-positive pivot has already failed the certificate: whatever follows is not used)
 #pragma unroll
 						for (int i = kk + 1; i < 6; i++) {
 							const double lik = Gs[i][kk] * id;
@@ -559,12 +559,12 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 						else if (best < 1e-5 || rb == 0) { going = false; need_exact = true; }  // (rb == 0: the host's rank bound assumed full-rank
 						                                                                        // tasks above; one was passed through -- the exact path decides)
 					} else if (going) {
-						const double ratio = best / c0;
+						const double ratio = best * wg_rcp(c0);
 						if (ratio < 1e-20) going = false;
 						else if (ratio < 1e-4 || s == rb) { going = false; need_exact = true; }
 					}
 					if (!going || s == rb) break;
-					const double inv = rsqrt(best);
+					const double inv = wg_rsqrt(best);
 					{
 						double acc = 0.0;
 						if (cj < n)

@@ -17,6 +17,13 @@ __device__ __forceinline__ double wg_rcp(const double x) {
 	y = fma(fma(-x, y, 1.0), y, y);
 	return fma(fma(-x, y, 1.0), y, y);
 }
+// 1/sqrt(x), x > 0 in the normal range: the same for the reciprocal square root
+__device__ __forceinline__ double wg_rsqrt(const double x) {
+	double y = __builtin_amdgcn_rsq(x);
+	const double h = 0.5 * x;
+	y = fma(y, fma(-h * y, y, 0.5), y);
+	return fma(y, fma(-h * y, y, 0.5), y);
+}
 
 typedef double saip_f64x4 __attribute__((ext_vector_type(4)));
 
