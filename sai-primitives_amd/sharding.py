@@ -62,14 +62,20 @@ class NativeGather:
         from . import capi
         L = capi.lib()
         ident = torch.zeros(128, dtype=torch.uint8)
+        err = None
         if rank == 0:
-            buf = (C.c_ubyte * 128)()
-            capi.check(L.saip_comm_unique_id(buf))
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            try:
+                buf = (C.c_ubyte * 128)()
+                capi.check(L.saip_comm_unique_id(buf))
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            except Exception as e:  # noqa: BLE001  (rank 0 must still take part in the broadcast below, or the other ranks hang in it)
+                err = e
         if world > 1:
             t = ident.to(device) if dist.get_backend() == "nccl" else ident
             dist.broadcast(t, src=0)
             ident = t.cpu()
+        if not bool(ident.any()):   # every rank sees the same thing and gives up together
+            raise RuntimeError(f"no RCCL unique id from rank 0 ({err})")
         buf = (C.c_ubyte * 128)(*ident.tolist())
         self._comm = C.c_void_p()
         capi.check(L.saip_comm_create(int(local_rank), int(world), int(rank), buf, C.byref(self._comm)))
