@@ -81,3 +81,77 @@ def test_random_option_combinations_match_oracle(seed):
             err = W.torque_error(tau[ok], ref[ok])
             print(f"fuzz seed {seed} B {B} kernel {ctrl.kernelName()} cycle {c}: err {err:.2e}, blended {int((st == 8).sum())}, refused {int((~ok).sum())}")
             assert err < TOL, (seed, kernel, c)
+
+
+def _random_partial_spec(rng):
+    """partial motion-force task (1 - 3 translation directions, 0 - 3 rotation directions, not necessarily orthogonal), optionally with
+    velocity saturation or an open-loop force / moment space, and a joint task on a random selection of 1 - 4 joints or on all of them"""
+    nt, nr = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+    dirs_t = [list(rng.standard_normal(3)) for _ in range(nt)]
+    dirs_r = [list(rng.standard_normal(3)) for _ in range(nr)] if nr else None
+    mf = W.motion_force_task("motion_force_task", "end-effector", tuple(rng.uniform(-0.03, 0.08, 3)), dirs_trans=dirs_t, dirs_rot=dirs_r)
+    mode = rng.integers(3)
+    if mode == 1:
+        mf.update(vel_sat=True, lin_sat=float(rng.uniform(0.05, 0.3)), ang_sat=float(rng.uniform(0.2, 1.0)))
+    elif mode == 2 and nt == 3 and nr == 3:
+        mf.update(force_dim=int(rng.integers(1, 3)), force_axis=list(rng.standard_normal(3)), moment_dim=int(rng.integers(0, 2)),
+                  moment_axis=list(rng.standard_normal(3)), kv_force=float(rng.uniform(5, 15)), kv_moment=float(rng.uniform(5, 15)))
+    if rng.random() < 0.5:
+        mf.update(ki_pos=float(rng.uniform(0, 5)), ki_ori=float(rng.uniform(0, 5)))
+    if rng.random() < 0.6:
+        rows = sorted(rng.choice(7, size=int(rng.integers(1, 5)), replace=False).tolist())
+        jt = W.joint_task("partial_joint_task", S=rows)
+    else:
+        jt = W.joint_task("joint_task")
+    if rng.random() < 0.5:
+        jt.update(ki=float(rng.uniform(0, 4)))
+    dec = [W.FULL_DYNAMIC_DECOUPLING, W.BOUNDED_INERTIA_ESTIMATES, W.IMPEDANCE]
+    mf["decoupling"] = dec[rng.integers(3)]
+    jt["decoupling"] = dec[rng.integers(3)]
+    opts = dict(gravity_comp=bool(rng.random() < 0.5), torque_saturation=bool(rng.random() < 0.5), joint_limit_avoidance=bool(rng.random() < 0.4))
+    return [mf, jt], opts
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_partial_stacks_match_oracle(seed):
+    """the FULL / general-joint-task instantiations of the eight-lane kernel (two-wavefront form at these batch sizes), the lane kernel
+    and the general kernel, whichever the engine picks for the stack, against the oracle"""
+    from oracle import Oracle
+    from sai_primitives_amd.controller import controller_from_specs
+    rng = np.random.default_rng(2000 + seed)
+    B = int(rng.choice([64, 333, 1024]))
+    spec, opts = _random_partial_spec(rng)
+    d = W.make_inputs(11 if opts["joint_limit_avoidance"] else 2, B)   # config 11: states pushed into the joint-limit zones
+    goals = [d["goals"][0], d["goals"][1]]
+    if spec[1]["S"] is not None:
+        m = len(spec[1]["S"])
+        g = d["goals"][1]
+        goals[1] = np.concatenate([g[:, :7][:, spec[1]["S"]], g[:, 7:14][:, spec[1]["S"]], g[:, 14:21][:, spec[1]["S"]]], axis=1)
+        assert goals[1].shape[1] == 3 * m
+    if spec[0].get("force_dim", 0) or spec[0].get("moment_dim", 0):
+        goals[0] = np.concatenate([goals[0], rng.uniform(-3, 3, (B, 6))], axis=1)   # goal force / moment of the open-loop force space
+    orc = Oracle(d["model"], spec, **opts)
+    seq = [d["q"]]
+    for _ in range(2):
+        seq.append(seq[-1] + 1e-3 * d["dq"] + 5e-4 * rng.standard_normal(d["q"].shape))
+    refs = [orc.step(q, d["dq"], goals, nthreads=8) for q in seq]
+    robot, ctrl, _ = controller_from_specs(d["model"].name, spec, B, device=0)
+    ctrl.setFlaggedTorquePolicy(True)
+    ctrl.enableGravityCompensation(opts["gravity_comp"])
+    ctrl.enableTorqueSaturation(opts["torque_saturation"])
+    ctrl.enableJointLimitAvoidance(opts["joint_limit_avoidance"])
+    for c, q in enumerate(seq):
+        robot.setQ(q)
+        robot.setDq(d["dq"])
+        robot.updateModel()
+        ctrl.updateControllerTaskModels()
+        ctrl.setGoals(goals)
+        tau = ctrl.computeControlTorques()
+        ref, st = refs[c]
+        assert np.array_equal(ctrl.status & 1, st & 1), (seed, c, np.flatnonzero((ctrl.status & 1) != (st & 1))[:8])
+        ok = (st & 1) == 0
+        assert ok.sum() > B // 2 and np.isfinite(tau[ok]).all()
+        err = W.torque_error(tau[ok], ref[ok])
+        print(f"fuzz partial seed {seed} B {B} kernel {ctrl.kernelName()} dirs {len(spec[0]['dirs_trans'])}+{len(spec[0]['dirs_rot'] or [])} "
+              f"S {spec[1]['S']} cycle {c}: err {err:.2e}, refused {int((~ok).sum())}")
+        assert err < TOL, (seed, c)
