@@ -1096,7 +1096,8 @@ hipError_t launch_otg_pair(const OtgDev& Oc, const OtgDev& Oj, int B, int ld, hi
 // depend on each other (the OTGs evolve their own state, they never read the robot's), and each is a handful of latency-bound
 // wavefronts -- one launch instead of two.  Workgroups [0, grid_i) integrate (four wavefronts = four groups of eight instances each),
 // then the Cartesian OTG, then the joint OTG.
-__global__ void __launch_bounds__(256) saip_integrate_otg_pair(const SimParams S, const OtgDev Oc, const OtgDev Oj, int B, int ld, int grid_i, int grid_c) {
+// (two wavefronts per SIMD: at 260 registers the launch needed two rounds of wavefronts; capped at 256 it fits one -- 21.7 -> 20.3 us per period)
+__global__ void __launch_bounds__(256, 2) saip_integrate_otg_pair(const SimParams S, const OtgDev Oc, const OtgDev Oj, int B, int ld, int grid_i, int grid_c) {
 	__shared__ OctDynInst smem[32];
 	const int blk = (int)blockIdx.x;
 	if (blk < grid_i) {
