@@ -101,6 +101,9 @@ struct TaskDev {
 
 struct CycleParams {
 	int B, ld, n, nt;
+	// rollouts without internal OTGs: the eight-lane kernel integrates the state under the torques it has just written (0 = off)
+	int sim_substeps;
+	double sim_dt, sim_damping, sim_gravity[3];
 	int gravity_comp, torque_sat, integ_always, diag;
 	int jla;           // RobotController::enableJointLimitAvoidance
 	int only_flagged;  // general kernel as the slow path behind the lane kernel: workgroups whose instance has status 0 exit at once

@@ -374,6 +374,9 @@ struct saip_batch {
 	int* flag_buf = nullptr;                 // [2 * (32 + ld)]: two { count, list } pairs of the device-side slow path, used alternately (CycleParams::flag_*)
 	unsigned flag_parity = 0;
 	bool otg_prelaunched = false;            // rollouts: the paired OTG step of the coming cycle already ran, fused with the previous integrate
+	int sim_want = 0;                        // rollouts: substeps the next cycle launch should integrate itself if it can (0 = no) ...
+	double sim_dt = 0, sim_damping = 0, sim_gravity[3] = {0, 0, 0};
+	bool sim_done = false;                   // ... and whether it did (eight-lane kernel, headline-type stack, no slow path behind)
 };
 
 static bool has_device(const saip_batch* b) { return b->device >= 0; }
@@ -1244,6 +1247,9 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.ld = b->ld;
 	P.n = b->model->n;
 	P.nt = (int)b->tasks.size();
+	P.sim_substeps = 0;
+	P.sim_dt = P.sim_damping = 0.0;
+	P.sim_gravity[0] = P.sim_gravity[1] = P.sim_gravity[2] = 0.0;
 	P.gravity_comp = b->gravity_comp;
 	P.torque_sat = b->torque_sat;
 	P.integ_always = b->integ_always;
@@ -1430,6 +1436,14 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (oct && P.oct_general_joint == 0 && b->tasks[0].dev.sing_handling) {
 			slow = false;
 			P.flag_count = P.flag_count_next = P.flag_list = nullptr;
+		}
+		b->sim_done = false;
+		if (b->sim_want > 0 && oct && !slow && P.oct_general_joint == 0) {  // nothing recomputes torques behind this launch: it can integrate as well
+			P.sim_substeps = b->sim_want;
+			P.sim_dt = b->sim_dt;
+			P.sim_damping = b->sim_damping;
+			for (int i = 0; i < 3; i++) P.sim_gravity[i] = b->sim_gravity[i];
+			b->sim_done = true;
 		}
 		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
 		if (oct) lane_ok = true;
@@ -1776,9 +1790,26 @@ extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double
 	saip_status st = need_ready(b, "saip_batch_rollout_async");
 	if (st) return st;
 	if (steps < 1 || !(sim_dt > 0) || substeps < 1 || damping < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_rollout_async: bad arguments");
+	bool any_otg = false;
+	for (auto& T : b->tasks) any_otg = any_otg || T.otg_enabled;
+	static const bool no_fuse_sim = getenv("SAIP_ROLLOUT_NO_FUSE") != nullptr;  // A/B measurements
 	auto period = [&](const bool more = false) -> saip_status {  // more: another period follows inside this call
+		// no internal OTG in the stack: the cycle launch integrates the state itself when it can (eight-lane kernel, no slow path behind)
+		b->sim_want = (!any_otg && !no_fuse_sim && b->model->n == 7) ? substeps : 0;
+		b->sim_dt = sim_dt;
+		b->sim_damping = damping;
+		for (int i = 0; i < 3; i++) b->sim_gravity[i] = gravity ? gravity[i] : b->model->dev.gravity[i];
+		b->sim_done = false;
 		saip_status s2 = launch_cycle(b, false);
-		return s2 ? s2 : enqueue_integrate(b, sim_dt, substeps, gravity, damping, more);
+		b->sim_want = 0;
+		if (s2) return s2;
+		if (b->sim_done) {  // the bookkeeping of enqueue_integrate
+			b->sim_done = false;
+			b->models_valid = false;
+			b->state_epoch++;
+			return SAIP_OK;
+		}
+		return enqueue_integrate(b, sim_dt, substeps, gravity, damping, more);
 	};
 	static const bool use_graph = getenv("SAIP_ROLLOUT_GRAPH") != nullptr;
 	bool cycle_dependent = false;  // the device-side slow path and the blended singularity strategies read per-cycle launch parameters

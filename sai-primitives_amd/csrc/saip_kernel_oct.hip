@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include "saip_device.h"
+#include "saip_dynamics_oct_body.h"
 #include "saip_fk.h"
 #include "saip_law.h"
 #include "saip_oct_common.h"
@@ -1965,14 +1966,38 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	STAMP(15);
 }
 
-template <bool FULL, int GJ, bool DUO = false>
+// SIM (rollouts of stacks without internal OTGs and without a slow path behind): the wavefront that finished the cycle of its eight
+// instances goes on to integrate them (saip_dynamics_oct_body.h) -- same lane layout, the torques it has just written, the LDS block
+// the cycle no longer needs: one launch per closed-loop period.  A separate instantiation, so that the benchmarked kernel does not carry it.
+template <bool FULL, int GJ, bool DUO = false, bool SIM = false>
 __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CycleParams P) {
 	__shared__ OctInst smem[DUO ? 16 : 8];
+	static_assert(sizeof(OctInst) >= sizeof(OctDynInst), "the integration step reuses the cycle's LDS blocks");
+	const bool wave_b = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
 	if (DUO) {
-		if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem, smem + 8);
+		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem, smem + 8);
 		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0>(P, smem, smem, smem + 8);
 	} else {
 		oct_cycle_body<FULL, GJ, 0>(P, smem, smem, smem);
+	}
+	if (SIM && !wave_b) {
+		SimParams S;
+		S.B = P.B;
+		S.ld = P.ld;
+		S.n = P.n;
+		S.substeps = P.sim_substeps;
+		S.dt = P.sim_dt;
+		S.damping = P.sim_damping;
+		S.gravity[0] = P.sim_gravity[0];
+		S.gravity[1] = P.sim_gravity[1];
+		S.gravity[2] = P.sim_gravity[2];
+		S.model = P.model;
+		S.q = const_cast<double*>(P.q);
+		S.dq = const_cast<double*>(P.dq);
+		S.tau = P.tau;
+		S.ddq = nullptr;
+		// (B's block in the two-wavefront form: B has left it for good at the last barrier; else this wavefront's own)
+		integrate_oct_body(S, reinterpret_cast<OctDynInst*>(DUO ? smem + 8 : smem), (int)blockIdx.x, (int)(threadIdx.x & 63));
 	}
 }
 
@@ -2000,10 +2025,16 @@ hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
 	} else if (P.jla || P.lane_general || P.oct_partial_mf) {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true>), grid, dim3(128), 0, stream, P);
+		if (P.sim_substeps > 0) {
+			if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true, true>), grid, dim3(128), 0, stream, P);
+			else hipLaunchKernelGGL((saip_cycle_oct<true, 0, false, true>), grid, block, 0, stream, P);
+		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
 	} else {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
+		if (P.sim_substeps > 0) {
+			if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true, true>), grid, dim3(128), 0, stream, P);
+			else hipLaunchKernelGGL((saip_cycle_oct<false, 0, false, true>), grid, block, 0, stream, P);
+		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
 	}
 	return hipGetLastError();

@@ -152,15 +152,17 @@ def test_eight_lane_dynamics_substeps_ragged_batch_and_coasting():
     assert not np.isfinite(dq2[42]).all()
 
 
-def test_rollout_with_fused_integrate_and_next_otg_equals_stepwise_loop():
+@pytest.mark.parametrize("otg", [True, False], ids=["internal_otg", "no_otg"])
+def test_rollout_with_fused_integrate_and_next_otg_equals_stepwise_loop(otg):
     """saip_batch_rollout_async puts the integration of period k and the internal OTG step of period k + 1 into one launch (they are
-    independent: the OTGs evolve their own state).  The same periods issued one call at a time (stepAsync + integrate: separate OTG,
-    cycle and integrate launches) must give the same robot state, OTG state and torques."""
+    independent: the OTGs evolve their own state); without internal OTGs the cycle launch of the eight-lane kernel integrates the state
+    itself (one launch per period).  The same periods issued one call at a time (stepAsync + integrate: separate OTG, cycle and
+    integrate launches) must give the same robot state, OTG state and torques."""
     B = 200
     d = W.make_inputs(2, B)
     out = []
     for fused in (True, False):
-        robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], B, disable_otg=False)
+        robot, ctrl, tasks = _engine(d["model"].name, d["tasks"], B, disable_otg=not otg)
         robot.setQ(d["q"])
         robot.setDq(np.zeros((B, 7)))
         robot.updateModel()
