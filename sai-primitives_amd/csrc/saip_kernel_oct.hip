@@ -272,6 +272,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	const TaskDev& mf = P.tasks[0];
 	const TaskDev& jt = P.tasks[1];
 	const int kmf = FULL ? mf.k : 6;  // rank of the motion-force task (partial tasks: rows >= k of its Jacobian are zero, diagonals padded with 1)
+	// disableSingularityHandling(): near-singular tasks are reduced in the kernel instead of being flagged (batch-uniform)
+	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;
 
 	STAMP(0);
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
@@ -446,8 +448,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
 		}
 	}
-	if (DUO) __syncthreads();  // workgroup barrier: B's Jacobian is complete (A arrives ~1 k clocks after B)
-	else oct_sync<DUO>();
+	if (DUO && !trunc_mode) __syncthreads();  // workgroup barrier: B's Jacobian is complete (A arrives ~1 k clocks after B)
+	else oct_sync<DUO>();                     // (reduced tasks: A waits further down, for the Jacobian B has reduced)
 	STAMP(3);
 	// ---------------------------------------------------------------- M^-1: Cholesky factor in every lane, own column of the inverse
 	// M_BIE = M + sum_e c_e e e^T, the diagonal clamped from below (SingularityHandler.cpp:176-182).  Usual case (at most one clamped
@@ -498,6 +500,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}
 	STAMP(4);
 	double Jf[6][N];
+	unsigned keep_bits_b = 0x3fu;
+	if (DUO && trunc_mode && ROLE == 1) {  // the Jacobian B has reduced, and which directions it kept (B is there ~15 k clocks later: its eigen-solve)
+		__syncthreads();
+		keep_bits_b = (unsigned)smB.vec[6][7];
+	}
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = (ROLE == 1 ? smB : sm).J[a][j];
 	double vw[6] = {0, 0, 0, 0, 0, 0};
@@ -522,9 +529,6 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #else
 	const bool strategies_on = GJ == 0 && mf.sing_handling && mf.sing_strategies && mf.sh != nullptr;  // batch-uniform; the blended branch lives in the headline stack's tail
 #endif
-	// disableSingularityHandling(): reduce the task instead of flagging.  (Never in the two-wavefront form: the reduction rewrites the
-	// Jacobian the inertia chain is waiting for; the launcher keeps such batches on the one-wavefront form.)
-	const bool trunc_mode = FULL && GJ == 2 && !DUO && P.oct_truncate;
 	double G[6][6], U6[6][6];
 	bool keepm[6] = {true, true, true, true, true, true};
 	if (roleB) {
@@ -682,6 +686,16 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		oct_sync<DUO>();
 		UNR for (int a = 0; a < 6; a++)
 			UNR for (int j = 0; j < N; j++) Jf[a][j] = sm.J[a][j];
+	}
+	if (DUO && trunc_mode) {
+		if (ROLE == 2) {
+			unsigned kb = 0;
+			UNR for (int c = 0; c < 6; c++) kb |= keepm[c] ? (1u << c) : 0u;
+			if (r == 0) sm.vec[6][7] = (double)kb;
+			__syncthreads();  // (unconditional: every wavefront B arrives, whether or not it had anything to reduce)
+		} else if (ROLE == 1) {
+			UNR for (int c = 0; c < 6; c++) keepm[c] = ((keep_bits_b >> c) & 1u) != 0u;
+		}
 	}
 	bool keep_ra = true;  // is this lane's row of the task kept (partial task: rows >= k are not; reduced task: the dropped directions)
 	STAMP(7);
@@ -886,7 +900,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				sm.vec[6][r] = fo;
 				sm.vec[5][r] = ffo;
 			}
-			if (r == 6) sm.vec[6][6] = singular ? 1.0 : 0.0;
+			if (r == 6) sm.vec[6][6] = (singular ? 1.0 : 0.0) + (truncated ? 2.0 : 0.0);
 		}
 		STAMP(29);
 		__syncthreads();
@@ -897,7 +911,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				Fum6[a] = smB.vec[6][a];
 				Ff6[a] = smB.vec[5][a];
 			}
-			if (GJ != 0) singular = smB.vec[6][6] != 0.0;  // (headline stack: the final flags arrive at the second barrier)
+			if (GJ != 0) {  // (headline stack: the final flags arrive at the second barrier)
+				const int fl = (int)smB.vec[6][6];
+				singular = (fl & 1) != 0;
+				truncated = (fl & 2) != 0;
+			}
 		}
 		if (GJ == 0) {
 			// both factor A (B cannot wait for A's factor: the tail is split between them from here)
@@ -2019,7 +2037,7 @@ hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
 	const bool duo = oct_duo_enabled((int)grid.x);
 	if (P.oct_general_joint == 2) {
-		if (duo && !P.oct_truncate) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, P);
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
 	} else if (P.oct_general_joint == 1) {
 		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, P);
