@@ -19,6 +19,7 @@ hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream);
 hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
+hipError_t launch_cycle_wave(const CycleParams& P, hipStream_t stream);
 hipError_t launch_pose(const CycleParams& P, int task, double* out, hipStream_t stream);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
@@ -372,7 +373,8 @@ struct saip_batch {
 	hipEvent_t time_ev[2] = {nullptr, nullptr};  // saip_batch_time_steps (created once: event creation is not part of a timed region)
 	bool flag_nan = false;                   // saip_batch_set_flagged_torque_policy
 	int* flag_buf = nullptr;                 // [2 * (32 + ld)]: two { count, list } pairs of the device-side slow path, used alternately (CycleParams::flag_*)
-	unsigned flag_parity = 0;
+	unsigned flag_parity = 0;                // advanced only by a launch that hands the pair to a kernel
+	bool flag_clean[2] = {true, true};       // whether each pair's count is known to be zero (the buffer is zeroed at allocation)
 	bool otg_prelaunched = false;            // rollouts: the paired OTG step of the coming cycle already ran, fused with the previous integrate
 	int sim_want = 0;                        // rollouts: substeps the next cycle launch should integrate itself if it can (0 = no) ...
 	double sim_dt = 0, sim_damping = 0, sim_gravity[3] = {0, 0, 0};
@@ -1338,6 +1340,18 @@ static bool lane_eligible(const saip_batch* b) {
 	}
 	return nmf <= 2;
 }
+// wavefront-per-instance kernel (saip_kernel_wave.hip): chains of 9..32 dof, any stack of motion-force tasks (rank >= 2) and joint tasks.
+// A passivity controller around a force loop keeps its stack on the general kernel: its observer state in HBM is advanced by the control
+// law itself, so an instance this kernel flags late in the hierarchy would advance it twice when the general kernel recomputes it.
+static bool wave_eligible(const saip_batch* b) {
+	const int n = b->model->n;
+	if (n <= 8 || n > 32) return false;
+	for (auto& T : b->tasks) {
+		if (T.dev.type == saip::TASK_MOTION_FORCE && (T.dev.cl_force || T.dev.cl_moment) && T.dev.popc_enabled) return false;
+		if (T.dev.type == saip::TASK_MOTION_FORCE && (T.dev.k < 2 || T.dev.k > 6)) return false;
+	}
+	return true;
+}
 // eight-lanes-per-instance kernel (saip_kernel_oct.hip): 7-dof chain, { MotionForceTask, JointTask }.  Either the headline stack
 // (full 6-dof motion-force task + full joint task: the joint task has rank <= 1) or any motion-force task of rank >= 2 with a joint
 // task of at most four rows (general range basis); default or general control laws, no closed-loop force control.
@@ -1422,7 +1436,6 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (slow) {
 			int* cur = b->flag_buf + (size_t)(b->flag_parity & 1u) * (b->ld + 32);
 			int* nxt = b->flag_buf + (size_t)((b->flag_parity + 1u) & 1u) * (b->ld + 32);
-			b->flag_parity++;
 			P.flag_count = cur;
 			P.flag_list = cur + 32;
 			P.flag_count_next = nxt;
@@ -1445,8 +1458,19 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 			for (int i = 0; i < 3; i++) P.sim_gravity[i] = b->sim_gravity[i];
 			b->sim_done = true;
 		}
+		if (slow && !b->flag_clean[b->flag_parity & 1u]) {
+			// the pair this launch appends to was not zeroed by the cycle before (a cycle without a slow path, another kernel choice, or a
+			// failed launch came in between): zero its count here, or stale entries would be recomputed a second time
+			HIP_TRY(hipMemsetAsync(P.flag_count, 0, sizeof(int), b->stream));
+			b->flag_clean[b->flag_parity & 1u] = true;
+		}
 		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
 		if (oct) lane_ok = true;
+		if (slow && lane_ok && e == hipSuccess) {  // the kernel appends to the current pair and zeroes the other one
+			b->flag_clean[b->flag_parity & 1u] = false;
+			b->flag_clean[(b->flag_parity + 1u) & 1u] = true;
+			b->flag_parity++;
+		}
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
 			b->kernel_name = oct ? "saip_cycle_oct" : "saip_cycle_lane";
@@ -1458,6 +1482,30 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		}
 	}
 	if (!diag && b->kernel_choice == 2) return fail(SAIP_ERR_UNSUPPORTED, "the lane-per-instance kernel does not cover this robot/task stack");
+	if (!diag && b->kernel_choice == 4 && !wave_eligible(b)) return fail(SAIP_ERR_UNSUPPORTED, "the wavefront-per-instance kernel covers chains of 9 to 32 dof without a passivity controller");
+	if (!diag && (b->kernel_choice == 0 || b->kernel_choice == 4) && wave_eligible(b)) {
+		// chains of 9..32 dof: one wavefront per instance, matrices in MFMA operand form (saip_kernel_wave.hip).  What it cannot certify
+		// (a task outside the non-singular branch, an ambiguous rank gap, ...) it leaves untouched on the device-side work list; the
+		// general kernel behind recomputes those instances -- an empty list costs that launch one scalar load per workgroup
+		int* cur = b->flag_buf + (size_t)(b->flag_parity & 1u) * (b->ld + 32);
+		int* nxt = b->flag_buf + (size_t)((b->flag_parity + 1u) & 1u) * (b->ld + 32);
+		P.flag_count = cur;
+		P.flag_list = cur + 32;
+		P.flag_count_next = nxt;
+		if (!b->flag_clean[b->flag_parity & 1u]) {
+			HIP_TRY(hipMemsetAsync(P.flag_count, 0, sizeof(int), b->stream));
+			b->flag_clean[b->flag_parity & 1u] = true;
+		}
+		hipError_t e = saip::launch_cycle_wave(P, b->stream);
+		if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "wavefront-per-instance kernel launch failed: %s", hipGetErrorString(e));
+		b->flag_clean[b->flag_parity & 1u] = false;
+		b->flag_clean[(b->flag_parity + 1u) & 1u] = true;
+		b->flag_parity++;
+		b->kernel_name = "saip_cycle_wave";
+		hipError_t e2 = saip::launch_cycle_wg_list(P, b->stream);
+		if (e2 != hipSuccess) return fail(SAIP_ERR_DEVICE, "slow-path kernel launch failed: %s", hipGetErrorString(e2));
+		return SAIP_OK;
+	}
 	hipError_t e = saip::launch_cycle_wg(P, b->stream);
 	if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
 	b->kernel_name = P.n <= 8 ? "saip_cycle_wg<8,64>" : "saip_cycle_wg<32,512>";
@@ -1734,7 +1782,7 @@ extern "C" saip_status saip_batch_wait_for(saip_batch* waiter, saip_batch* produ
 }
 
 extern "C" saip_status saip_batch_set_kernel(saip_batch* b, int which) {
-	if (!b || which < 0 || which > 3) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1, 2 or 3");
+	if (!b || which < 0 || which > 4) return fail(SAIP_ERR_INVALID_ARGUMENT, "kernel selector must be 0, 1, 2, 3 or 4");
 	b->kernel_choice = which;
 	return SAIP_OK;
 }

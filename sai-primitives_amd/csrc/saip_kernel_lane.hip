@@ -1177,7 +1177,10 @@ __global__ void __launch_bounds__(64) saip_cycle_lane(const CycleParams P) {
 			else if (P.flag_nan) P.tau[(size_t)j * ld + b] = __builtin_nan("");
 		}
 		P.status[b] = singular ? 1 : 0;
-		if (singular && P.flag_list) P.flag_list[atomicAdd(P.flag_count, 1)] = b;  // work list of the device-side slow path
+		if (singular && P.flag_list) {
+			const int slot = atomicAdd(P.flag_count, 1);
+			if (slot < P.B) P.flag_list[slot] = b;
+		}  // work list of the device-side slow path
 		if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;   // the other list: its last readers finished a cycle ago
 		// integrators: commit what the control laws advanced them to, unless the instance ended flagged (then nothing advances: the slow
 		// path launched behind recomputes it from the untouched state, or it stays invalid)

@@ -1964,7 +1964,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
 	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
 	if (live && r == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (blended_i ? 8 : 0));
-	if (live && r == 0 && singular && P.flag_list) P.flag_list[atomicAdd(P.flag_count, 1)] = b;  // work list of the device-side slow path
+	if (live && r == 0 && singular && P.flag_list) {
+		const int slot = atomicAdd(P.flag_count, 1);
+		if (slot < P.B) P.flag_list[slot] = b;
+	}  // work list of the device-side slow path
 	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;                       // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged (then nothing advances: the slow path
 	// launched behind recomputes it from the untouched state, or it stays invalid); the lanes that wrote the shadow rows copy them

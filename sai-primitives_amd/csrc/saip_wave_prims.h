@@ -1,0 +1,209 @@
+// Register-resident dense linear algebra for ONE WAVEFRONT PER ROBOT INSTANCE (saip_kernel_wave.hip: chains of 9..32 dof).
+//
+// Every matrix of the instance lives in the wavefront's registers in the operand layout of v_mfma_f64_16x16x4_f64, so products need
+// no data movement at all and nothing is synchronised by a barrier.  With lo = lane & 15, hi = lane >> 4:
+//
+//   "stored form" of a matrix X (4 KS rows, 16 T columns):   v[ks][t] = X[4 ks + hi][16 t + lo]          (one double per lane)
+//
+// This is at once the B operand of X (k index = hi), the A operand of X^T (row = lo, k = hi) and -- four consecutive ks at a time --
+// the C/D tile of the instruction (row = 4 r + hi, column = lo; cdna_hip_programming.md:160-161).  Hence ONE product primitive,
+//
+//   wv_mm(S1, S2) = stored(S1^T S2),      contraction over the ROW index of both stored operands,
+//
+// whose result is again in stored form; every product of the control cycle is arranged to be of that shape (the transposed
+// operand is obtained by swapping the roles of the two factors, never by moving data).  Symmetric matrices (M^-1, Lambda) are their
+// own transposes.  Vectors live in LDS: "row distribution" x[4 ks + hi] feeds wv_matvec, which returns y = S^T x in "column
+// distribution" y[16 t + lo] (the same value in the four lanes lo, lo + 16, lo + 32, lo + 48).
+//
+// SPD inverses are a blocked symmetric sweep (wv_sweep): pivot blocks of 4 (= the k depth of the instruction); the panel scaling
+// W = P D^-1, the trailing update X -= W P^T and the fix-up of the pivot's block column all ride on the matrix cores; the 4 x 4
+// diagonal block is inverted redundantly per lane from lane-broadcast (v_readlane) entries.  tools/proto/wave_forms.py is the NumPy
+// model of this file's index algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "saip_oct_common.h"
+
+namespace saip {
+
+typedef double wv_f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wv_u32x2 __attribute__((ext_vector_type(2)));
+
+// ordering point for LDS traffic inside the (single) wavefront of a workgroup: LDS operations of one wavefront execute in order, so a
+// wavefront-scope fence is all it takes (no s_barrier)
+__device__ __forceinline__ void wv_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wv_pack(const unsigned lo, const unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// sum over the four 16-lane rows (lanes lo, lo + 16, lo + 32, lo + 48), every lane gets the total, bitwise the same in all four:
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange whole rows between two registers -- two VALU moves per dword, no LDS
+__device__ __forceinline__ double wv_hsum(const double x) {
+	const unsigned l = (unsigned)__double2loint(x), h = (unsigned)__double2hiint(x);
+	const wv_u32x2 a = __builtin_amdgcn_permlane16_swap(l, l, false, false);
+	const wv_u32x2 b = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+	const double y = wv_pack(a.x, b.x) + wv_pack(a.y, b.y);  // rows {0,1}: r0 + r1, rows {2,3}: r2 + r3
+	const unsigned l2 = (unsigned)__double2loint(y), h2 = (unsigned)__double2hiint(y);
+	const wv_u32x2 c = __builtin_amdgcn_permlane32_swap(l2, l2, false, false);
+	const wv_u32x2 d = __builtin_amdgcn_permlane32_swap(h2, h2, false, false);
+	return wv_pack(c.x, d.x) + wv_pack(c.y, d.y);
+}
+
+// value of the lane `n` places to the right inside the 16-lane row, cyclically (DPP row_ror)
+template <int N>
+__device__ __forceinline__ double wv_ror(const double x) {
+	const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + N, 0xF, 0xF, false);
+	const int h = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + N, 0xF, 0xF, false);
+	return __hiloint2double(h, l);
+}
+template <int N>
+__device__ __forceinline__ int wv_ror_i(const int x) {
+	return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
+}
+// sum over the 16 lanes of a row; the pairing is commutative at every step, so all lanes end with bitwise the same value
+__device__ __forceinline__ double wv_rowsum(double x) {
+	x += wv_ror<8>(x);
+	x += wv_ror<4>(x);
+	x += wv_ror<2>(x);
+	return x + wv_ror<1>(x);
+}
+__device__ __forceinline__ double wv_wavesum(const double x) { return wv_hsum(wv_rowsum(x)); }
+
+// (value, index) arg-max over the 16 lanes of a row, ties to the lower index: a total order, so every lane ends with the same pair
+#define WV_ARGMAX_STEP(N)                                                   \
+	{                                                                       \
+		const double ob = wv_ror<N>(best);                                  \
+		const int oj = wv_ror_i<N>(jb);                                     \
+		const bool take = ob > best || (ob == best && oj < jb);             \
+		best = take ? ob : best;                                            \
+		jb = take ? oj : jb;                                                \
+	}
+__device__ __forceinline__ void wv_row_argmax(double& best, int& jb) {
+	WV_ARGMAX_STEP(8)
+	WV_ARGMAX_STEP(4)
+	WV_ARGMAX_STEP(2)
+	WV_ARGMAX_STEP(1)
+}
+
+__device__ __forceinline__ double wv_readlane(const double x, const int src) {  // src wave-uniform
+	const int l = __builtin_amdgcn_readlane(__double2loint(x), src);
+	const int h = __builtin_amdgcn_readlane(__double2hiint(x), src);
+	return __hiloint2double(h, l);
+}
+
+// C (+)= sign * S1^T S2.  A: stored S1 (4 KS x 16 TA), B: stored S2 (4 KS x 16 TB); C: the first RK register rows of the stored
+// 16 TA x 16 TB result (RK = 4 TA keeps all of it; a k x n result with k <= 8 keeps RK = 2).  The TA x TB tiles are independent
+// accumulation chains, interleaved over ks.
+template <bool ACC, bool NEG, int KS, int TA, int TB, int RK>
+__device__ __forceinline__ void wv_mm(const double (&A)[KS][TA], const double (&B)[KS][TB], double (&C)[RK][TB]) {
+	static_assert(RK <= 4 * TA, "result rows");
+	wv_f64x4 acc[TA][TB];
+	UNR for (int rt = 0; rt < TA; rt++)
+		UNR for (int ct = 0; ct < TB; ct++)
+			UNR for (int r = 0; r < 4; r++) acc[rt][ct][r] = (ACC && 4 * rt + r < RK) ? C[4 * rt + r][ct] : 0.0;
+	UNR for (int ks = 0; ks < KS; ks++)
+		UNR for (int rt = 0; rt < TA; rt++) {
+			if (4 * rt >= RK) continue;
+			const double a = NEG ? -A[ks][rt] : A[ks][rt];
+			UNR for (int ct = 0; ct < TB; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[ks][ct], acc[rt][ct], 0, 0, 0);
+		}
+	UNR for (int rt = 0; rt < TA; rt++)
+		UNR for (int ct = 0; ct < TB; ct++)
+			UNR for (int r = 0; r < 4; r++)
+				if (4 * rt + r < RK) C[4 * rt + r][ct] = acc[rt][ct][r];
+}
+
+// y = S^T x in column distribution (y[t] = entry 16 t + lo, the same in all four rows); xr = x in row distribution (xr[ks] = x[4 ks + hi])
+template <int KS, int T>
+__device__ __forceinline__ void wv_matvec(const double (&S)[KS][T], const double (&xr)[KS], double (&y)[T]) {
+	UNR for (int t = 0; t < T; t++) {
+		double s = 0.0;
+		UNR for (int ks = 0; ks < KS; ks++) s = fma(S[ks][t], xr[ks], s);
+		y[t] = wv_hsum(s);
+	}
+}
+template <int KS>
+__device__ __forceinline__ void wv_load_rows(const double* x, const int hi, double (&xr)[KS]) {
+	UNR for (int ks = 0; ks < KS; ks++) xr[ks] = x[4 * ks + hi];
+}
+
+// In place: stored symmetric positive definite X (16 T x 16 T) -> stored -X^-1 on the leading 4 nb rows / columns (nb wave-uniform;
+// what lies beyond must be the identity -- it is left alone).  Returns the smallest LDL^T pivot met: X is positive definite iff it is
+// positive (the singular-value certificates test it against their tolerance; a caller that gets a non-positive one discards the
+// result).  Block step kb (pivot rows 4 kb .. 4 kb + 3, living in column tile t0 = kb / 4 at lanes lo = rho .. rho + 3, rho = 4 (kb % 4)):
+//   P_t = v[kb][t]                       the pivot's block row = (by symmetry) its block column, already an MFMA operand
+//   D   = the 4 x 4 diagonal block       16 lanes of P_t0; every lane rebuilds it from v_readlane broadcasts and inverts it (Cholesky)
+//   W_t = P_t D^-1                       one MFMA per tile: A operand = D^-1 on rows rho .., B operand = P_t; lands in register kb % 4
+//   X  -= W P'^T                         T x T MFMAs; P' = P with -I on the pivot's own columns and those columns of X zeroed first, so
+//                                        that the block column comes out as +W exactly (sweep operator: a_ik <- a_ik / a_kk)
+//   v[kb][t] = W_t, diagonal block = -D^-1
+template <int T>
+__device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, const int lo, const int hi) {
+	double minpiv = 1.0e300;
+	UNR for (int kb = 0; kb < 4 * T; kb++) {
+		if (kb < nb) {  // wave-uniform
+			const int t0 = kb >> 2, rho = 4 * (kb & 3);
+			double P[T];
+			UNR for (int t = 0; t < T; t++) P[t] = v[kb][t];
+			// D[b][a] sits in lane (rho + a) + 16 b of P[t0]; lower triangle by broadcast
+			double L[4][4], dinv[4];
+			UNR for (int i = 0; i < 4; i++)
+				UNR for (int j2 = 0; j2 <= i; j2++) L[i][j2] = wv_readlane(P[t0], (rho + j2) + 16 * i);
+			UNR for (int k = 0; k < 4; k++) {
+				minpiv = fmin(minpiv, L[k][k]);
+				const double rs = oct_rsqrt(L[k][k]);
+				dinv[k] = rs;
+				UNR for (int i = k + 1; i < 4; i++) L[i][k] *= rs;
+				UNR for (int j2 = k + 1; j2 < 4; j2++)
+					UNR for (int i = j2; i < 4; i++) L[i][j2] = fma(-L[i][k], L[j2][k], L[i][j2]);
+			}
+			double x[4];
+			oct_solve_unit<4>(L, dinv, hi, x);  // column hi of D^-1
+			const int a = lo - rho;
+			const bool inblk = a >= 0 && a < 4;
+			const double xa = (a == 0) ? x[0] : (a == 1) ? x[1] : (a == 2) ? x[2] : x[3];
+			const double dl = inblk ? xa : 0.0;  // D^-1[a][hi] on the pivot's lanes, 0 elsewhere
+			double W[T];
+			UNR for (int t = 0; t < T; t++) {
+				wv_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dl, P[t], acc, 0, 0, 0);
+				W[t] = acc[kb & 3];  // W[16 t + lo][hi]
+			}
+			UNR for (int ks = 0; ks < 4 * T; ks++) v[ks][t0] = inblk ? 0.0 : v[ks][t0];
+			double Pm[T];
+			UNR for (int t = 0; t < T; t++) Pm[t] = P[t];
+			Pm[t0] = inblk ? ((hi == a) ? -1.0 : 0.0) : Pm[t0];
+			UNR for (int rt = 0; rt < T; rt++)
+				UNR for (int ct = 0; ct < T; ct++) {
+					wv_f64x4 acc;
+					UNR for (int r = 0; r < 4; r++) acc[r] = v[4 * rt + r][ct];
+					acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[rt], Pm[ct], acc, 0, 0, 0);
+					UNR for (int r = 0; r < 4; r++) v[4 * rt + r][ct] = acc[r];
+				}
+			UNR for (int t = 0; t < T; t++) v[kb][t] = W[t];
+			v[kb][t0] = inblk ? -dl : v[kb][t0];
+		}
+	}
+	return minpiv;
+}
+
+template <int KS, int T>
+__device__ __forceinline__ void wv_negate(double (&v)[KS][T]) {
+	UNR for (int ks = 0; ks < KS; ks++)
+		UNR for (int t = 0; t < T; t++) v[ks][t] = -v[ks][t];
+}
+// identity on the diagonal entries i >= from (i < upto), untouched elsewhere: pads a k x k block to the next multiple of the pivot block
+template <int KS, int T>
+__device__ __forceinline__ void wv_pad_identity(double (&v)[KS][T], const int from, const int upto, const int lo, const int hi) {
+	UNR for (int ks = 0; ks < KS; ks++)
+		UNR for (int t = 0; t < T; t++) {
+			const int i = 4 * ks + hi, j = 16 * t + lo;
+			const bool diag = (i == j), pad = (i >= from || j >= from) && i < upto && j < upto;
+			v[ks][t] = pad ? (diag ? 1.0 : 0.0) : v[ks][t];
+		}
+}
+
+}  // namespace saip
