@@ -29,25 +29,57 @@
 #include "saip_law.h"
 #include "saip_wave_prims.h"
 
+#if defined(SAIP_STAMP_WAVE)
+// diagnostic build only (never shipped): s_memtime of lane 0 of the first 256 instances at the phase boundaries (tools/wave_stamps.py)
+__device__ unsigned long long saip_stamps_wave[256][64];
+#define WSTAMP(id)                                                                              \
+	do {                                                                                        \
+		if (lane == 0 && b < 256) saip_stamps_wave[b][id] = __builtin_amdgcn_s_memtime();       \
+	} while (0)
+#else
+#define WSTAMP(id)
+#endif
+
 namespace saip {
 
 struct WaveSmem {
 	static constexpr int LDI = 33;
 	double img[32 * LDI];  // staging for the kinematics scans, then the image of U^T Jp (joint task), read back in both operand forms
 	double jd[32][12];     // per joint, about the world origin: motion axis S = (w, v), F = Ic S = (f, nO)
+	double fr[32][12];     // world frame of every body: R (row-major), o
 	double q[32], dq[32], tau[32], va[32], vb[32], vc[32], vd[32], act[32], diagM[32];
 	double goal[96];
 	double vw[8], Fum[8], Ff[8], xp[4], Rc[12];
-	double f8[16], ff8[16], g8[16];
+	double f8[SAIP_MAXT][8], ff8[SAIP_MAXT][8], g8[16];  // per motion-force task: B^T F_um, B^T F_f (range(P) coordinates); g = Lambda_mod fhat + ffhat
 	int idx[16];
 	int flag2;
 };
+
+// sin / cos of a joint angle: saip_fk.h's Cody-Waite + fdlibm kernels without the library fallback for |x| >= 1e5 (whose private arrays
+// would put scratch into this kernel): such an angle flags the instance instead (the general kernel evaluates it)
+__device__ __forceinline__ void wv_sincos(const double x, double* sn, double* cs) {
+	const double k = rint(x * 6.36619772367581382433e-01);
+	double r = fma(-k, 1.57079632673412561417e+00, x);
+	r = fma(-k, 6.07710050650619224932e-11, r);
+	const double z = r * r;
+	const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+	const double s0 = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+	const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+	const double c0 = 1.0 - fma(0.5, z, -z * pc);
+	const int q = (int)k & 3;
+	const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+	*sn = (q & 2) ? -sa : sa;
+	*cs = ((q + 1) & 2) ? -ca : ca;
+}
 
 __device__ __forceinline__ double wv_dot6(const double* S, const double* F) {  // S = (w, v), F = (f, nO): w . nO + v . f
 	return fma(S[5], F[2], fma(S[4], F[1], fma(S[3], F[0], fma(S[2], F[5], fma(S[1], F[4], S[0] * F[3])))));
 }
 
-__global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
+#ifndef SAIP_WAVE_OCC
+#define SAIP_WAVE_OCC 2  // wavefronts per SIMD the register allocation aims at (A/B knob of tools/oct_variant.sh)
+#endif
+__global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const CycleParams P) {
 	__shared__ WaveSmem sm;
 	const int b = blockIdx.x;
 	if (b >= P.B) return;
@@ -59,9 +91,11 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 	constexpr int LDI = WaveSmem::LDI;
 
 	bool flagged = false;  // wave-uniform
+	WSTAMP(0);
 	// ---------------------------------------------------------------- state
 	const double qj = jv ? P.q[(size_t)j * ld + b] : 0.0;
 	const double dqj = jv ? P.dq[(size_t)j * ld + b] : 0.0;
+	if (__ballot(jv && !(fabs(qj) < 1.0e5)) != 0ull) flagged = true;  // not a joint angle (or not finite): left to the general kernel
 	if (lane < 32) {
 		sm.q[j] = qj;
 		sm.dq[j] = dqj;
@@ -75,7 +109,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 	{
 		const double ax = jr.axis[0], ay = jr.axis[1], az = jr.axis[2];
 		double s, c;
-		sincos_joint(qj, &s, &c);
+		wv_sincos(qj, &s, &c);
 		if (!rev) {
 			s = 0.0;
 			c = 1.0;
@@ -113,6 +147,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 			wv_sync();
 		}
 	}
+	WSTAMP(1);
 	// world axis, spatial inertia of body j about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
 	double z[3], Bd[10];
 	{
@@ -176,6 +211,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 							  Bd[7] * w[0] + Bd[5] * w[1] + Bd[9] * w[2] + (hz * v[0] - hx * v[2]),
 							  Bd[8] * w[0] + Bd[9] * w[1] + Bd[6] * w[2] + (hx * v[1] - hy * v[0])};
 		if (lane < 32) {
+			UNR for (int e = 0; e < 12; e++) sm.fr[j][e] = X[e];
 			UNR for (int e = 0; e < 3; e++) {
 				sm.jd[j][e] = jv ? w[e] : 0.0;
 				sm.jd[j][3 + e] = jv ? v[e] : 0.0;
@@ -195,6 +231,109 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 		}
 	}
 	wv_sync();
+	// ---------------------------------------------------------------- motion-force control laws (MotionForceTask.cpp:286-509), ahead of everything
+	// that needs registers: a law depends on the kinematics only (control frame, vw = Jw dq, goals), runs on one lane and carries a
+	// large set of temporaries (sigma projectors, ...) -- here nothing else is live yet.  F_um, F_f wait in LDS as range(P) coordinates.
+	unsigned commit_lo = 0, commit_hi = 0;
+	for (int t = 0; t < P.nt; t++) {
+		const TaskDev& tk = P.tasks[t];
+		if (tk.type != TASK_MOTION_FORCE) continue;
+		const bool track = tk.has_ki || P.integ_always;
+		const int k = tk.k, bd = tk.body;
+		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = tk.goal[(size_t)e * ld + b];
+		double Rb[9], ob[3], pw[3], Rcf[9];
+		UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bd][e];
+		UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bd][9 + e];
+		oct_mat3_vec(Rb, tk.pos, pw);
+		UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
+		UNR for (int r = 0; r < 3; r++)
+			UNR for (int cc = 0; cc < 3; cc++) Rcf[3 * r + cc] = Rb[3 * r] * tk.rot[cc] + Rb[3 * r + 1] * tk.rot[3 + cc] + Rb[3 * r + 2] * tk.rot[6 + cc];
+		// task-frame velocities use the unprojected Jacobian (MotionForceTask.cpp:293-298): vw = Jw dq, column j = (w_j x p + v_j; w_j)
+		double vwp[6] = {0, 0, 0, 0, 0, 0};
+		UNR for (int ks = 0; ks < 8; ks++) {
+			const int jj = 4 * ks + hi;
+			const double* S = sm.jd[jj];
+			const double dqv = (jj <= bd) ? sm.dq[jj] : 0.0;
+			vwp[0] = fma(S[1] * pw[2] - S[2] * pw[1] + S[3], dqv, vwp[0]);
+			vwp[1] = fma(S[2] * pw[0] - S[0] * pw[2] + S[4], dqv, vwp[1]);
+			vwp[2] = fma(S[0] * pw[1] - S[1] * pw[0] + S[5], dqv, vwp[2]);
+			vwp[3] = fma(S[0], dqv, vwp[3]);
+			vwp[4] = fma(S[1], dqv, vwp[4]);
+			vwp[5] = fma(S[2], dqv, vwp[5]);
+		}
+		UNR for (int e = 0; e < 6; e++) {
+			const double sv = wv_hsum(vwp[e]);
+			if (lane == 0) sm.vw[e] = sv;
+		}
+		if (lane == 0) {
+			UNR for (int e = 0; e < 3; e++) sm.xp[e] = pw[e];
+			UNR for (int e = 0; e < 9; e++) sm.Rc[e] = Rcf[e];
+		}
+		wv_sync();
+		if (lane == 0) {
+			double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, ifm[6] = {0, 0, 0, 0, 0, 0};
+			if (track)
+				for (int i = 0; i < 3; i++) {
+					ip[i] = tk.integ[(size_t)i * ld + b];
+					io[i] = tk.integ[(size_t)(3 + i) * ld + b];
+				}
+			const bool closed = tk.cl_force || tk.cl_moment;
+			if (closed)
+				for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * ld + b];
+			bool ovf = false;
+			if (tk.general_law) {
+				// velocity saturation, force / moment spaces, open- or closed-loop force control
+				law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, sm.goal, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, ld, &ovf);
+			} else {
+				// the defaults (sigma_force = sigma_moment = 0, no velocity saturation): MotionForceTask.cpp:411-468 with the host's sigma matrices
+				const double* G = sm.goal;
+				const double* vw = sm.vw;
+				double v[3], w[3], e3[3], tmp[3], oe[3] = {0, 0, 0}, dphi[3];
+				UNR for (int i = 0; i < 3; i++) {
+					v[i] = tk.Ppos[3 * i] * vw[0] + tk.Ppos[3 * i + 1] * vw[1] + tk.Ppos[3 * i + 2] * vw[2];
+					w[i] = tk.Pori[3 * i] * vw[3] + tk.Pori[3 * i + 1] * vw[4] + tk.Pori[3 * i + 2] * vw[5];
+					e3[i] = pw[i] - G[i];
+				}
+				UNR for (int i = 0; i < 3; i++) ip[i] += (tk.sig_p[3 * i] * e3[0] + tk.sig_p[3 * i + 1] * e3[1] + tk.sig_p[3 * i + 2] * e3[2]) * tk.dt;
+				UNR for (int i = 0; i < 3; i++) tmp[i] = G[18 + i] - tk.kp_pos[i] * e3[i] - tk.kv_pos[i] * (v[i] - G[12 + i]) - tk.ki_pos[i] * ip[i];
+				UNR for (int i = 0; i < 3; i++) sm.Fum[i] = tk.sig_p[3 * i] * tmp[0] + tk.sig_p[3 * i + 1] * tmp[1] + tk.sig_p[3 * i + 2] * tmp[2];
+				UNR for (int c = 0; c < 3; c++) {  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+					const double a0 = Rcf[c], a1 = Rcf[3 + c], a2 = Rcf[6 + c], b0 = G[3 + c], b1 = G[6 + c], b2 = G[9 + c];
+					oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+					oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+					oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+				}
+				UNR for (int i = 0; i < 3; i++) dphi[i] = tk.sig_o[3 * i] * oe[0] + tk.sig_o[3 * i + 1] * oe[1] + tk.sig_o[3 * i + 2] * oe[2];
+				UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * tk.dt;
+				UNR for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk.kp_ori[i] * dphi[i] - tk.kv_ori[i] * (w[i] - G[15 + i]) - tk.ki_ori[i] * io[i];
+				UNR for (int i = 0; i < 3; i++) sm.Fum[3 + i] = tk.sig_o[3 * i] * tmp[0] + tk.sig_o[3 * i + 1] * tmp[1] + tk.sig_o[3 * i + 2] * tmp[2];
+				UNR for (int i = 0; i < 6; i++) sm.Ff[i] = 0.0;
+			}
+			if (ovf) sm.flag2 = 1;
+			if (closed)
+				for (int i = 0; i < 6; i++) tk.integ_new[(size_t)(6 + i) * ld + b] = ifm[i];
+			if (track)
+				for (int i = 0; i < 3; i++) {
+					tk.integ_new[(size_t)i * ld + b] = ip[i];
+					tk.integ_new[(size_t)(3 + i) * ld + b] = io[i];
+				}
+		}
+		if (track) commit_lo |= 1u << t;
+		if (tk.cl_force || tk.cl_moment) commit_hi |= 1u << t;
+		wv_sync();
+		if (lane < 8) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
+			double s1 = 0.0, s2 = 0.0;
+			if (lane < k)
+				for (int i = 0; i < 6; i++) {
+					s1 = fma(tk.Bm[i * 6 + lane], sm.Fum[i], s1);
+					s2 = fma(tk.Bm[i * 6 + lane], sm.Ff[i], s2);
+				}
+			sm.f8[t][lane] = s1;
+			sm.ff8[t][lane] = s2;
+		}
+		wv_sync();
+	}
+	WSTAMP(2);
 	// ---------------------------------------------------------------- M(q) in stored form: M_ij = S_min(i,j) . F_max(i,j); identity beyond n
 	double Minv[8][2];
 	{
@@ -221,16 +360,17 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 			}
 		}
 	}
+	WSTAMP(3);
 	{
 		const double mp = wv_sweep<2>(Minv, (n + 3) >> 2, lo, hi);
-		if (!(mp > 0.0)) flagged = true;
+		if (!(mp > 0.0)) flagged = true;  // (wv_sweep returns a scalar-unit value: these branches are scalar)
 		wv_negate(Minv);
 	}
 	wv_sync();
+	WSTAMP(4);
 	// ---------------------------------------------------------------- bounded inertia estimates: clamped entries, K^-1
-	double Em[8][1], Kinv[2][1];
-	int nclamp = 0;
-	UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = 0.0;
+	double Kinv[2][1];
+	int nclamp = 0, myidx = -1;  // column lo of the index matrix E (n x c) selects joint idx[lo]
 	Kinv[0][0] = Kinv[1][0] = 0.0;
 	if (P.any_bie && !flagged) {
 		const double thr = P.bie_thr;
@@ -243,9 +383,9 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 		if (nclamp > 8) {
 			flagged = true;
 		} else if (nclamp > 0) {
-			const int myidx = lo < nclamp ? sm.idx[lo] : -1;  // column lo of E selects joint idx[lo]
+			myidx = lo < nclamp ? sm.idx[lo] : -1;
+			double Em[8][1], ME[8][1], K4[4][1];
 			UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
-			double ME[8][1], K4[4][1];
 			wv_mm<false, false>(Minv, Em, ME);  // M^-1 E (n x c)
 			wv_mm<false, false>(Em, ME, K4);    // E^T M^-1 E (c x c)
 			UNR for (int ks = 0; ks < 4; ks++) {
@@ -261,39 +401,36 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 			Kinv[1][0] = -K4[1][0];
 		}
 	}
+	WSTAMP(5);
 	// ---------------------------------------------------------------- task hierarchy
 	double Np[8][2];
 	UNR for (int ks = 0; ks < 8; ks++)
 		UNR for (int t = 0; t < 2; t++) Np[ks][t] = (4 * ks + hi == 16 * t + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
-	unsigned commit_lo = 0, commit_hi = 0;
+	bool all_full = true;  // every task so far acts with its full rank (motion-force tasks: certified, else flagged; joint tasks: r == m)
 	for (int t = 0; t < P.nt && !flagged; t++) {
 		const TaskDev& tk = P.tasks[t];
 		const bool need_N = t + 1 < P.nt;
 		const bool track = tk.has_ki || P.integ_always;
-		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = tk.goal[(size_t)e * ld + b];
+		WSTAMP(8 + 10 * t);
+		if (tk.type != TASK_MOTION_FORCE)
+			for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = tk.goal[(size_t)e * ld + b];
 		if (tk.decoupling == DEC_BIE && tk.bie_threshold != P.bie_thr) {
 			flagged = true;
 			break;
 		}
 		if (tk.type == TASK_MOTION_FORCE) {
 			const int k = tk.k, bd = tk.body;
-			// control point and frame of the task: the world frame of body `bd` sits in lane bd
-			double Rb[9], ob[3], pw[3], Rcf[9];
-			UNR for (int e = 0; e < 9; e++) Rb[e] = wv_readlane(X[e], bd);
-			UNR for (int e = 0; e < 3; e++) ob[e] = wv_readlane(X[9 + e], bd);
+			// control point of the task (uniform LDS address: a broadcast read)
+			double Rb[9], ob[3], pw[3];
+			UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bd][e];
+			UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bd][9 + e];
 			oct_mat3_vec(Rb, tk.pos, pw);
 			UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
-			UNR for (int r = 0; r < 3; r++)
-				UNR for (int cc = 0; cc < 3; cc++) Rcf[3 * r + cc] = Rb[3 * r] * tk.rot[cc] + Rb[3 * r + 1] * tk.rot[3 + cc] + Rb[3 * r + 2] * tk.rot[6 + cc];
-			if (lane == 0) {
-				UNR for (int e = 0; e < 3; e++) sm.xp[e] = pw[e];
-				UNR for (int e = 0; e < 9; e++) sm.Rc[e] = Rcf[e];
-			}
 			// Jb^T = Jw^T Bm (n x k) in stored form: lane (lo, hi) owns task direction lo of joints 4 ks + hi; column j of
 			// JWorldFrame is (w_j x p + v_j; w_j) for the joints up to the body (MotionForceTask.cpp:262)
 			double bmc[6];
 			UNR for (int i = 0; i < 6; i++) bmc[i] = (lo < k) ? tk.Bm[i * 6 + (lo < 6 ? lo : 0)] : 0.0;
-			double Jbt[8][1], vwp[6] = {0, 0, 0, 0, 0, 0};
+			double Jbt[8][1];
 			UNR for (int ks = 0; ks < 8; ks++) {
 				const int jj = 4 * ks + hi;
 				const double* S = sm.jd[jj];
@@ -301,23 +438,14 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				const double w0 = on ? S[0] : 0.0, w1 = on ? S[1] : 0.0, w2 = on ? S[2] : 0.0;
 				const double c0 = on ? (w1 * pw[2] - w2 * pw[1] + S[3]) : 0.0, c1 = on ? (w2 * pw[0] - w0 * pw[2] + S[4]) : 0.0,
 							 c2 = on ? (w0 * pw[1] - w1 * pw[0] + S[5]) : 0.0;
-				const double dqv = sm.dq[jj];
-				vwp[0] = fma(c0, dqv, vwp[0]);
-				vwp[1] = fma(c1, dqv, vwp[1]);
-				vwp[2] = fma(c2, dqv, vwp[2]);
-				vwp[3] = fma(w0, dqv, vwp[3]);
-				vwp[4] = fma(w1, dqv, vwp[4]);
-				vwp[5] = fma(w2, dqv, vwp[5]);
 				Jbt[ks][0] = fma(w2, bmc[5], fma(w1, bmc[4], fma(w0, bmc[3], fma(c2, bmc[2], fma(c1, bmc[1], c0 * bmc[0])))));
 			}
-			// task-frame velocities use the unprojected Jacobian (MotionForceTask.cpp:293-298): vw = Jw dq
-			UNR for (int e = 0; e < 6; e++) {
-				const double s = wv_hsum(vwp[e]);
-				if (lane == 0) sm.vw[e] = s;
-			}
+			__builtin_amdgcn_sched_barrier(0);
+			WSTAMP(9 + 10 * t);
 			double Jh[2][2], Jht[8][1];
 			wv_mm<false, false>(Jbt, Np, Jh);   // Jh = Jb N_prec (k x n)
 			wv_mm<false, false>(Np, Jbt, Jht);  // Jh^T (n x k)
+			WSTAMP(10 + 10 * t);
 			// singular values of the projected Jacobian (SingularityHandler.cpp:78-121): certificate on G = Jh Jh^T instead of an SVD
 			bool certified;
 			{
@@ -344,12 +472,13 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					Gc[ks][0] = val;
 				}
 				const double mp = wv_sweep<1>(Gc, 2, lo, hi);
-				certified = (mp > 1e-13) && ok_s0 && (tr > 0.0) && !nonfinite;
+				certified = wv_uniform((mp > 1e-13) && ok_s0 && (tr > 0.0) && !nonfinite);
 			}
 			if (!certified) {  // outside the non-singular branch, or too close to call: the general kernel decides (exact eigen-solve)
 				flagged = true;
 				break;
 			}
+			WSTAMP(11 + 10 * t);
 			double T1[2][2], T1t[8][1], A2[2][1], Lam[4][1], Lmod[4][1];
 			wv_mm<false, false>(Jht, Minv, T1);   // Jh M^-1 (k x n)
 			wv_mm<false, false>(Minv, Jht, T1t);  // M^-1 Jh^T (n x k)
@@ -369,6 +498,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				flagged = true;
 				break;
 			}
+			WSTAMP(12 + 10 * t);
 			if (tk.decoupling == DEC_FULL) {
 				UNR for (int ks = 0; ks < 4; ks++) Lmod[ks][0] = Lam[ks][0];
 			} else if (tk.decoupling == DEC_IMPEDANCE) {
@@ -376,7 +506,8 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 			} else if (nclamp == 0) {
 				UNR for (int ks = 0; ks < 4; ks++) Lmod[ks][0] = Lam[ks][0];
 			} else {
-				double Ytt[2][1], Zk[2][1], AB[2][1];
+				double Em[8][1], Ytt[2][1], Zk[2][1], AB[2][1];
+				UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
 				wv_mm<false, false>(Em, T1t, Ytt);    // (T1 E)^T  (c x k)
 				wv_mm<false, false>(Kinv, Ytt, Zk);   // K^-1 (T1 E)^T
 				AB[0][0] = A2[0][0];
@@ -387,47 +518,14 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					break;
 				}
 			}
-			// control law on one lane (MotionForceTask.cpp:286-509), then g = Lambda_mod B^T F_um + B^T F_f (SingularityHandler.cpp:307-309)
-			wv_sync();
-			if (lane == 0) {
-				double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, ifm[6] = {0, 0, 0, 0, 0, 0};
-				if (track)
-					for (int i = 0; i < 3; i++) {
-						ip[i] = tk.integ[(size_t)i * ld + b];
-						io[i] = tk.integ[(size_t)(3 + i) * ld + b];
-					}
-				const bool closed = tk.cl_force || tk.cl_moment;
-				if (closed)
-					for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * ld + b];
-				bool ovf = false;
-				law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, sm.goal, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, ld, &ovf);
-				if (ovf) sm.flag2 = 1;
-				if (closed)
-					for (int i = 0; i < 6; i++) tk.integ_new[(size_t)(6 + i) * ld + b] = ifm[i];
-				if (track)
-					for (int i = 0; i < 3; i++) {
-						tk.integ_new[(size_t)i * ld + b] = ip[i];
-						tk.integ_new[(size_t)(3 + i) * ld + b] = io[i];
-					}
-			}
-			if (track) commit_lo |= 1u << t;
-			if (tk.cl_force || tk.cl_moment) commit_hi |= 1u << t;
-			wv_sync();
-			if (lane < 16) {
-				double s = 0.0, s2 = 0.0;
-				UNR for (int i = 0; i < 6; i++) {
-					s = fma(bmc[i], sm.Fum[i], s);
-					s2 = fma(bmc[i], sm.Ff[i], s2);
-				}
-				sm.f8[lane] = s;  // bmc is zero for lo >= k
-				sm.ff8[lane] = s2;
-			}
+			WSTAMP(13 + 10 * t);
+			// g = Lambda_mod B^T F_um + B^T F_f (SingularityHandler.cpp:307-309); the control law itself ran ahead of the task algebra
 			wv_sync();
 			{
 				double Lm2[2][1] = {{Lmod[0][0]}, {Lmod[1][0]}}, fr[2], y[1];
-				wv_load_rows(sm.f8, hi, fr);
+				wv_load_rows(sm.f8[t], hi, fr);
 				wv_matvec(Lm2, fr, y);
-				if (lane < 16) sm.g8[lane] = y[0] + sm.ff8[lane];
+				if (lane < 16) sm.g8[lane] = (lane < 8) ? y[0] + sm.ff8[t][lane] : 0.0;
 			}
 			wv_sync();
 			{
@@ -440,6 +538,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				}
 			}
 			// computeTorques(tau_prec): the reference's _Lambda is never written => no compensation
+			WSTAMP(14 + 10 * t);
 			if (need_N) {  // N_prec <- N N_prec, N^T = I - Jh^T (Lambda T1)
 				double Lm2[2][1] = {{Lam[0][0]}, {Lam[1][0]}}, Jbart[2][2], Nt[8][2], Np2[8][2];
 				wv_mm<false, false>(Lm2, T1, Jbart);
@@ -451,6 +550,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = Np2[ks][tt];
 			}
 			wv_sync();
+			WSTAMP(15 + 10 * t);
 		} else {
 			// ------------------------------------------------------------ JointTask
 			const int m = tk.m;
@@ -501,6 +601,140 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				sm.va[j] = 0.0;   // a1 = U^T xa, filled by the Gram-Schmidt loop
 				sm.act[j] = 0.0;  // b1 = U^T f
 			}
+			if (tk.s_identity && m == n && all_full && !need_N) {
+				// ---- full joint task (always the last of a hierarchy: RobotController.cpp:33-41) WITHOUT a range basis.  Jp = N_prec and
+				// U Lambda U^T = X^+ with X = N_prec M^-1 N_prec^T, so tau = N_prec^T (X^+ a + X_B^+ f).  range(X) = range(N_prec) is the
+				// common null space of the raw task Jacobians C above (full rank each): for any gamma > 0
+				//     (X + gamma C^T C)^-1 = X^+ + (C^T C)^+ / gamma     and     N_prec^T (C^T C)^+ = 0        (C N_prec = 0),
+				// hence tau = N_prec^T ((X + gamma C^T C)^-1 a + (X_B + gamma C^T C)^-1 f): two SPD sweeps on the matrix cores instead of a pivoted
+				// Gram-Schmidt (n - sum k sequential steps) and the two reduced inverses.  matrixRangeBasis' rank decision (sigma_i / sigma_0 >= 1e-3,
+				// JointTask.cpp:233) is certified instead of computed: N_prec is a projector, so its non-zero singular values are >= 1 and
+				// sigma_0 <= ||N_prec||_F; ||N_prec||_F <= 100 keeps every one of them a factor 10 inside the tolerance (else: general kernel).
+				double fs = 0.0;
+				UNR for (int ks = 0; ks < 8; ks++)
+					UNR for (int tt = 0; tt < 2; tt++) fs = fma(Np[ks][tt], Np[ks][tt], fs);
+				const double fro2 = wv_uniform(wv_wavesum(fs));
+				if (!(fro2 <= 1.0e4)) {
+					flagged = true;
+					break;
+				}
+				double CtC[8][2];
+				UNR for (int ks = 0; ks < 8; ks++)
+					UNR for (int tt = 0; tt < 2; tt++) CtC[ks][tt] = 0.0;
+				for (int u = 0; u < t; u++) {
+					const TaskDev& tu = P.tasks[u];
+					if (tu.type == TASK_MOTION_FORCE) {
+						const int ku = tu.k, bu = tu.body;
+						double Rb[9], ob[3], pw[3], Jb[2][2];  // stored Jb = Bm^T Jw (k x n)
+						UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bu][e];
+						UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bu][9 + e];
+						oct_mat3_vec(Rb, tu.pos, pw);
+						UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
+						double bm[2][6];
+						UNR for (int ks = 0; ks < 2; ks++)
+							UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi < ku) ? tu.Bm[i * 6 + (4 * ks + hi < 6 ? 4 * ks + hi : 0)] : 0.0;
+						UNR for (int tt = 0; tt < 2; tt++) {
+							const int jj = 16 * tt + lo;
+							const double* S = sm.jd[jj];
+							const bool on = jj <= bu;
+							const double w0 = on ? S[0] : 0.0, w1 = on ? S[1] : 0.0, w2 = on ? S[2] : 0.0;
+							const double c0 = on ? (w1 * pw[2] - w2 * pw[1] + S[3]) : 0.0, c1 = on ? (w2 * pw[0] - w0 * pw[2] + S[4]) : 0.0,
+										 c2 = on ? (w0 * pw[1] - w1 * pw[0] + S[5]) : 0.0;
+							UNR for (int ks = 0; ks < 2; ks++)
+								Jb[ks][tt] = fma(w2, bm[ks][5], fma(w1, bm[ks][4], fma(w0, bm[ks][3], fma(c2, bm[ks][2], fma(c1, bm[ks][1], c0 * bm[ks][0])))));
+						}
+						wv_mm<true, false>(Jb, Jb, CtC);  // += Jb^T Jb
+					} else {
+						double Ss[8][2];  // stored S (m x n), full row rank under its N_prec (all_full)
+						UNR for (int ks = 0; ks < 8; ks++)
+							UNR for (int tt = 0; tt < 2; tt++)
+								Ss[ks][tt] = (4 * ks + hi < tu.m && 16 * tt + lo < n) ? tu.S[(4 * ks + hi) * n + 16 * tt + lo] : 0.0;
+						wv_mm<true, false>(Ss, Ss, CtC);  // += S^T S
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				const bool same = tk.decoupling == DEC_FULL || (tk.decoupling == DEC_BIE && nclamp == 0), ident = tk.decoupling == DEC_IMPEDANCE;
+				double Xm[8][2], Ztt[2][2];
+				{
+					double NpT[8][2], Rm[8][2];  // stored N_prec^T through the LDS image, then M^-1 N_prec^T
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] = Np[ks][tt];
+					wv_sync();
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) NpT[ks][tt] = sm.img[(16 * tt + lo) * LDI + 4 * ks + hi];
+					wv_mm<false, false>(Minv, NpT, Rm);
+					wv_mm<false, false>(NpT, Rm, Xm);  // X = N_prec M^-1 N_prec^T
+					if (!same && !ident) {
+						double Em[8][1];
+						UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
+						wv_mm<false, false>(Em, Rm, Ztt);  // (N_prec M^-1 E)^T (c x n)
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				double dx = 0.0, dc = 0.0;
+				UNR for (int ks = 0; ks < 8; ks++)
+					UNR for (int tt = 0; tt < 2; tt++)
+						if (4 * ks + hi == 16 * tt + lo) {
+							dx += Xm[ks][tt];
+							dc += CtC[ks][tt];
+						}
+				const double trX = wv_uniform(wv_wavesum(dx)), trC = wv_uniform(wv_wavesum(dc));
+				const double gam = trC > 0.0 ? trX / trC : 0.0;
+				const int nbn = (n + 3) >> 2;
+				double zr[8], y2[2], zsum[2] = {0.0, 0.0};
+				if (ident) {  // Lambda_mod = I on the range: U U^T f = X^+ X f restricted... the identity acts in range coordinates: U U^T f
+					// U U^T = X X^+: (X + gamma C^T C)^-1 X f  (the C part annihilates X's range complement)
+					flagged = true;  // (impedance-type posture tasks keep the Gram-Schmidt path of the general kernel)
+					break;
+				}
+				if (!same) {  // X_B = X - Z K^-1 Z^T (bounded inertia estimates), then (X_B + gamma C^T C)^-1 f
+					double XB[8][2], Zk[2][2];
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) XB[ks][tt] = fma(gam, CtC[ks][tt], Xm[ks][tt]);
+					wv_mm<false, false>(Kinv, Ztt, Zk);
+					wv_mm<true, true>(Ztt, Zk, XB);
+					wv_pad_identity(XB, n, 4 * nbn, lo, hi);
+					const double mp = wv_sweep<2>(XB, nbn, lo, hi);
+					if (!(mp > 0.0)) flagged = true;
+					wv_load_rows(sm.vb, hi, zr);
+					wv_matvec(XB, zr, y2);
+					zsum[0] -= y2[0];
+					zsum[1] -= y2[1];
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				UNR for (int ks = 0; ks < 8; ks++)
+					UNR for (int tt = 0; tt < 2; tt++) Xm[ks][tt] = fma(gam, CtC[ks][tt], Xm[ks][tt]);
+				wv_pad_identity(Xm, n, 4 * nbn, lo, hi);
+				{
+					const double mp = wv_sweep<2>(Xm, nbn, lo, hi);
+					if (!(mp > 0.0)) flagged = true;
+				}
+				if (flagged) break;
+				wv_load_rows(sm.vc, hi, zr);
+				if (same) {
+					double fr8[8];
+					wv_load_rows(sm.vb, hi, fr8);
+					UNR for (int ks = 0; ks < 8; ks++) zr[ks] += fr8[ks];
+				}
+				wv_matvec(Xm, zr, y2);  // (the sweep leaves -inverse)
+				zsum[0] -= y2[0];
+				zsum[1] -= y2[1];
+				wv_sync();
+				if (hi == 0) {
+					sm.vd[lo] = zsum[0];
+					sm.vd[16 + lo] = zsum[1];
+				}
+				wv_sync();
+				wv_load_rows(sm.vd, hi, zr);
+				wv_matvec(Np, zr, y2);  // tau += N_prec^T z
+				if (hi == 0) {
+					sm.tau[lo] += y2[0];
+					sm.tau[16 + lo] += y2[1];
+				}
+				wv_sync();
+				WSTAMP(13 + 10 * t);
+				continue;
+			}
 			// Jp = S N_prec (JointTask.cpp:231)
 			double Wc[8][2];
 			if (tk.s_identity) {
@@ -516,11 +750,9 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				wv_mm<false, false>(St, Np, Wc);
 			}
 			wv_sync();
+			WSTAMP(9 + 10 * t);
 			// matrixRangeBasis(Jp) (JointTask.cpp:233): column-pivoted Gram-Schmidt, accepted only on a clean rank gap (next pivot below
 			// 1e-10 or above 1e-2 of the first); row s of U^T Jp goes to the LDS image, U^T xa / U^T f are taken on the fly
-			double xar[8], xbr[8];
-			wv_load_rows(sm.vc, hi, xar);
-			wv_load_rows(sm.vb, hi, xbr);
 			const int rb = P.rank_bound[t] < m ? P.rank_bound[t] : m;
 			bool need_exact = false, going = true;
 			int rank = 0;
@@ -538,8 +770,9 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					jb = 16 + lo;
 				}
 				wv_row_argmax(best, jb);
+				best = wv_uniform(best);
 				if (s == 0) {
-					const double frob2 = wv_rowsum(nr[0] + nr[1]);
+					const double frob2 = wv_uniform(wv_rowsum(nr[0] + nr[1]));
 					c0 = best;
 					if (frob2 < 1e-6) going = false;  // ||Jp||_F < 1e-3: empty range
 					else if (best < 1e-5 || rb == 0) {
@@ -567,8 +800,8 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					d[tt] = wv_hsum(acc);
 				}
 				UNR for (int ks = 0; ks < 8; ks++) {
-					pa = fma(u[ks], xar[ks], pa);
-					pb = fma(u[ks], xbr[ks], pb);
+					pa = fma(u[ks], sm.vc[4 * ks + hi], pa);
+					pb = fma(u[ks], sm.vb[4 * ks + hi], pb);
 				}
 				pa = wv_hsum(pa);
 				pb = wv_hsum(pb);
@@ -596,48 +829,57 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 				break;
 			}
 			const int r = rank;
+			if (r != m) all_full = false;
 			wv_sync();
+			WSTAMP(10 + 10 * t);
 			if (r > 0) {
-				double Jh[8][2], Jht[8][2];
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) {
-						const int rowi = 4 * ks + hi, coli = 16 * tt + lo;
-						Jh[ks][tt] = rowi < r ? sm.img[rowi * LDI + coli] : 0.0;   // U^T Jp (r x n)
-						Jht[ks][tt] = coli < r ? sm.img[coli * LDI + rowi] : 0.0;  // its transpose (n x r)
-					}
+				// both operand forms of U^T Jp come from the LDS image whenever they are needed: no more than five 32 x 32 matrices are
+				// ever live (M^-1, N_prec and three of this block's)
+				auto load_Jh = [&](double (&Jh)[8][2]) {
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) Jh[ks][tt] = (4 * ks + hi) < r ? sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] : 0.0;  // U^T Jp (r x n)
+				};
+				auto load_Jht = [&](double (&Jht)[8][2]) {
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) Jht[ks][tt] = (16 * tt + lo) < r ? sm.img[(16 * tt + lo) * LDI + 4 * ks + hi] : 0.0;  // its transpose (n x r)
+				};
 				const int nb = (r + 3) >> 2;
-				double T1t[8][2], A[8][2];
-				wv_mm<false, false>(Minv, Jht, T1t);  // M^-1 Jh^T (n x r)
-				wv_mm<false, false>(T1t, Jht, A);     // Jh M^-1 Jh^T
+				const bool same = tk.decoupling == DEC_FULL || (tk.decoupling == DEC_BIE && nclamp == 0), ident = tk.decoupling == DEC_IMPEDANCE;
+				double A[8][2], Ytt[2][2];
+				{
+					double Jht[8][2], T1t[8][2];
+					load_Jht(Jht);
+					wv_mm<false, false>(Minv, Jht, T1t);  // M^-1 Jh^T (n x r)
+					wv_mm<false, false>(T1t, Jht, A);     // Jh M^-1 Jh^T
+					if (!same && !ident) {
+						double Em[8][1];
+						UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
+						wv_mm<false, false>(Em, T1t, Ytt);  // (T1 E)^T (c x r)
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				WSTAMP(11 + 10 * t);
 				// Lambda_mod (JointTask.cpp:253-267) first: its action on b1 = U^T f, then Lambda itself in place
 				double ymod[2];
 				{
-					double LM[8][2];
-					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) LM[ks][tt] = A[ks][tt];
-					bool ident = false, same = false;
-					if (tk.decoupling == DEC_FULL || (tk.decoupling == DEC_BIE && nclamp == 0)) same = true;
-					else if (tk.decoupling == DEC_IMPEDANCE) ident = true;
-					else {
-						double Ytt[2][2], Zk[2][2];
-						wv_mm<false, false>(Em, T1t, Ytt);   // (T1 E)^T (c x r)
-						wv_mm<false, false>(Kinv, Ytt, Zk);  // K^-1 (T1 E)^T
-						wv_mm<true, true>(Ytt, Zk, LM);      // A - (T1 E) K^-1 (T1 E)^T
-					}
 					double b1r[8];
 					wv_load_rows(sm.act, hi, b1r);
 					if (ident) {
 						ymod[0] = sm.act[lo];
 						ymod[1] = sm.act[16 + lo];
-					} else {
-						if (!same) {
-							wv_pad_identity(LM, r, 4 * nb, lo, hi);
-							const double mp = wv_sweep<2>(LM, nb, lo, hi);
-							if (!(mp > 0.0)) flagged = true;
-							wv_negate(LM);
-							wv_matvec(LM, b1r, ymod);
-						}
+					} else if (!same) {
+						double LM[8][2], Zk[2][2];
+						UNR for (int ks = 0; ks < 8; ks++)
+							UNR for (int tt = 0; tt < 2; tt++) LM[ks][tt] = A[ks][tt];
+						wv_mm<false, false>(Kinv, Ytt, Zk);  // K^-1 (T1 E)^T
+						wv_mm<true, true>(Ytt, Zk, LM);      // A - (T1 E) K^-1 (T1 E)^T
+						wv_pad_identity(LM, r, 4 * nb, lo, hi);
+						const double mp = wv_sweep<2>(LM, nb, lo, hi);
+						if (!(mp > 0.0)) flagged = true;
+						wv_negate(LM);
+						wv_matvec(LM, b1r, ymod);
 					}
+					__builtin_amdgcn_sched_barrier(0);
 					wv_pad_identity(A, r, 4 * nb, lo, hi);
 					const double mp = wv_sweep<2>(A, nb, lo, hi);
 					if (!(mp > 0.0)) flagged = true;
@@ -645,6 +887,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					if (same) wv_matvec(A, b1r, ymod);
 				}
 				if (flagged) break;
+				WSTAMP(12 + 10 * t);
 				{
 					double a1r[8], y[2];
 					wv_load_rows(sm.va, hi, a1r);
@@ -655,8 +898,9 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 					}
 				}
 				wv_sync();
-				{
-					double gr[8], y[2];
+				if (!need_N) {
+					double Jh[8][2], gr[8], y[2];
+					load_Jh(Jh);
 					wv_load_rows(sm.vd, hi, gr);
 					wv_matvec(Jh, gr, y);  // tau += Jh^T g
 					if (hi == 0) {
@@ -664,16 +908,32 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 						sm.tau[16 + lo] += y[1];
 					}
 				}
+				WSTAMP(13 + 10 * t);
 				if (need_N) {
-					double T1[8][2], Jbart[8][2], Nt[8][2], Np2[8][2];
-					wv_mm<false, false>(Jht, Minv, T1);   // Jh M^-1 (r x n)
-					wv_mm<false, false>(A, T1, Jbart);    // Lambda T1
+					double Jbart[8][2];
+					{
+						double Jht[8][2], T1[8][2];
+						load_Jht(Jht);
+						wv_mm<false, false>(Jht, Minv, T1);  // Jh M^-1 (r x n)
+						wv_mm<false, false>(A, T1, Jbart);   // Lambda T1
+					}
+					__builtin_amdgcn_sched_barrier(0);
+					double Jh[8][2], Nt[8][2], gr[8], y[2];
+					load_Jh(Jh);
+					wv_load_rows(sm.vd, hi, gr);
+					wv_matvec(Jh, gr, y);  // tau += Jh^T g
+					if (hi == 0) {
+						sm.tau[lo] += y[0];
+						sm.tau[16 + lo] += y[1];
+					}
 					UNR for (int ks = 0; ks < 8; ks++)
 						UNR for (int tt = 0; tt < 2; tt++) {
 							Nt[ks][tt] = (4 * ks + hi == 16 * tt + lo) ? 1.0 : 0.0;
 							if (4 * ks + hi >= r) Jbart[ks][tt] = 0.0;  // the identity padding of Lambda is not part of it
 						}
 					wv_mm<true, true>(Jh, Jbart, Nt);
+					__builtin_amdgcn_sched_barrier(0);
+					double Np2[8][2];
 					wv_mm<false, false>(Nt, Np, Np2);
 					UNR for (int ks = 0; ks < 8; ks++)
 						UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = Np2[ks][tt];
@@ -684,6 +944,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 		}
 	}
 	wv_sync();
+	WSTAMP(60);
 	// ---------------------------------------------------------------- post-processing, RobotController.cpp:86-116
 	double tv = sm.tau[j];
 	if (P.torque_sat && jv) {
@@ -743,6 +1004,7 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 			if (slot < P.B) P.flag_list[slot] = b;
 		}
 	}
+	WSTAMP(61);
 	if (P.flag_list && b == 0 && lane == 0) *P.flag_count_next = 0;  // the other list: its last readers finished a cycle ago
 	if (!flagged) {  // integrators: commit what the control laws advanced them to (a flagged instance advances nothing)
 		for (int t = 0; t < P.nt; t++) {
@@ -756,6 +1018,11 @@ __global__ void __launch_bounds__(64, 2) saip_cycle_wave(const CycleParams P) {
 	}
 }
 
+#if defined(SAIP_STAMP_WAVE)
+extern "C" int saip_debug_stamps_wave(unsigned long long* out) {
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_wave), sizeof(unsigned long long) * 256 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 hipError_t launch_cycle_wave(const CycleParams& P, hipStream_t stream) {
 	hipLaunchKernelGGL(saip_cycle_wave, dim3(P.B), dim3(64), 0, stream, P);
 	return hipGetLastError();

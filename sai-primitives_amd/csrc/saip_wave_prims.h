@@ -88,6 +88,15 @@ __device__ __forceinline__ void wv_row_argmax(double& best, int& jb) {
 	WV_ARGMAX_STEP(1)
 }
 
+// A value every lane holds identically, re-read through the scalar unit: tells the compiler it is wave-uniform, so that the branches it
+// feeds become scalar branches instead of EXEC-masked regions (an instance's whole control flow is uniform: one wavefront, one instance)
+__device__ __forceinline__ double wv_uniform(const double x) {
+	const int l = __builtin_amdgcn_readfirstlane(__double2loint(x));
+	const int h = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+	return __hiloint2double(h, l);
+}
+__device__ __forceinline__ bool wv_uniform(const bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
 __device__ __forceinline__ double wv_readlane(const double x, const int src) {  // src wave-uniform
 	const int l = __builtin_amdgcn_readlane(__double2loint(x), src);
 	const int h = __builtin_amdgcn_readlane(__double2hiint(x), src);
@@ -153,7 +162,7 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 			UNR for (int i = 0; i < 4; i++)
 				UNR for (int j2 = 0; j2 <= i; j2++) L[i][j2] = wv_readlane(P[t0], (rho + j2) + 16 * i);
 			UNR for (int k = 0; k < 4; k++) {
-				minpiv = fmin(minpiv, L[k][k]);
+				minpiv = (L[k][k] < minpiv || L[k][k] != L[k][k]) ? L[k][k] : minpiv;  // (a NaN pivot sticks: every later comparison with it is false)
 				const double rs = oct_rsqrt(L[k][k]);
 				dinv[k] = rs;
 				UNR for (int i = k + 1; i < 4; i++) L[i][k] *= rs;
@@ -187,7 +196,7 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 			v[kb][t0] = inblk ? -dl : v[kb][t0];
 		}
 	}
-	return minpiv;
+	return wv_uniform(minpiv);
 }
 
 template <int KS, int T>
