@@ -2,8 +2,10 @@
 """Headline benchmark: control-cycles/sec for BASELINE.json configs[1]
 (4096 x Panda 7-DoF, full MotionForceTask + full JointTask in its nullspace) per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts the N ranks itself, see _spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 2 --dry-run                     (no GPU: ranks, shards and the gather shapes rehearsed over gloo)
+    python bench.py --config 4 --gpus 8                    (BASELINE config 4: 65536 instances = 8192 per GPU)
 
 One "step" = one control cycle (updateModel + updateControllerTaskModels + computeControlTorques) of every instance of
 the rank's batch = one launch of the cycle kernel, inputs already resident in HBM.  Weak scaling: every rank owns
@@ -55,18 +57,94 @@ def cpu_baseline(d, seconds_target=12.0):
             "single_thread_value": B * r1 / dt1}
 
 
+def _spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here -- fresh child processes, one per GPU, with
+    the environment torch.distributed.run would give them -- BEFORE anything in this process touches a GPU (the parent never does).
+    Rank 0's stdout (the JSON line) is passed through; the exit code is the worst of the ranks'."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out.decode().splitlines():   # stdout carries the JSON line only; anything else a library printed there goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal of the N-rank run (no GPU, no kernel): every rank builds the configuration-only controller of its shard, the ranks
+    rendezvous over gloo, gather slabs of the real shape [dof][ld] and check them; rank 0 prints the line with n_gpus = the number of ranks
+    the process group counts.  tests/test_bench_cli.py runs it with 2 ranks."""
+    import numpy as np
+    import torch
+    import workloads as W
+    from sai_primitives_amd import sharding
+    from sai_primitives_amd.controller import controller_from_specs
+    if world > 1:
+        sharding.init_process_group("gloo")
+    import torch.distributed as dist
+    B = args.batch
+    model = W.load_robot(W.CONFIGS[args.config]["robot"])
+    tasks = W.config_tasks(args.config)
+    ld = sharding.shard_ld(B * world, world)
+    robot, ctrl, _ = controller_from_specs(model.name, tasks, B, device=-1, leading_dimension=ld)   # host logic only: the engine has no CPU path
+    n = robot.dof()
+    assert ctrl.devicePointers()["ld"] == ld
+    slab = torch.full((n, ld), float(rank + 1), dtype=torch.float64)
+    got = sharding.gather_torques(slab, world, out=sharding.gather_buffer(slab, world))
+    ok = all(bool((got[r] == r + 1).all()) for r in range(world))
+    counted = dist.get_world_size() if world > 1 else 1
+    ok = ok and counted == args.gpus
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if counted != args.gpus:
+            raise SystemExit(f"bench: --gpus {args.gpus} but the process group counts {counted} ranks")
+        print(json.dumps({
+            "metric": f"control-cycles/sec (whole node), {n}-DoF {len(tasks)}-task hierarchy, batch={B}", "value": None, "unit": "control-cycles/s",
+            "n_gpus": counted, "dry_run": True, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {W.CONFIGS[args.config]['desc']}", "batch_per_gpu": B, "global_batch": B * world,
+                       "shards": [[r * B, (r + 1) * B] for r in range(world)], "gather_shape": [world, n, ld],
+                       "parallelism": f"instances sharded x{world}, no data-path collective, one final torque all_gather", "gather": "gloo (dry run)"},
+            "valid": ok}))
+    if not ok:
+        raise SystemExit("bench --dry-run: gather check failed")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (config 2: 4096)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the configuration's: 4096 for configs 2, 3, 5; 8192 = 65536 / 8 for config 4)")
     ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse ranks, shards and gather shapes over gloo")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general workgroup-per-instance, 2 lane-per-instance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic", type=float, default=None, help="measured HBM bytes per launch (from a separate rocprofv3 --pmc pass); "
                     "default: the committed PMC summary profiles/pmc_traffic.json when it matches kernel/config/batch")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process only starts the ranks (it must not touch a GPU itself: the ranks are fresh processes)
+        if not args.dry_run:
+            import torch
+            have = torch.cuda.device_count()   # (does not initialise the GPU)
+            if have < args.gpus:
+                raise SystemExit(f"bench: --gpus {args.gpus} but only {have} GPU(s) are visible; no line is printed for a run that is not the one asked for")
+        sys.exit(_spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -76,8 +154,12 @@ def main():
     from sai_primitives_amd.controller import controller_from_specs
 
     rank, local_rank, world = sharding.dist_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.batch is None:
+        args.batch = 8192 if args.config == 4 else W.CONFIGS[args.config]["batch"]
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -116,6 +198,10 @@ def main():
                 native.close()
             native = None
         gather_kind = "engine: ncclAllGather (RCCL) on the engine stream" if native is not None else "torch.distributed all_gather_into_tensor (RCCL)"
+    # n_gpus is what the communicator itself counts (ncclCommCount of the engine's communicator, else the process group's size), never --gpus
+    counted = native.world() if native is not None else (dist.get_world_size() if world > 1 else 1)
+    if counted != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but the communicator counts {counted} ranks: no line is printed")
 
     def final_gather():
         if native is not None:
@@ -145,7 +231,7 @@ def main():
 
     # correctness of what was timed: finite torques, no flagged instance, gather holds this rank's slab
     tau = ctrl.getTorques()
-    ok = bool(np.isfinite(tau).all() and (ctrl.status & 1).sum() == 0)  # bit 0 = flagged (NaN torques); bits 1..3 are informational (truncated / POPC window / blended)
+    ok = bool(np.isfinite(tau).all() and (ctrl.status & 1).sum() == 0)  # bit 0 = flagged (torques held or NaN by policy); bits 1..3 are informational (truncated / POPC window / blended)
     ok = ok and bool(torch.equal(gathered[rank], tau_t))
     # cross-check of the timed kernel against the engine's other, independently written kernel (general workgroup-per-instance
     # path) on the same resident inputs: catches a wrong-but-finite result without touching the oracle
@@ -188,7 +274,7 @@ def main():
         ach_gbs = byts * B / launch_s / 1e9
         out = {
             "metric": f"control-cycles/sec (whole node), {n}-DoF {len(d['tasks'])}-task hierarchy, batch={B}",
-            "value": value, "value_event_timed": B * world * args.steps / (ev_ms * 1e-3), "unit": "control-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_event_timed": B * world * args.steps / (ev_ms * 1e-3), "unit": "control-cycles/s", "n_gpus": counted, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {W.CONFIGS[args.config]['desc']}", "batch_per_gpu": B,

@@ -96,6 +96,9 @@ saip_status saip_batch_create(const saip_model* model, int batch_size, int devic
 void saip_batch_destroy(saip_batch* batch);
 int saip_batch_size(const saip_batch* batch);
 int saip_batch_ld(const saip_batch* batch); /* leading dimension (instances) of device SoA arrays */
+/* before saip_batch_finalize: a larger leading dimension than the default (B rounded up to 32; must stay a multiple of 32).  The shards of a
+ * sharded run that differ by one instance take the largest shard's, so that the final all-gather moves slabs of one shape. */
+saip_status saip_batch_set_leading_dimension(saip_batch* batch, int ld);
 int saip_batch_dof(const saip_batch* batch);
 
 /* MotionForceTask constructors, MotionForceTask.h:96-110 / MotionForceTask.cpp:16-89.
@@ -307,7 +310,9 @@ saip_status saip_batch_get_task_nullspace_host(saip_batch*, int task, double* N 
  * RobotController's post-processing.  tau_prec = NULL is computeTorques(); otherwise the joint task subtracts its disturbance
  * compensation (JointTask.cpp:285-292) and the motion-force task adds nothing (its _Lambda is never written, MotionForceTask.cpp:140,273).
  * compute_torques after a state change without a new update_model is SAIP_ERR_ORDER (the reference would mix a fresh Jacobian with
- * stale Lambda / N_prec, MotionForceTask.cpp:280-283).  status: per-instance codes as for the whole cycle (torques NaN where 1). */
+ * stale Lambda / N_prec, MotionForceTask.cpp:280-283).  status: per-instance codes as for the whole cycle; where it is 1 the task's
+ * torques follow saip_batch_set_flagged_torque_policy like the controller's (default: left as they were -- zero before the first valid
+ * call --, 1: NaN): check the status, not isnan. */
 saip_status saip_batch_task_update_model(saip_batch*, int task, const double* N_prec_host /* NULL = identity */);
 saip_status saip_batch_task_update_model_device(saip_batch*, int task, const double* N_prec_dev /* NULL = identity; asynchronous */);
 saip_status saip_batch_task_compute_torques(saip_batch*, int task, const double* tau_prec_host /*[dof][B] or NULL*/, double* tau_host /*[dof][B]*/, uint8_t* status_host /*[B] or NULL*/);
@@ -341,11 +346,15 @@ saip_status saip_batch_time_steps(saip_batch*, int steps, int warmup, double* el
  *     communicator; saip_batch_all_gather_torques enqueues the all-gather on the batch's stream: gathered_dev = [world][dof][ld]. */
 #define SAIP_COMM_ID_BYTES 128
 typedef struct saip_comm saip_comm;
+/* can this process join a communicator on `device` (librccl loads, the device can be selected)?  Ask on EVERY rank and reduce the answers
+ * before any rank calls saip_comm_create: a rank that fails locally would leave the others blocked inside ncclCommInitRank. */
+saip_status saip_comm_probe(int device);
 saip_status saip_comm_unique_id(void* id128);
 saip_status saip_comm_create(int device, int world, int rank, const void* id128, saip_comm** out);
 void saip_comm_destroy(saip_comm* comm);
-int saip_comm_world(const saip_comm* comm);
+int saip_comm_world(const saip_comm* comm); /* the number of ranks RCCL counts in the communicator (ncclCommCount) */
 int saip_comm_rank(const saip_comm* comm);
+/* every rank's batch must have the same dof and leading dimension (saip_batch_set_leading_dimension for uneven shards) */
 saip_status saip_batch_all_gather_torques(saip_batch* batch, saip_comm* comm, double* gathered_dev);
 /* (b) one process, n devices: one batch + stream + communicator per device.  saip_multi_create makes the (unfinalized) batches -- add the same
  *     tasks to every saip_multi_batch(m, i) -- saip_multi_finalize finalizes them, runs ncclCommInitAll and allocates the gather buffers;

@@ -98,6 +98,7 @@ def lib():
         "saip_batch_destroy": (None, [vp]),
         "saip_batch_size": (C.c_int, [vp]),
         "saip_batch_ld": (C.c_int, [vp]),
+        "saip_batch_set_leading_dimension": (C.c_int, [vp, C.c_int]),
         "saip_batch_add_motion_force_task": (C.c_int, [vp, C.c_char_p, C.c_char_p, dp, dp, dp, C.c_int, dp, C.c_int, C.c_double, ip]),
         "saip_batch_add_joint_task": (C.c_int, [vp, C.c_char_p, dp, C.c_int, C.c_double, ip]),
         "saip_batch_finalize": (C.c_int, [vp]),
@@ -179,6 +180,7 @@ def lib():
         "saip_batch_kernel_name": (C.c_char_p, [vp]),
         "saip_batch_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "saip_batch_dof": (C.c_int, [vp]),
+        "saip_comm_probe": (C.c_int, [C.c_int]),
         "saip_comm_unique_id": (C.c_int, [vp]),
         "saip_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
         "saip_comm_destroy": (None, [vp]),

@@ -14,6 +14,7 @@ per-robot Eigen vector replaced by a (B, size) NumPy array.  Differences from th
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import enum
 import json
 import os
@@ -96,7 +97,10 @@ class SaiModel:
         self._q = np.zeros((self.batch_size, self._n))
         self._dq = np.zeros((self.batch_size, self._n))
         self._controller = None
-        self._controllers = []  # every batch that mirrors this robot's state: the RobotController and the private batches of tasks driven by hand
+        # every batch that mirrors this robot's state: the RobotController and the private batches of tasks driven by hand.  Weak
+        # references: a controller the user dropped must be collectable (its __del__ frees the device batch) and must not keep receiving
+        # the robot's state at every updateModel()
+        self._controllers = weakref.WeakSet()
         self._state_version = 0
 
     def __del__(self):
@@ -129,7 +133,7 @@ class SaiModel:
 
     def updateModel(self):
         """pushes q/dq to the device; kinematics and dynamics are evaluated inside the cycle kernel"""
-        for c in self._controllers:
+        for c in list(self._controllers):
             c._push_state()
 
     def jointLimits(self):
@@ -168,8 +172,15 @@ class _Task:
     def getTaskName(self):
         return self._name
 
+    def _log_call(self, fn_name, args, key=None):
+        """the configuration log replayed into the batch the task joins holds the LAST call per setter (per field for setters that address
+        several): a caller that sets gains every cycle neither grows it nor replays duplicates"""
+        k = (fn_name, key)
+        self._log = [e for e in self._log if e[2] != k]
+        self._log.append((fn_name, args, k))
+
     def _cfg(self, fn_name, *args):
-        self._log.append((fn_name, args))
+        self._log_call(fn_name, args)
         if self._ctrl is not None:
             self._ctrl._call(fn_name, self._id, *args)
 
@@ -418,7 +429,7 @@ class MotionForceTask(_Task):
     def _space(self, fn, dim, axis):
         a = np.ascontiguousarray(np.asarray(axis if axis is not None else (0.0, 0.0, 0.0), float).reshape(3))
         self._keepalive.append(a)
-        self._log.append((fn, (int(dim), _dptr(a), None)))
+        self._log_call(fn, (int(dim), _dptr(a), None))
         if self._ctrl is None:
             return None
         ch = C.c_int(0)
@@ -798,7 +809,9 @@ class JointTask(_Task):
 class RobotController:
     """RobotController.h:47-90 for B robots at once."""
 
-    def __init__(self, robot: SaiModel, tasks, _private=False):
+    def __init__(self, robot: SaiModel, tasks, _private=False, leading_dimension=None):
+        """leading_dimension (engine extra): the leading dimension of the device arrays when it must be larger than the batch rounded up
+        to 32 -- the shards of a sharded run all take the largest shard's, so that the final all-gather moves slabs of one shape"""
         L = capi.lib()
         if len(tasks) == 0:  # RobotController.cpp:11-14
             raise ValueError("RobotController must have at least one task")
@@ -810,6 +823,12 @@ class RobotController:
                 raise ValueError(f"task [{t.getTaskName()}] already belongs to a RobotController")
         h = C.c_void_p()
         capi.check(L.saip_batch_create(robot._h, robot.batch_size, robot.device, C.byref(h)))
+        if leading_dimension is not None:
+            try:
+                capi.check(L.saip_batch_set_leading_dimension(h, int(leading_dimension)))
+            except Exception:
+                L.saip_batch_destroy(h)
+                raise
         self._h = h
         self._robot = robot
         self.batch_size = robot.batch_size
@@ -833,14 +852,14 @@ class RobotController:
                 t._ctrl._release()
             t._ctrl = self
             t._manual = False
-            for fn, args in t._log:
+            for fn, args, _key in t._log:
                 self._call(fn, t._id, *args)
             if goal is not None:
                 a = np.ascontiguousarray(goal.T)
                 capi.check(L.saip_batch_set_goal_host(h, t._id, _dptr(a)))
         if not _private:
             robot._controller = self
-        robot._controllers.append(self)
+        robot._controllers.add(self)
         self._pushed_version = -1
         self._has_device = robot.device >= 0
 
@@ -851,8 +870,7 @@ class RobotController:
 
     def _release(self):
         """a private one-task batch whose task joins a RobotController"""
-        if self in self._robot._controllers:
-            self._robot._controllers.remove(self)
+        self._robot._controllers.discard(self)
         self.__del__()
 
     def _call(self, fn_name, *args):
@@ -873,7 +891,8 @@ class RobotController:
             t._manual = False
 
     def computeControlTorques(self):
-        """returns (B, dof) joint torques; per-instance status in self.status (0 ok, 1 singular -> NaN row)"""
+        """returns (B, dof) joint torques; per-instance status in self.status (0 ok; bit 0 = refused: that row holds the last valid torques --
+        zero before the first -- or NaN with setFlaggedTorquePolicy(True); check the status, not isnan)"""
         n, B = self._robot.dof(), self.batch_size
         tau = np.empty((n, B))
         st = np.zeros(B, np.uint8)
@@ -999,11 +1018,11 @@ class RobotController:
         self._call("saip_batch_bind_tau_device", C.c_void_p(ptr))
 
 
-def controller_from_specs(description, tasks, batch_size, device=0, *, disable_otg=True):
+def controller_from_specs(description, tasks, batch_size, device=0, *, disable_otg=True, leading_dimension=None):
     """Build (robot, controller, task objects) from workloads.py-style task specs (used by tests and bench)."""
     robot = SaiModel(description, batch_size, device)
     objs = tasks_from_specs(robot, tasks, disable_otg=disable_otg)
-    ctrl = RobotController(robot, objs)
+    ctrl = RobotController(robot, objs, leading_dimension=leading_dimension)
     return robot, ctrl, objs
 
 

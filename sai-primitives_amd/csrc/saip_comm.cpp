@@ -28,19 +28,27 @@ struct Rccl {
 	decltype(&ncclCommInitRank) CommInitRank = nullptr;
 	decltype(&ncclCommInitAll) CommInitAll = nullptr;
 	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;
+	char why[256] = "librccl.so was never looked for";  // dlerror() of the failed load (dlerror itself returns NULL on later calls)
 	decltype(&ncclAllGather) AllGather = nullptr;
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
-Rccl* rccl() {
+Rccl& rccl_state() {
 	static Rccl r;
+	return r;
+}
+Rccl* rccl() {
+	Rccl& r = rccl_state();
 	static bool tried = false;
 	if (!tried) {
 		tried = true;
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
 			r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
 			if (r.lib) break;
+			const char* e = dlerror();
+			snprintf(r.why, sizeof(r.why), "%s", e ? e : "dlopen failed");
 		}
 		if (r.lib) {
 #define SAIP_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
@@ -48,12 +56,16 @@ Rccl* rccl() {
 			SAIP_SYM(CommInitRank, "ncclCommInitRank");
 			SAIP_SYM(CommInitAll, "ncclCommInitAll");
 			SAIP_SYM(CommDestroy, "ncclCommDestroy");
+			SAIP_SYM(CommCount, "ncclCommCount");
 			SAIP_SYM(AllGather, "ncclAllGather");
 			SAIP_SYM(GroupStart, "ncclGroupStart");
 			SAIP_SYM(GroupEnd, "ncclGroupEnd");
 			SAIP_SYM(GetErrorString, "ncclGetErrorString");
 #undef SAIP_SYM
-			if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) r.lib = nullptr;
+			if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.CommCount || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+				r.lib = nullptr;
+				snprintf(r.why, sizeof(r.why), "librccl.so lacks one of the entry points the engine uses");
+			}
 		}
 	}
 	return r.lib ? &r : nullptr;
@@ -76,9 +88,18 @@ struct saip_comm {
 	int device = -1, world = 0, rank = 0;
 };
 
+// can this process take part in a communicator on `device`?  (librccl loads, the device can be selected.)  Every rank asks this BEFORE any
+// rank enters ncclCommInitRank, and the launcher reduces the answers: a rank that failed locally would otherwise leave the others blocked
+// inside the collective initialisation
+extern "C" saip_status saip_comm_probe(int device) {
+	Rccl* R = rccl();
+	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", rccl_state().why);
+	HIP_TRY2(hipSetDevice(device));
+	return SAIP_OK;
+}
 extern "C" saip_status saip_comm_unique_id(void* id128) {
 	Rccl* R = rccl();
-	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", rccl_state().why);
 	if (!id128) return fail_external(SAIP_ERR_INVALID_ARGUMENT, "saip_comm_unique_id: null buffer");
 	static_assert(sizeof(ncclUniqueId) == SAIP_COMM_ID_BYTES, "unique id size");
 	RCCL_TRY(R, R->GetUniqueId((ncclUniqueId*)id128));
@@ -86,7 +107,7 @@ extern "C" saip_status saip_comm_unique_id(void* id128) {
 }
 extern "C" saip_status saip_comm_create(int device, int world, int rank, const void* id128, saip_comm** out) {
 	Rccl* R = rccl();
-	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", rccl_state().why);
 	if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail_external(SAIP_ERR_INVALID_ARGUMENT, "saip_comm_create: bad arguments");
 	HIP_TRY2(hipSetDevice(device));
 	ncclUniqueId id;
@@ -109,13 +130,19 @@ extern "C" void saip_comm_destroy(saip_comm* c) {
 		if (c->comm) (void)R->CommDestroy(c->comm);
 	delete c;
 }
-extern "C" int saip_comm_world(const saip_comm* c) { return c ? c->world : 0; }
+// number of ranks RCCL itself counts in the communicator (ncclCommCount), not what the caller asked for
+extern "C" int saip_comm_world(const saip_comm* c) {
+	Rccl* R = rccl();
+	if (!c || !R || !c->comm) return 0;
+	int n = 0;
+	return R->CommCount(c->comm, &n) == ncclSuccess ? n : 0;
+}
 extern "C" int saip_comm_rank(const saip_comm* c) { return c ? c->rank : -1; }
 
 // the final torque gather: [dof][ld] of this rank -> gathered_dev [world][dof][ld] on every rank, asynchronously on the batch's stream
 extern "C" saip_status saip_batch_all_gather_torques(saip_batch* b, saip_comm* c, double* gathered_dev) {
 	Rccl* R = rccl();
-	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded");
+	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", rccl_state().why);
 	if (!b || !c || !gathered_dev) return fail_external(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_all_gather_torques: null argument");
 	double* tau = saip_batch_device_tau(b);
 	hipStream_t stream = (hipStream_t)saip_batch_stream(b);
@@ -157,7 +184,7 @@ extern "C" saip_status saip_multi_finalize(saip_multi* m) {
 	if (!m) return fail_external(SAIP_ERR_INVALID_ARGUMENT, "null multi");
 	if (m->finalized) return SAIP_OK;
 	Rccl* R = rccl();
-	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+	if (!R) return fail_external(SAIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", rccl_state().why);
 	for (saip_batch* b : m->batches) {
 		saip_status st = saip_batch_finalize(b);
 		if (st) return st;

@@ -406,6 +406,15 @@ extern "C" saip_status saip_batch_create(const saip_model* model, int batch_size
 	*out = b;
 	return SAIP_OK;
 }
+// leading dimension of the device arrays (default: B rounded up to 32).  Shards of a sharded run that differ by an instance all take the
+// ld of the largest one, so that the final all-gather moves slabs of one shape (sharding.shard_ld)
+extern "C" saip_status saip_batch_set_leading_dimension(saip_batch* b, int ld) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	if (b->finalized) return fail(SAIP_ERR_ORDER, "the leading dimension is fixed by saip_batch_finalize");
+	if (ld < b->B || ld % 32 != 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "leading dimension %d: must be a multiple of 32 and at least the batch size %d", ld, b->B);
+	b->ld = ld;
+	return SAIP_OK;
+}
 extern "C" void saip_batch_destroy(saip_batch* b) {
 	if (!b) return;
 	if (has_device(b)) {
@@ -1850,14 +1859,19 @@ extern "C" saip_status saip_batch_rollout_async(saip_batch* b, int steps, double
 		b->sim_done = false;
 		saip_status s2 = launch_cycle(b, false);
 		b->sim_want = 0;
-		if (s2) return s2;
+		if (s2) {
+			b->otg_prelaunched = false;  // a failed period must not leave the next standalone cycle believing its OTG step has already run
+			return s2;
+		}
 		if (b->sim_done) {  // the bookkeeping of enqueue_integrate
 			b->sim_done = false;
 			b->models_valid = false;
 			b->state_epoch++;
 			return SAIP_OK;
 		}
-		return enqueue_integrate(b, sim_dt, substeps, gravity, damping, more);
+		s2 = enqueue_integrate(b, sim_dt, substeps, gravity, damping, more);
+		if (s2) b->otg_prelaunched = false;
+		return s2;
 	};
 	static const bool use_graph = getenv("SAIP_ROLLOUT_GRAPH") != nullptr;
 	bool cycle_dependent = false;  // the device-side slow path and the blended singularity strategies read per-cycle launch parameters

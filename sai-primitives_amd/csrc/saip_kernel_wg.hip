@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void wg_cycle(const CycleParams& P, const int b, WgSm
 
 	if (P.single_task >= 0) {
 		// TemplateTask::computeTorques[(tau_prec)]: this task's torques alone (sm.tau started from tau_prec: it feeds the joint task's
-		// disturbance compensation, JointTask.cpp:285-292); none of RobotController's post-processing.  A flagged instance reports NaN.
+		// disturbance compensation, JointTask.cpp:285-292); none of RobotController's post-processing.  A flagged instance follows the flagged-torque policy (held or NaN).
 		const double nanv = __builtin_nan("");
 		if (tid < n && do_law) {
 			const double tp = P.ext_tau_prec ? P.ext_tau_prec[(size_t)tid * P.ld + b] : 0.0;

@@ -44,7 +44,12 @@ def gather_torques(tau_local, world: int, out=None):
     have the same shape: ranks with uneven shards pad to common_ld(total, world) (see shard_ld)."""
     import torch.distributed as dist
     if world == 1:
-        return tau_local.unsqueeze(0)  # a gather over one rank is the identity: the engine already wrote the slab, nothing to move
+        # a gather over one rank is the identity: the engine already wrote the slab, nothing to move.  The result ALIASES tau_local (it
+        # changes with the next cycle) unless an `out` buffer is given, which then receives a copy like on several ranks
+        if out is not None:
+            out[0].copy_(tau_local)
+            return out
+        return tau_local.unsqueeze(0)
     if out is None:
         out = gather_buffer(tau_local, world)
     dist.all_gather_into_tensor(out.view((-1,) + tuple(tau_local.shape[1:])), tau_local.contiguous())  # concat along dim 0
@@ -53,7 +58,11 @@ def gather_torques(tau_local, world: int, out=None):
 
 class NativeGather:
     """the final torque gather done by the engine itself: C++ on RCCL (csrc/saip_comm.cpp), ncclAllGather on the batch's stream.
-    torch.distributed only carries the 128-byte unique id from rank 0 to the other ranks (the launcher's rendezvous)."""
+    torch.distributed only carries the 128-byte unique id from rank 0 to the other ranks (the launcher's rendezvous).
+    Construction is collective and fails on ALL ranks or on none: every rank first probes what it needs locally (librccl, its device,
+    on rank 0 the unique id) and the answers are reduced before anybody enters ncclCommInitRank -- a rank that failed on its own would
+    otherwise leave the others blocked inside it.  The slabs must have one shape on every rank (same dof, same leading dimension:
+    RobotController(..., leading_dimension=shard_ld(total, world)) for uneven shards); that is checked here as well."""
 
     def __init__(self, ctrl, world: int, rank: int, local_rank: int, device):
         import ctypes as C
@@ -63,23 +72,39 @@ class NativeGather:
         L = capi.lib()
         ident = torch.zeros(128, dtype=torch.uint8)
         err = None
-        if rank == 0:
-            try:
+        try:
+            capi.check(L.saip_comm_probe(int(local_rank)))
+            if rank == 0:
                 buf = (C.c_ubyte * 128)()
                 capi.check(L.saip_comm_unique_id(buf))
                 ident = torch.tensor(list(buf), dtype=torch.uint8)
-            except Exception as e:  # noqa: BLE001  (rank 0 must still take part in the broadcast below, or the other ranks hang in it)
-                err = e
+        except Exception as e:  # noqa: BLE001  (the rank still takes part in the reductions below, or the other ranks hang in them)
+            err = e
+        shape = [float(L.saip_batch_dof(ctrl._h)), float(L.saip_batch_ld(ctrl._h))]
         if world > 1:
-            t = ident.to(device) if dist.get_backend() == "nccl" else ident
+            on_dev = dist.get_backend() == "nccl"
+            flags = torch.tensor([1.0 if err is not None else 0.0, shape[0], shape[1], -shape[0], -shape[1]], dtype=torch.float64)
+            flags = flags.to(device) if on_dev else flags
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            flags = flags.cpu().tolist()
+            if flags[0] != 0.0:
+                raise RuntimeError(f"native RCCL gather unavailable on some rank (this rank: {err})")
+            if flags[1] != -flags[3] or flags[2] != -flags[4]:
+                raise RuntimeError(f"torque slabs differ across ranks (this rank: dof {shape[0]:.0f}, ld {shape[1]:.0f}; largest {flags[1]:.0f}, {flags[2]:.0f}): "
+                                   "give every rank's controller leading_dimension=shard_ld(total, world)")
+            t = ident.to(device) if on_dev else ident
             dist.broadcast(t, src=0)
             ident = t.cpu()
-        if not bool(ident.any()):   # every rank sees the same thing and gives up together
-            raise RuntimeError(f"no RCCL unique id from rank 0 ({err})")
+        elif err is not None:
+            raise RuntimeError(f"native RCCL gather unavailable ({err})")
         buf = (C.c_ubyte * 128)(*ident.tolist())
         self._comm = C.c_void_p()
         capi.check(L.saip_comm_create(int(local_rank), int(world), int(rank), buf, C.byref(self._comm)))
         self._ctrl, self._L = ctrl, L
+
+    def world(self) -> int:
+        """the number of ranks RCCL counts in the communicator (ncclCommCount)"""
+        return int(self._L.saip_comm_world(self._comm))
 
     def gather(self, out):
         """out: torch tensor [world, dof, ld] on this rank's GPU; asynchronous on the engine stream"""

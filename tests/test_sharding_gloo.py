@@ -108,3 +108,24 @@ def test_shard_range_covers_everything_once():
             lo, hi = sharding.shard_range(total, world, r)
             seen += list(range(lo, hi))
         assert seen == list(range(total))
+
+
+def test_uneven_shards_share_one_leading_dimension():
+    """the native gather (saip_batch_all_gather_torques) moves dof * ld doubles per rank: shards that differ by one instance must be created
+    with the largest shard's leading dimension (saip_batch_set_leading_dimension), which NativeGather checks across ranks"""
+    import pytest
+    from sai_primitives_amd import sharding
+    from sai_primitives_amd.controller import controller_from_specs
+    import workloads as W
+    total, world = 4097, 8            # shards of 513 and 512 instances: default ld 544 and 512
+    ld = sharding.shard_ld(total, world)
+    assert ld == 544
+    tasks = W.config_tasks(2)
+    for rank in (0, 7):
+        lo, hi = sharding.shard_range(total, world, rank)
+        _, ctrl, _ = controller_from_specs("panda_arm", tasks, hi - lo, device=-1, leading_dimension=ld)
+        assert ctrl.devicePointers()["ld"] == ld
+    with pytest.raises(ValueError):
+        controller_from_specs("panda_arm", tasks, 513, device=-1, leading_dimension=512)   # smaller than the batch
+    with pytest.raises(ValueError):
+        controller_from_specs("panda_arm", tasks, 513, device=-1, leading_dimension=550)   # not a multiple of 32
