@@ -175,7 +175,11 @@ saip_status saip_batch_set_internal_otg(saip_batch*, int task, int enabled);
  * 0.3 m/s, 2 m/s^2, pi/3 rad/s, 2 pi rad/s^2 (MotionForceTask.h:68-71).
  * Enabling a previously disabled OTG re-initialises it at the current task position / pose on the next cycle. */
 saip_status saip_batch_set_otg_acceleration_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, int count);
-/* JointTask::enableInternalOtgJerkLimited (JointTask.cpp:383-406): third-order Ruckig profiles are not implemented -> SAIP_ERR_UNSUPPORTED */
+/* JointTask::enableInternalOtgJerkLimited(max_velocity, max_acceleration, max_jerk) (JointTask.cpp:383-410; OTG_joints::setMaxJerk,
+ * OTG_joints.cpp:73-86): count = 1 or the task dof.  MotionForceTask::enableInternalOtgJerkLimited (MotionForceTask.cpp:525-545): count = 2,
+ * {linear, angular} each.  Third-order (jerk-limited) Ruckig profiles on the device (csrc/saip_otg3.h: the reference's vendored Ruckig
+ * 0.10.1 position interface, ruckig/src/ruckig/position-third-step{1,2}.cpp); limits must be positive.  The OTG is re-initialised at the
+ * current task position / pose on the next cycle when it was off or acceleration-limited (JointTask.cpp:400-402). */
 saip_status saip_batch_set_otg_jerk_limited(saip_batch*, int task, const double* max_velocity, const double* max_acceleration, const double* max_jerk, int count);
 /* ---- the step after the path: what the reference's examples do with the external simulator,
  * sim->setJointTorques(tau); sim->integrate() (examples/05-using_robot_controller/05-using_robot_controller.cpp:225-231).

@@ -371,8 +371,15 @@ public:
 			return saip_batch_set_otg_acceleration_limited(b, id, v, a, 2);
 		});
 	}
-	void enableInternalOtgJerkLimited(double, double, double, double, double, double) {
-		cfg([](saip_batch* b, int id) { return saip_batch_set_otg_jerk_limited(b, id, nullptr, nullptr, nullptr, 0); });
+	// MotionForceTask::enableInternalOtgJerkLimited, MotionForceTask.cpp:525-545 (argument order of MotionForceTask.h:416-421)
+	void enableInternalOtgJerkLimited(double max_linear_velocity, double max_linear_acceleration, double max_linear_jerk, double max_angular_velocity,
+									  double max_angular_acceleration, double max_angular_jerk) {
+		_otg_enabled = true;
+		cfg([=](saip_batch* b, int id) {
+			const double v[2] = {max_linear_velocity, max_angular_velocity}, a[2] = {max_linear_acceleration, max_angular_acceleration},
+						 j[2] = {max_linear_jerk, max_angular_jerk};
+			return saip_batch_set_otg_jerk_limited(b, id, v, a, j, 2);
+		});
 	}
 	// MotionForceTask::enableVelocitySaturation(linear, angular), MotionForceTask.cpp:771-792
 	void enableVelocitySaturation(double linear_vel_sat = 0.3, double angular_vel_sat = M_PI / 3) {
@@ -477,13 +484,14 @@ public:
 		for (int i = 0; i < n; i++) I[(size_t)i * n + i] = 1.0;
 		return I;
 	}
-	// JointTask.cpp:358-381 (defaults JointTask.h:40-41); the jerk-limited variant throws (not on the device)
+	// JointTask.cpp:358-381 (defaults JointTask.h:40-41); jerk-limited: JointTask.cpp:383-410
 	void enableInternalOtgAccelerationLimited(double max_velocity = M_PI / 3.0, double max_acceleration = 2.0 * M_PI) {
 		_otg_enabled = true;
 		cfg([=](saip_batch* b, int id) { return saip_batch_set_otg_acceleration_limited(b, id, &max_velocity, &max_acceleration, 1); });
 	}
-	void enableInternalOtgJerkLimited(double, double, double) {
-		cfg([](saip_batch* b, int id) { return saip_batch_set_otg_jerk_limited(b, id, nullptr, nullptr, nullptr, 0); });
+	void enableInternalOtgJerkLimited(double max_velocity, double max_acceleration, double max_jerk) {
+		_otg_enabled = true;
+		cfg([=](saip_batch* b, int id) { return saip_batch_set_otg_jerk_limited(b, id, &max_velocity, &max_acceleration, &max_jerk, 1); });
 	}
 	void enableVelocitySaturation(double saturation_velocity = M_PI / 3.0) {  // JointTask.cpp:410-421
 		cfg([=](saip_batch* b, int id) {

@@ -39,6 +39,8 @@ def lib():
         L.otgref_joints_destroy.argtypes = [C.c_void_p]
         L.otgref_joints_reinitialize.argtypes = [C.c_void_p, dp]
         L.otgref_joints_set_limits.argtypes = [C.c_void_p, dp, dp]
+        L.otgref_joints_set_jerk_limits.argtypes = [C.c_void_p, dp, dp, dp]
+        L.otgref_cart_set_jerk_limits.argtypes = [C.c_void_p, dp]
         L.otgref_joints_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, ip]
         L.otgref_joints_finished_with_velocity.argtypes = [C.c_void_p]
         L.otgref_cart_create.restype = C.c_void_p
@@ -81,6 +83,11 @@ class JointsOtgRef:
         am = np.ascontiguousarray(np.broadcast_to(np.asarray(amax, float), (self.n,)))
         lib().otgref_joints_set_limits(self._h, _p(vm), _p(am))
 
+    def set_jerk_limits(self, vmax, amax, jmax):
+        """JointTask::enableInternalOtgJerkLimited's setters (the re-initialisation that may precede them is reinitialize())"""
+        vm, am, jm = (np.ascontiguousarray(np.broadcast_to(np.asarray(x, float), (self.n,))) for x in (vmax, amax, jmax))
+        lib().otgref_joints_set_jerk_limits(self._h, _p(vm), _p(am), _p(jm))
+
     def step(self, goal_pos, goal_vel=None):
         gp = np.ascontiguousarray(goal_pos, float)
         gv = np.zeros(self.n) if goal_vel is None else np.ascontiguousarray(goal_vel, float)
@@ -110,6 +117,12 @@ class CartesianOtgRef:
     def set_limits(self, limits):
         lim = np.ascontiguousarray(limits, float)
         lib().otgref_cart_set_limits(self._h, _p(lim))
+
+    def set_jerk_limits(self, limits6):
+        """(max linear velocity, acceleration, jerk, max angular velocity, acceleration, jerk): MotionForceTask::enableInternalOtgJerkLimited"""
+        lim = np.ascontiguousarray(limits6, float)
+        assert lim.size == 6
+        lib().otgref_cart_set_jerk_limits(self._h, _p(lim))
 
     def reinitialize(self, pos, R, mask=3):
         p, Rm = np.ascontiguousarray(pos, float), np.ascontiguousarray(np.asarray(R).reshape(9), float)

@@ -119,6 +119,17 @@ void otgref_joints_set_limits(void* h, const double* vmax, const double* amax) {
 		o->input.current_acceleration[i] = 0.0;
 	}
 }
+// JointTask::enableInternalOtgJerkLimited (JointTask.cpp:383-410): setMaxVelocity / setMaxAcceleration / setMaxJerk (OTG_joints.cpp:44-86).
+// The re-initialisation at the current position that precedes it when the OTG was off or acceleration-limited (:400-402) is the
+// caller's otgref_joints_reinitialize.
+void otgref_joints_set_jerk_limits(void* h, const double* vmax, const double* amax, const double* jmax) {
+	auto* o = (JointsOtg*)h;
+	for (int i = 0; i < o->dim; i++) {
+		o->input.max_velocity[i] = vmax[i];
+		o->input.max_acceleration[i] = amax[i];
+		o->input.max_jerk[i] = jmax[i];
+	}
+}
 void otgref_joints_destroy(void* h) { delete (JointsOtg*)h; }
 void otgref_joints_reinitialize(void* h, const double* q0) { ((JointsOtg*)h)->reinitialize(q0); }
 
@@ -397,6 +408,16 @@ void otgref_cart_set_limits(void* h, const double* lim) {
 		o->input.max_acceleration[i] = lim[i < 3 ? 1 : 3];
 		o->input.max_jerk[i] = std::numeric_limits<double>::infinity();
 		o->input.current_acceleration[i] = 0.0;  // disableJerkLimits, OTG_6dof_cartesian.h:86-89
+	}
+}
+// MotionForceTask::enableInternalOtgJerkLimited (MotionForceTask.cpp:525-545): lim = {max linear velocity, acceleration, jerk, max angular
+// velocity, acceleration, jerk} (OTG_6dof_cartesian.cpp:86-136); the preceding re-initialisation (:530-532) is the caller's
+void otgref_cart_set_jerk_limits(void* h, const double* lim) {
+	auto* o = (CartesianOtg*)h;
+	for (int i = 0; i < 6; i++) {
+		o->input.max_velocity[i] = lim[i < 3 ? 0 : 3];
+		o->input.max_acceleration[i] = lim[i < 3 ? 1 : 4];
+		o->input.max_jerk[i] = lim[i < 3 ? 2 : 5];
 	}
 }
 void* otgref_cart_create(double dt, const double* p0, const double* R0, const double* lim) {

@@ -262,12 +262,6 @@ class _Task:
         self._otg_enabled = False
         self._cfg("saip_batch_set_internal_otg", 0)
 
-    def enableInternalOtgJerkLimited(self, *a):
-        """third-order (jerk-limited) Ruckig profiles are not implemented on the device"""
-        z = np.zeros(1)
-        self._keepalive.append(z)
-        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(z), _dptr(z), _dptr(z), 1)
-
     def getInternalOtgEnabled(self):
         return self._otg_enabled
 
@@ -629,6 +623,16 @@ class MotionForceTask(_Task):
         self._otg_enabled = True
         self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), 2)
 
+    def enableInternalOtgJerkLimited(self, max_linear_velocity=0.3, max_linear_acceleration=2.0, max_linear_jerk=10.0,
+                                     max_angular_velocity=np.pi / 3, max_angular_acceleration=2 * np.pi, max_angular_jerk=10 * np.pi):
+        """MotionForceTask.h:416-421 / MotionForceTask.cpp:525-545 (defaults: MotionForceTask.h:68-73)"""
+        v = np.ascontiguousarray([float(max_linear_velocity), float(max_angular_velocity)])
+        a = np.ascontiguousarray([float(max_linear_acceleration), float(max_angular_acceleration)])
+        j = np.ascontiguousarray([float(max_linear_jerk), float(max_angular_jerk)])
+        self._keepalive.append((v, a, j))
+        self._otg_enabled = True
+        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), 2)
+
     # desired state = OTG output when enabled, else the goal (MotionForceTask.h getDesired*)
     def getDesiredPosition(self):
         return self._desired_block()[:, 0:3]
@@ -793,6 +797,16 @@ class JointTask(_Task):
         self._keepalive.append((v, a))
         self._otg_enabled = True
         self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), int(v.shape[0]))
+
+    def enableInternalOtgJerkLimited(self, max_velocity, max_acceleration, max_jerk):
+        """JointTask.h:298-316 / JointTask.cpp:383-410: third-order (jerk-limited) Ruckig profiles; scalars or one value per task dof.  The OTG
+        is re-initialised at the current task position when it was off or acceleration-limited (the engine does so at the next cycle)"""
+        v, a, j = (np.ascontiguousarray(np.atleast_1d(np.asarray(x, float))) for x in (max_velocity, max_acceleration, max_jerk))
+        if not (v.shape == a.shape == j.shape) or v.shape[0] not in (1, self.getTaskDof()):
+            raise ValueError("max velocity, max acceleration or max jerk vector size not consistent with task dof in JointTask::enableInternalOtgJerkLimited")
+        self._keepalive.append((v, a, j))
+        self._otg_enabled = True
+        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), int(v.shape[0]))
 
     def getDesiredPosition(self):  # JointTask.h:185-200: the OTG output when enabled, else the goal
         return self._desired_block()[:, :self.getTaskDof()]

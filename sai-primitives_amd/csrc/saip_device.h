@@ -163,10 +163,11 @@ enum { OTG_FLAG_GOAL_REACHED = 1, OTG_FLAG_RUCKIG_INIT = 2, OTG_FLAG_STATE_VALID
 	   OTG_FLAG_GOAL_ORI_VALID = 32, OTG_FLAG_INVALID_GOAL = 64 };
 struct OtgDev {
 	int m, gs;             // task dof; lanes per robot (8 or 32)
-	int epoch, pad_;       // bumped when the limits change: forces a new trajectory like InputParameter::operator!= does
+	int epoch, jerk;       // epoch: bumped when the limits change (forces a new trajectory like InputParameter::operator!= does); jerk: 1 =
+	                       // jerk-limited mode (third-order profiles, OTG_joints::setMaxJerk), 0 = acceleration-limited (the reference default)
 	long long lanes;       // B * gs = stride of one state field
 	double dt;             // control period (Ruckig delta_time)
-	const double* limits;  // [2][SAIP_MAXN] device copy of the limits below: max velocity, max acceleration per task dof
+	const double* limits;  // [3][SAIP_MAXN] device copy of the limits: max velocity, max acceleration, max jerk per task dof
 	double* state;         // [fields][lanes], lane-major
 	double* time;          // [ld] OutputParameter::time
 	double* duration;      // [ld] Trajectory::duration

@@ -331,7 +331,7 @@ struct TaskHost {
 	// internal OTG of a joint task (saip_otg.hip): acceleration-limited, defaults JointTask.h:39-41
 	bool otg_alloc = false, otg_inited = false, otg_limits_dirty = true;
 	OtgDev otg;
-	double otg_limits[2 * SAIP_MAXN];  // max velocity, max acceleration per task dof
+	double otg_limits[3 * SAIP_MAXN];  // max velocity, max acceleration, max jerk per task dof (the jerk row only in jerk-limited mode)
 	double* otg_limits_dev = nullptr;
 	double* desired_dev = nullptr;
 	bool vel_sat = false;
@@ -541,7 +541,7 @@ extern "C" saip_status saip_batch_add_motion_force_task(saip_batch* b, const cha
 	memset(&T.otg, 0, sizeof(T.otg));
 	T.otg.m = 6;
 	T.otg.gs = 8;
-	for (int i = 0; i < SAIP_MAXN; i++) T.otg_limits[i] = T.otg_limits[SAIP_MAXN + i] = 1.0;
+	for (int i = 0; i < SAIP_MAXN; i++) T.otg_limits[i] = T.otg_limits[SAIP_MAXN + i] = T.otg_limits[2 * SAIP_MAXN + i] = 1.0;
 	for (int i = 0; i < 3; i++) {  // MotionForceTask.h:68-71
 		T.otg_limits[i] = 0.3;
 		T.otg_limits[SAIP_MAXN + i] = 2.0;
@@ -622,6 +622,7 @@ extern "C" saip_status saip_batch_add_joint_task(saip_batch* b, const char* task
 	for (int i = 0; i < SAIP_MAXN; i++) {
 		T.otg_limits[i] = M_PI / 3.0;              // DefaultParameters::otg_max_velocity, JointTask.h:40
 		T.otg_limits[SAIP_MAXN + i] = 2.0 * M_PI;  // DefaultParameters::otg_max_acceleration, JointTask.h:41
+		T.otg_limits[2 * SAIP_MAXN + i] = 10.0 * M_PI;  // DefaultParameters::otg_max_jerk, JointTask.h:42 (used in jerk-limited mode only)
 	}
 	b->tasks.push_back(T);
 	b->config_dirty = true;
@@ -900,7 +901,8 @@ extern "C" saip_status saip_batch_set_otg_acceleration_limited(saip_batch* b, in
 		}
 		T.otg_limits_dirty = true;
 		T.otg.epoch++;
-		if (!T.otg_enabled) T.otg_inited = false;
+		if (!T.otg_enabled || T.otg.jerk) T.otg_inited = false;  // MotionForceTask.cpp:513-515: re-initialised when the OTG was off or jerk-limited
+		T.otg.jerk = 0;
 		T.otg_enabled = true;
 		b->config_dirty = true;
 		return SAIP_OK;
@@ -918,15 +920,56 @@ extern "C" saip_status saip_batch_set_otg_acceleration_limited(saip_batch* b, in
 	}
 	T.otg_limits_dirty = true;
 	T.otg.epoch++;
-	if (!T.otg_enabled) T.otg_inited = false;
+	if (!T.otg_enabled || T.otg.jerk) T.otg_inited = false;  // JointTask.cpp:374-376
+	T.otg.jerk = 0;
 	T.otg_enabled = true;
 	b->config_dirty = true;
 	return SAIP_OK;
 }
-extern "C" saip_status saip_batch_set_otg_jerk_limited(saip_batch* b, int t, const double*, const double*, const double*, int) {
+// JointTask::enableInternalOtgJerkLimited (JointTask.cpp:383-410; OTG_joints::setMaxVelocity / setMaxAcceleration / setMaxJerk, OTG_joints.cpp:44-86) and
+// MotionForceTask::enableInternalOtgJerkLimited (MotionForceTask.cpp:525-545; OTG_6dof_cartesian::setMaxJerk, OTG_6dof_cartesian.cpp:126-136):
+// third-order Ruckig profiles on the device (csrc/saip_otg3.h).  The OTG is re-initialised at the current task position when it was off or
+// acceleration-limited (:400-402 / :530-532).
+extern "C" saip_status saip_batch_set_otg_jerk_limited(saip_batch* b, int t, const double* max_velocity, const double* max_acceleration, const double* max_jerk, int count) {
 	saip_status st = check_batch(b, t, "saip_batch_set_otg_jerk_limited");
 	if (st) return st;
-	return fail(SAIP_ERR_UNSUPPORTED, "jerk-limited internal OTG (enableInternalOtgJerkLimited) is not implemented on the device; use the acceleration-limited mode");
+	if (t < 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad task");
+	TaskHost& T = b->tasks[t];
+	if (T.dev.type == saip::TASK_MOTION_FORCE) {
+		if (!max_velocity || !max_acceleration || !max_jerk || count != 2)
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "motion-force task: pass {linear, angular} max velocities, max accelerations and max jerks (count = 2)");
+		for (int i = 0; i < 2; i++) {
+			if (!(max_velocity[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity set to 0 or negative value in some directions in OTG_6dof_cartesian::setMax%sVelocity", i ? "Angular" : "Linear");
+			if (!(max_acceleration[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max acceleration set to 0 or negative value in some directions in OTG_6dof_cartesian::setMax%sAcceleration", i ? "Angular" : "Linear");
+			if (!(max_jerk[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max jerk set to 0 or negative value in some directions in OTG_6dof_cartesian::setMaxJerk");
+		}
+		for (int i = 0; i < 6; i++) {
+			T.otg_limits[i] = max_velocity[i / 3];
+			T.otg_limits[SAIP_MAXN + i] = max_acceleration[i / 3];
+			T.otg_limits[2 * SAIP_MAXN + i] = max_jerk[i / 3];
+		}
+	} else {
+		const int m = T.dev.m;
+		if (!max_velocity || !max_acceleration || !max_jerk || (count != 1 && count != m))
+			return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity, max acceleration or max jerk vector size not consistent with task dof in JointTask::enableInternalOtgJerkLimited");
+		for (int i = 0; i < count; i++) {
+			if (!(max_velocity[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max velocity cannot be 0 or negative in any directions in OTG_joints::setMaxVelocity");
+			if (!(max_acceleration[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max acceleration cannot be 0 or negative in any directions in OTG_joints::setMaxAcceleration");
+			if (!(max_jerk[i] > 0)) return fail(SAIP_ERR_INVALID_ARGUMENT, "max jerk cannot be 0 or negative in any directions in OTG_joints::setMaxJerk");
+		}
+		for (int i = 0; i < m; i++) {
+			T.otg_limits[i] = max_velocity[count == 1 ? 0 : i];
+			T.otg_limits[SAIP_MAXN + i] = max_acceleration[count == 1 ? 0 : i];
+			T.otg_limits[2 * SAIP_MAXN + i] = max_jerk[count == 1 ? 0 : i];
+		}
+	}
+	T.otg_limits_dirty = true;
+	T.otg.epoch++;
+	if (!T.otg_enabled || !T.otg.jerk) T.otg_inited = false;
+	T.otg.jerk = 1;
+	T.otg_enabled = true;
+	b->config_dirty = true;
+	return SAIP_OK;
 }
 extern "C" saip_status saip_batch_set_velocity_saturation(saip_batch* b, int t, int enabled) {
 	saip_status st = check_batch(b, t, "saip_batch_set_velocity_saturation");
@@ -1193,7 +1236,7 @@ static saip_status ensure_otg(saip_batch* b, TaskHost& T) {
 	if ((st = dev_alloc(b, &O.state, (size_t)saip::otg_state_fields() * (size_t)O.lanes)) || (st = dev_alloc(b, &O.time, (size_t)b->ld)) ||
 		(st = dev_alloc(b, &O.duration, (size_t)b->ld)) || (st = dev_alloc(b, &O.flags, (size_t)b->ld)) || (st = dev_alloc(b, &O.seen_epoch, (size_t)b->ld)) ||
 		(st = dev_alloc(b, &O.result, (size_t)b->ld)) || (st = dev_alloc(b, &T.desired_dev, (size_t)T.dev.goal_comps * b->ld)) ||
-		(st = dev_alloc(b, &T.otg_limits_dev, (size_t)2 * SAIP_MAXN)))
+		(st = dev_alloc(b, &T.otg_limits_dev, (size_t)3 * SAIP_MAXN)))
 		return st;
 	if (T.dev.type == saip::TASK_MOTION_FORCE && (st = dev_alloc(b, &O.frame, (size_t)21 * b->ld))) return st;
 	O.model = b->model_dev;
@@ -1394,7 +1437,8 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 // both OTGs of a { MotionForceTask, JointTask } stack on, initialised and with clean limits: their cycle-mode steps share one launch
 static bool otg_pair_ready(saip_batch* b) {
 	if (!(b->tasks.size() == 2 && b->tasks[0].otg_enabled && b->tasks[1].otg_enabled && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE &&
-		  b->tasks[1].dev.type == saip::TASK_JOINT && b->tasks[1].otg.gs == 8 && !b->tasks[0].otg_limits_dirty && !b->tasks[1].otg_limits_dirty))
+		  b->tasks[1].dev.type == saip::TASK_JOINT && b->tasks[1].otg.gs == 8 && !b->tasks[0].otg_limits_dirty && !b->tasks[1].otg_limits_dirty &&
+		  !b->tasks[0].otg.jerk && !b->tasks[1].otg.jerk))
 		return false;
 	for (int t = 0; t < 2; t++) {
 		TaskHost& T = b->tasks[t];

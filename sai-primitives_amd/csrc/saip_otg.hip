@@ -31,6 +31,8 @@
 
 #pragma clang fp contract(off)
 
+#include "saip_otg3.h"  // jerk-limited (third-order) profiles: brake, step 1, step 2, sampling -- per-lane functions
+
 namespace saip {
 
 namespace {
@@ -292,6 +294,11 @@ enum {
 	F_A0, F_A2, F_A6,            //                 and their accelerations
 	F_P0, F_V0,                  // profile start (after the brake pre-trajectory)
 	F_BR_T, F_BR_A, F_BR_P, F_BR_V,  // brake pre-trajectory: duration, acceleration, start state
+	// jerk-limited mode only (the third-order profile has seven live segments, a jerk per segment and a two-section brake pre-trajectory)
+	F3_T3, F3_T4, F3_T5,
+	F3_A1, F3_A3, F3_A4, F3_A5, F3_A7,
+	F3_J0, F3_J1, F3_J2, F3_J3, F3_J4, F3_J5, F3_J6,
+	F3_BR_T1, F3_BR_J0, F3_BR_J1, F3_BR_P1, F3_BR_V1, F3_BR_A1,
 	F_COUNT
 };
 
@@ -366,15 +373,21 @@ struct Lane {
 	double in_p, in_v, in_a, tg_p, tg_v, out_p, out_v, out_a;  // wrapper _input.current/target, _output.new
 	double ci_p, ci_v, ci_a, ci_tp, ci_tv;                      // ruckig current_input
 	double t[7], a[7], P0, V0, br_t, br_a, br_p, br_v;          // stored trajectory of this dof
+	// jerk-limited mode: a[] holds a[0..6] of the third-order profile, a7 its last entry; br_t / br_a / br_p / br_v are section 0 of the brake
+	double j[7], a7, br_t1, br_j0, br_j1, br_p1, br_v1, br_a1;
 };
 
 #define ST(f) S[(size_t)(f) * stride + li]
+template <bool JERK = false>
 __device__ __forceinline__ void lane_load(Lane& L, const double* S, size_t stride, size_t li, bool act) {
 	L.in_p = L.in_v = L.in_a = L.tg_p = L.tg_v = L.out_p = L.out_v = L.out_a = 0.0;
 	L.ci_p = L.ci_v = L.ci_a = L.ci_tp = L.ci_tv = 0.0;
 #pragma unroll
 	for (int i = 0; i < 7; i++) L.t[i] = L.a[i] = 0.0;
 	L.P0 = L.V0 = L.br_t = L.br_a = L.br_p = L.br_v = 0.0;
+#pragma unroll
+	for (int i = 0; i < 7; i++) L.j[i] = 0.0;
+	L.a7 = L.br_t1 = L.br_j0 = L.br_j1 = L.br_p1 = L.br_v1 = L.br_a1 = 0.0;
 	if (!act) return;
 	L.in_p = ST(F_IN_P);
 	L.in_v = ST(F_IN_V);
@@ -402,8 +415,27 @@ __device__ __forceinline__ void lane_load(Lane& L, const double* S, size_t strid
 	L.br_a = ST(F_BR_A);
 	L.br_p = ST(F_BR_P);
 	L.br_v = ST(F_BR_V);
+	if (JERK) {
+		L.t[3] = ST(F3_T3);
+		L.t[4] = ST(F3_T4);
+		L.t[5] = ST(F3_T5);
+		L.a[1] = ST(F3_A1);
+		L.a[3] = ST(F3_A3);
+		L.a[4] = ST(F3_A4);
+		L.a[5] = ST(F3_A5);
+		L.a7 = ST(F3_A7);
+#pragma unroll
+		for (int i = 0; i < 7; i++) L.j[i] = ST(F3_J0 + i);
+		L.br_t1 = ST(F3_BR_T1);
+		L.br_j0 = ST(F3_BR_J0);
+		L.br_j1 = ST(F3_BR_J1);
+		L.br_p1 = ST(F3_BR_P1);
+		L.br_v1 = ST(F3_BR_V1);
+		L.br_a1 = ST(F3_BR_A1);
+	}
 }
 // new_traj: a trajectory was (re)calculated this cycle; plain sampling cycles leave the profile fields alone
+template <bool JERK = false>
 __device__ __forceinline__ void lane_store(const Lane& L, double* S, size_t stride, size_t li, bool new_traj) {
 	ST(F_IN_P) = L.in_p;
 	ST(F_IN_V) = L.in_v;
@@ -432,6 +464,24 @@ __device__ __forceinline__ void lane_store(const Lane& L, double* S, size_t stri
 		ST(F_BR_A) = L.br_a;
 		ST(F_BR_P) = L.br_p;
 		ST(F_BR_V) = L.br_v;
+		if (JERK) {
+			ST(F3_T3) = L.t[3];
+			ST(F3_T4) = L.t[4];
+			ST(F3_T5) = L.t[5];
+			ST(F3_A1) = L.a[1];
+			ST(F3_A3) = L.a[3];
+			ST(F3_A4) = L.a[4];
+			ST(F3_A5) = L.a[5];
+			ST(F3_A7) = L.a7;
+#pragma unroll
+			for (int i = 0; i < 7; i++) ST(F3_J0 + i) = L.j[i];
+			ST(F3_BR_T1) = L.br_t1;
+			ST(F3_BR_J0) = L.br_j0;
+			ST(F3_BR_J1) = L.br_j1;
+			ST(F3_BR_P1) = L.br_p1;
+			ST(F3_BR_V1) = L.br_v1;
+			ST(F3_BR_A1) = L.br_a1;
+		}
 	}
 }
 #undef ST
@@ -612,11 +662,219 @@ __device__ __forceinline__ int ruckig_update(const Grp<GS>& g, bool act, bool ru
 	return result;
 }
 
+
+// ---------------------------------------------------------------- jerk-limited mode (JointTask::enableInternalOtgJerkLimited, JointTask.cpp:383-410;
+// MotionForceTask.cpp:525-545; OTG_joints::setMaxJerk, OTG_joints.cpp:73-86): Ruckig::update with the third-order position interface.
+// Same skeleton as ruckig_update above -- brake pre-trajectory, step 1 per dof, synchronisation over the lane group (now with up to two
+// blocked intervals per dof: 3 m candidate durations), phase synchronisation (the control is the jerk), step 2 -- with the per-dof closed
+// forms of saip_otg3.h.  The trajectory calculation keeps its profiles in private memory (it runs only when a goal or a limit changed);
+// the per-cycle sampling does not touch them.
+__device__ __noinline__ void o3_phase_check(otg3::P3& ph, const int cs, const double jf, const double vMax, const double vMin, const double aMax, const double aMin,
+											const double jMax, bool* ok) {
+	*ok = (cs == otg3::UDDU) ? otg3::o3_check_jf<otg3::UDDU, otg3::L_NONE>(ph, jf, vMax, vMin, aMax, aMin, jMax)
+							 : otg3::o3_check_jf<otg3::UDUD, otg3::L_NONE>(ph, jf, vMax, vMin, aMax, aMin, jMax);
+}
+template <int GS>
+__device__ __noinline__ int ruckig_update3(const Grp<GS>& g, bool act, bool run, int m, double vMax, double aMax, double jMax, bool new_limits, double dt, Lane& L,
+										   int& flags, double& time, double& duration, bool* new_traj) {
+	using namespace otg3;
+	const int dof = g.dof;
+	const double vMin = -vMax, aMin = -aMax;
+	int result = 0;
+	*new_traj = false;
+	const bool differs = act && !(L.in_p == L.ci_p && L.in_v == L.ci_v && L.in_a == L.ci_a && L.tg_p == L.ci_tp && L.tg_v == L.ci_tv);
+	const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
+
+	if (g.any(need_calc)) {
+		// validate_input (input_parameter.hpp:155-330, check_target_state_within_limits only; the target acceleration is always 0 here)
+		bool bad = act && need_calc && (isnan(L.in_p) || isnan(L.in_v) || isnan(L.in_a) || isnan(L.tg_p) || isnan(L.tg_v) || L.tg_v > vMax || L.tg_v < vMin);
+		int err = g.any(bad) ? -100 : 0;
+
+		// ---------------------------------------------------- per-dof: brake pre-trajectory + step 1 (calculator_target.hpp:235-318)
+		Block3 blk;
+		Brake3 br;
+		double np0 = L.in_p, nv0 = L.in_v, na0 = L.in_a;
+		{
+			o3_brake(br, np0, nv0, na0, vMax, vMin, aMax, aMin, jMax);
+			O3Step1 s1;
+			s1.init(np0, nv0, na0, L.tg_p, L.tg_v, 0.0, vMax, vMin, aMax, aMin, jMax);
+			bool found = false;
+			if (act && need_calc && err == 0) found = s1.run(blk, br.duration);
+			if (!found) {
+				blk.t_min = 0.0;
+				blk.has_a = blk.has_b = false;
+				blk.a_left = blk.a_right = blk.b_left = blk.b_right = OTG_INF;
+				blk.pmin = s1.w;
+			}
+			if (err == 0 && g.any(act && need_calc && !found)) err = -110;  // ErrorExecutionTimeCalculation
+		}
+
+		// ---------------------------------------------------- synchronize (calculator_target.hpp:128-207): the smallest candidate duration
+		// {t_min, a.right, b.right} of any dof that no dof blocks; ties towards the lower candidate index
+		double t_sync = OTG_INF;
+		int lim_idx = -1;  // candidate index = quot * m + dof
+		if (m == 1) {      // :320-325: a single dof keeps its fastest profile
+			t_sync = blk.t_min;
+			lim_idx = 0;
+		} else {
+			for (int c = 0; c < 3; c++) {
+				const double mine = (c == 0) ? blk.t_min : (c == 1 ? (blk.has_a ? blk.a_right : OTG_INF) : (blk.has_b ? blk.b_right : OTG_INF));
+				for (int s = 0; s < m; s++) {
+					const double cand = g.bcast(mine, s);
+					const bool blocked = act && ((cand < blk.t_min) || (blk.has_a && blk.a_left < cand && cand < blk.a_right) || (blk.has_b && blk.b_left < cand && cand < blk.b_right));
+					const bool is_blocked = g.any(blocked);
+					if (!is_blocked && !isinf(cand) && !(cand < 0.0) && cand < t_sync) {
+						t_sync = cand;
+						lim_idx = c * m + s;
+					}
+				}
+			}
+		}
+		if (err == 0 && lim_idx < 0) err = -111;  // ErrorSynchronizationCalculation
+		const int lim_dof = lim_idx < 0 ? 0 : lim_idx % m;
+		const int lim_quot = lim_idx < 0 ? 0 : lim_idx / m;
+		if (err == 0 && m > 1 && t_sync > 7.6e3) err = -101;  // ErrorTrajectoryDuration, :354-358
+
+		P3 mine = blk.pmin;  // profile of this dof
+		if (dof == lim_dof && lim_quot == 1) mine = blk.pa;
+		if (dof == lim_dof && lim_quot == 2) mine = blk.pb;
+		bool done = (t_sync == 0.0) || (m == 1);  // :360-366: every dof keeps its p_min
+
+		// ---------------------------------------------------- phase synchronisation (calculator_target.hpp:44-126, 373-455)
+		if (err == 0 && !done) {
+			const double pdv = L.tg_p - L.in_p;
+			int which = 0;  // 1 pd, 2 v0, 3 a0, 4 vf (af = 0)
+			if (dabs(pdv) > OTG_DBL_EPS) which = 1;
+			else if (dabs(L.in_v) > OTG_DBL_EPS) which = 2;
+			else if (dabs(L.in_a) > OTG_DBL_EPS) which = 3;
+			else if (dabs(L.tg_v) > OTG_DBL_EPS) which = 4;
+			const unsigned long long cand_bits = g.bits(act && which != 0);
+			bool collinear = cand_bits != 0ull;
+			const int sdof = collinear ? __builtin_ctzll(cand_bits) : 0;
+			const int swhich = g.bcast(which, sdof);
+			const double sv = swhich == 1 ? pdv : (swhich == 2 ? L.in_v : (swhich == 3 ? L.in_a : L.tg_v));  // scale_vector[dof]
+			const double scale = g.bcast(sv, sdof);
+			const double pd_scale = g.bcast(pdv, sdof) / scale, v0_scale = g.bcast(L.in_v, sdof) / scale, vf_scale = g.bcast(L.tg_v, sdof) / scale;
+			const double a0_scale = g.bcast(L.in_a, sdof) / scale, af_scale = 0.0 / scale;
+			const double scale_limiting = g.bcast(sv, lim_dof);
+			const int lim_dir = g.bcast(mine.dir, lim_dof);
+			const int lim_cs = g.bcast(mine.cs, lim_dof);
+			const double control_limiting = (lim_dir == 0) ? g.bcast(jMax, lim_dof) : -g.bcast(jMax, lim_dof);
+			const bool off = act && (dabs(pdv - pd_scale * sv) > OTG_DBL_EPS || dabs(L.in_v - v0_scale * sv) > OTG_DBL_EPS ||
+									 dabs(L.in_a - a0_scale * sv) > OTG_DBL_EPS || dabs(L.tg_v - vf_scale * sv) > OTG_DBL_EPS ||
+									 dabs(0.0 - af_scale * sv) > OTG_DBL_EPS);
+			if (g.any(off)) collinear = false;
+			const double phase_control = control_limiting * sv / scale_limiting;
+			if (collinear) {
+				P3 ph = blk.pmin;  // boundary state of this dof
+#pragma unroll
+				for (int i = 0; i < 7; i++) ph.t[i] = g.bcast(mine.t[i], lim_dof);  // p.t = p_limiting.t
+				bool okp = true;
+				if (act && dof != lim_dof) o3_phase_check(ph, lim_cs, phase_control, vMax, vMin, aMax, aMin, jMax, &okp);
+				if (!g.any(act && !okp)) {
+					if (dof != lim_dof) mine = ph;
+					done = true;
+				}
+			}
+		}
+		// ---------------------------------------------------- time synchronisation (calculator_target.hpp:457-521)
+		if (err == 0 && !done) {
+			bool ok2 = true;
+			if (act && dof != lim_dof) {
+				const double t_profile = t_sync - br.duration - 0.0;
+				if (dabs(t_profile - blk.t_min) < 2 * OTG_DBL_EPS) mine = blk.pmin;
+				else if (blk.has_a && dabs(t_profile - blk.a_right) < 2 * OTG_DBL_EPS) mine = blk.pa;
+				else if (blk.has_b && dabs(t_profile - blk.b_right) < 2 * OTG_DBL_EPS) mine = blk.pb;
+				else {
+					O3Step2 s2;
+					s2.init(t_profile, np0, nv0, na0, L.tg_p, L.tg_v, 0.0, vMax, vMin, aMax, aMin, jMax);
+					mine = blk.pmin;  // boundary state
+					ok2 = s2.run(mine);
+				}
+			}
+			if (g.any(act && !ok2)) err = -111;
+		}
+
+		if (need_calc) {
+			if (err != 0) {
+				result = err;  // ruckig.hpp:199-201: returns before touching current_input / output
+			} else {
+#pragma unroll
+				for (int i = 0; i < 7; i++) {
+					L.t[i] = mine.t[i];
+					L.a[i] = mine.a[i];
+					L.j[i] = mine.j[i];
+				}
+				L.a7 = mine.a[7];
+				L.P0 = mine.p[0];
+				L.V0 = mine.v[0];
+				L.br_t = br.t[0];
+				L.br_t1 = (br.duration > 0 && br.t[1] > 0.0) ? br.t[1] : 0.0;
+				L.br_j0 = br.j[0];
+				L.br_j1 = br.j[1];
+				L.br_p = br.p[0];
+				L.br_v = br.v[0];
+				L.br_a = br.a[0];
+				L.br_p1 = br.p[1];
+				L.br_v1 = br.v[1];
+				L.br_a1 = br.a[1];
+				if (!(br.duration > 0)) L.br_t = 0.0;
+				duration = t_sync;
+				time = 0.0;
+				L.ci_p = L.in_p;  // current_input = input, ruckig.hpp:203
+				L.ci_v = L.in_v;
+				L.ci_a = L.in_a;
+				L.ci_tp = L.tg_p;
+				L.ci_tv = L.tg_v;
+				flags |= OTG_FLAG_RUCKIG_INIT;
+				*new_traj = true;
+			}
+		}
+	}
+
+	if (run && result == 0) {
+		// ruckig.hpp:209-220: advance one control period along the stored trajectory
+		time = time + dt;
+		P3 pr;
+		Brake3 br;
+#pragma unroll
+		for (int i = 0; i < 7; i++) {
+			pr.t[i] = L.t[i];
+			pr.a[i] = L.a[i];
+			pr.j[i] = L.j[i];
+		}
+		pr.a[7] = L.a7;
+		pr.p[0] = L.P0;
+		pr.v[0] = L.V0;
+		br.t[0] = L.br_t;
+		br.t[1] = L.br_t1;
+		br.duration = L.br_t + L.br_t1;
+		br.j[0] = L.br_j0;
+		br.j[1] = L.br_j1;
+		br.p[0] = L.br_p;
+		br.v[0] = L.br_v;
+		br.a[0] = L.br_a;
+		br.p[1] = L.br_p1;
+		br.v[1] = L.br_v1;
+		br.a[1] = L.br_a1;
+		double pn, vn, an;
+		o3_sample(time, duration, pr, br, pn, vn, an);
+		L.out_p = pn;
+		L.out_v = vn;
+		L.out_a = an;
+		L.ci_p = L.out_p;  // output.pass_to_input(current_input)
+		L.ci_v = L.out_v;
+		L.ci_a = L.out_a;
+		if (time > duration) result = 1;  // Finished
+	}
+	return result;
+}
+
 }  // namespace
 
 // One control cycle of the internal OTG of one joint task for the whole batch.  mode 0: cycle (JointTask.cpp:313-319);
 // mode 1: OTG_joints::reInitialize(S q) (JointTask.cpp:95-106, OTG_joints.cpp:28-42).
-template <int GS>
+template <int GS, bool JERK = false>
 __device__ __forceinline__ void otg_joints_body(const OtgDev& O, const int B, const int ld, const int mode, const int block) {
 	const Grp<GS> g;
 	const int gtid = block * blockDim.x + threadIdx.x;
@@ -672,13 +930,13 @@ __device__ __forceinline__ void otg_joints_body(const OtgDev& O, const int B, co
 	const double goal_p = act ? O.goal[gi] : 0.0;
 	const double goal_v = act ? O.goal[gi + (size_t)m * ld] : 0.0;
 	Lane L;
-	lane_load(L, S, stride, li, act);
+	lane_load<JERK>(L, S, stride, li, act);
 	int flags = inst_ok ? O.flags[inst] : 0;
-	const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0;
+	const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0, jMax = (JERK && act) ? O.limits[2 * SAIP_MAXN + dof] : 1.0;
 	// new limits since the last cycle: enableInternalOtgAccelerationLimited -> disableJerkLimits() zeroes the current acceleration
 	// of the wrapper's input (OTG_joints.cpp:90-93); the changed limits themselves force a new trajectory (ruckig.hpp:197)
 	const bool new_limits = inst_ok && (O.epoch != O.seen_epoch[inst]);
-	if (new_limits) L.in_a = 0.0;
+	if (new_limits && !JERK) L.in_a = 0.0;
 
 	// setGoalPositionAndVelocity, OTG_joints.cpp:98-114 (Eigen isApprox: ||a-b||^2 <= 1e-24 min(||a||^2, ||b||^2))
 	{
@@ -697,7 +955,8 @@ __device__ __forceinline__ void otg_joints_body(const OtgDev& O, const int B, co
 	const bool run = inst_ok && !(flags & OTG_FLAG_GOAL_REACHED);  // OTG_joints.cpp:117-119
 	if (g.any(run)) {
 		double time = inst_ok ? O.time[inst] : 0.0, duration = inst_ok ? O.duration[inst] : 0.0;
-		result = ruckig_update<GS>(g, act, run, m, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+		if (JERK) result = ruckig_update3<GS>(g, act, run, m, vMax, aMax, jMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+		else result = ruckig_update<GS>(g, act, run, m, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
 		// OTG_joints::update after the ruckig call, OTG_joints.cpp:125-149
 		if (run) {
 			if (result == 1) {
@@ -730,7 +989,7 @@ __device__ __forceinline__ void otg_joints_body(const OtgDev& O, const int B, co
 		}
 	}
 	if (act) {
-		lane_store(L, S, stride, li, new_traj);
+		lane_store<JERK>(L, S, stride, li, new_traj);
 		// JointTask.cpp:317-319: the desired state the control law tracks
 		O.desired[gi] = L.out_p;
 		O.desired[gi + (size_t)m * ld] = L.out_v;
@@ -935,6 +1194,7 @@ __device__ __forceinline__ void cart_set_goal_position(const Grp<GS>& g, Lane& L
 
 // mode 0: one control cycle (MotionForceTask.cpp:394-406).  mode 1 | (mask << 4): reInitialize (mask 3), reInitializeLinear
 // (mask 1), reInitializeAngular (mask 2) at the current pose of the control frame (OTG_6dof_cartesian.cpp:46-84).
+template <bool JERK = false>
 __device__ __forceinline__ void otg_cartesian_body(const OtgDev& O, const int B, const int ld, const int mode, const int block) {
 	constexpr int GS = 8;
 	const Grp<GS> g;
@@ -949,7 +1209,7 @@ __device__ __forceinline__ void otg_cartesian_body(const OtgDev& O, const int B,
 	const size_t ib = inst_ok ? (size_t)inst : 0;
 
 	Lane L;
-	lane_load(L, S, stride, li, act);
+	lane_load<JERK>(L, S, stride, li, act);
 	int flags = inst_ok ? O.flags[inst] : 0;
 	CartFrames F;
 #pragma unroll
@@ -993,16 +1253,17 @@ __device__ __forceinline__ void otg_cartesian_body(const OtgDev& O, const int B,
 		}
 #pragma unroll
 		for (int e = 0; e < 9; e++) Rg.m[e] = O.goal[(size_t)(3 + e) * ld + ib];
-		const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0;
+		const double vMax = act ? O.limits[dof] : 1.0, aMax = act ? O.limits[SAIP_MAXN + dof] : 1.0, jMax = (JERK && act) ? O.limits[2 * SAIP_MAXN + dof] : 1.0;
 		const bool new_limits = inst_ok && (O.epoch != O.seen_epoch[inst]);
-		if (new_limits) L.in_a = 0.0;  // disableJerkLimits, OTG_6dof_cartesian.h:86-89
+		if (new_limits && !JERK) L.in_a = 0.0;  // disableJerkLimits, OTG_6dof_cartesian.h:86-89
 		flags &= ~OTG_FLAG_INVALID_GOAL;
 		cart_set_goal_position<GS>(g, L, flags, gp, gv);                     // MotionForceTask.cpp:395-396
 		cart_set_goal_orientation<GS>(g, act, L, F, flags, Rg, gw);          // :397-398
 		run = inst_ok && !(flags & OTG_FLAG_GOAL_REACHED);                   // OTG_6dof_cartesian.cpp:194-196
 		if (g.any(run)) {
 			double time = O.time[ib], duration = O.duration[ib];
-			result = ruckig_update<GS>(g, act, run, 6, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+			if (JERK) result = ruckig_update3<GS>(g, act, run, 6, vMax, aMax, jMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
+			else result = ruckig_update<GS>(g, act, run, 6, vMax, aMax, new_limits, O.dt, L, flags, time, duration, &new_traj);
 			if (run) {  // :201-225
 				if (result == 1) {
 					const double vn2 = g.sum(act ? L.out_v * L.out_v : 0.0);
@@ -1034,7 +1295,7 @@ __device__ __forceinline__ void otg_cartesian_body(const OtgDev& O, const int B,
 	}
 
 	// ------------------------------------------------------------ stores: lane state, frames, desired state (goal layout)
-	if (act) lane_store(L, S, stride, li, new_traj);
+	if (act) lane_store<JERK>(L, S, stride, li, new_traj);
 	if (inst_ok) {
 		const double op[3] = {g.bcast(L.out_p, 3), g.bcast(L.out_p, 4), g.bcast(L.out_p, 5)};
 		const double ov[3] = {g.bcast(L.out_v, 3), g.bcast(L.out_v, 4), g.bcast(L.out_v, 5)};
@@ -1076,6 +1337,14 @@ __global__ void __launch_bounds__(256) saip_otg_joints(const OtgDev O, int B, in
 }
 __global__ void __launch_bounds__(256) saip_otg_cartesian(const OtgDev O, int B, int ld, int mode) {
 	otg_cartesian_body(O, B, ld, mode, blockIdx.x);
+}
+// jerk-limited mode: kernels of their own, so that the third-order solver's registers and private memory stay out of the default mode's
+template <int GS>
+__global__ void __launch_bounds__(256) saip_otg3_joints(const OtgDev O, int B, int ld, int mode) {
+	otg_joints_body<GS, true>(O, B, ld, mode, blockIdx.x);
+}
+__global__ void __launch_bounds__(256) saip_otg3_cartesian(const OtgDev O, int B, int ld, int mode) {
+	otg_cartesian_body<true>(O, B, ld, mode, blockIdx.x);
 }
 // One launch for the two OTGs of a { MotionForceTask, JointTask } stack in their cycle mode: they are independent and each is a few
 // latency-bound wavefronts, so the second launch only added its latency.  Workgroups [0, grid_c) run the Cartesian OTG, the rest the
@@ -1121,7 +1390,8 @@ hipError_t launch_integrate_otg_pair(const SimParams& S, const OtgDev& Oc, const
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream) {
 	const int block = 256;
 	const int grid = (int)(((long long)O.lanes + block - 1) / block);
-	hipLaunchKernelGGL(saip_otg_cartesian, dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	if (O.jerk) hipLaunchKernelGGL(saip_otg3_cartesian, dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	else hipLaunchKernelGGL(saip_otg_cartesian, dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
 	return hipGetLastError();
 }
 
@@ -1132,7 +1402,10 @@ hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream
 	const long long lanes = (long long)O.lanes;
 	const int block = 256;
 	const int grid = (int)((lanes + block - 1) / block);
-	if (gs == 8) hipLaunchKernelGGL((saip_otg_joints<8>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	if (O.jerk) {
+		if (gs == 8) hipLaunchKernelGGL((saip_otg3_joints<8>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+		else hipLaunchKernelGGL((saip_otg3_joints<32>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
+	} else if (gs == 8) hipLaunchKernelGGL((saip_otg_joints<8>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
 	else hipLaunchKernelGGL((saip_otg_joints<32>), dim3(grid), dim3(block), 0, stream, O, B, ld, mode);
 	return hipGetLastError();
 }

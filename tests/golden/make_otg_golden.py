@@ -76,6 +76,51 @@ def scenarios():
     g2 = g1 + rng.uniform(-0.3, 0.3, (B5, 30))
     out["otg_chain30"] = dict(robot="chain30", S=None, q0=q0, K=1300, vmax=np.pi / 3, amax=2 * np.pi,
                               events=[(0, "goal", (g1, np.zeros((B5, 30)))), (300, "goal", (g2, np.zeros((B5, 30))))])
+
+    # ---- jerk-limited mode (JointTask::enableInternalOtgJerkLimited, third-order Ruckig profiles): key `jmax`; "limits" events carry
+    # (max velocity, max acceleration, max jerk); "mode" events switch between the two modes (the wrapper re-initialises the OTG at the
+    # current task position when the mode changes, JointTask.cpp:374-376, 400-402)
+    rngj = np.random.default_rng(0x07C3)
+    # 6: from rest, example 02's limits (examples/02-joint_control_internal_otg:175: pi, 3 pi, 3 pi); the first instances move along a line
+    q0 = q_nom + rngj.uniform(-0.2, 0.2, (B, 7))
+    g = q0 + rngj.uniform(-0.7, 0.7, (B, 7))
+    g[:4] = q0[:4] + rngj.uniform(-0.6, 0.6, (4, 1)) * rngj.uniform(0.2, 1.0, (4, 7))
+    g[4] = q0[4]
+    out["otg_jerk_rest_to_goal"] = dict(robot="panda_arm", S=None, q0=q0, K=1500, vmax=np.pi, amax=3 * np.pi, jmax=3 * np.pi,
+                                        events=[(0, "goal", (g, np.zeros((B, 7))))])
+    # 7: goals changed in flight (non-zero velocity AND acceleration at the switch: step 2 of every dof but the limiting one), a goal
+    #    with goal velocities, per-joint limits lowered in flight (third-order brake pre-trajectories)
+    q0 = q_nom + rngj.uniform(-0.2, 0.2, (B, 7))
+    g1 = q0 + rngj.uniform(-0.6, 0.6, (B, 7))
+    g2 = g1 + rngj.uniform(-0.5, 0.5, (B, 7))
+    g3 = q0 + rngj.uniform(-0.3, 0.3, (B, 7))
+    gv3 = rngj.uniform(-0.2, 0.2, (B, 7))
+    gv3[:4] = 0.0
+    vm = np.array([1.0, 0.8, 1.2, 0.9, 1.5, 1.1, 2.0])
+    am = np.array([4.0, 3.0, 6.0, 5.0, 8.0, 7.0, 9.0])
+    jm = np.array([30.0, 20.0, 50.0, 40.0, 60.0, 45.0, 80.0])
+    out["otg_jerk_goal_changes"] = dict(robot="panda_arm", S=None, q0=q0, K=5600, vmax=vm, amax=am, jmax=jm,
+                                        events=[(0, "goal", (g1, np.zeros((B, 7)))), (230, "goal", (g2, np.zeros((B, 7)))),
+                                                (520, "limits", (0.4 * vm, 0.5 * am, 0.6 * jm)), (900, "goal", (g3, gv3)),
+                                                (1700, "goal", (g3, np.zeros((B, 7))))], reference_throws=True)
+    # 8: mode switches in flight: acceleration-limited -> jerk-limited -> acceleration-limited, partial joint task
+    S = np.eye(7)[[1, 3, 5]]
+    q0 = q_nom + rngj.uniform(-0.2, 0.2, (B, 7))
+    x0 = q0 @ S.T
+    g1 = x0 + rngj.uniform(-0.5, 0.5, (B, 3))
+    g2 = x0 + rngj.uniform(-0.5, 0.5, (B, 3))
+    g3 = x0 + rngj.uniform(-0.5, 0.5, (B, 3))
+    out["otg_jerk_mode_switch"] = dict(robot="panda_arm", S=S, q0=q0, K=2200, vmax=np.pi / 3, amax=2 * np.pi, jmax=None,
+                                       events=[(0, "goal", (g1, np.zeros((B, 3)))), (300, "mode", ("jerk", q0, (np.pi / 3, 2 * np.pi, 10 * np.pi))),
+                                               (300, "goal", (g2, np.zeros((B, 3)))), (1100, "mode", ("acc", q0, (np.pi / 3, 2 * np.pi))),
+                                               (1100, "goal", (g3, np.zeros((B, 3))))])
+    # 9: 30-dof chain (32-lane groups), goal change in flight
+    q0 = rngj.uniform(-0.6, 0.6, (B5, 30))
+    g1 = q0 + rngj.uniform(-0.5, 0.5, (B5, 30))
+    g1[0] = q0[0] + 0.4 * rngj.uniform(0.1, 1.0, 30)
+    g2 = g1 + rngj.uniform(-0.3, 0.3, (B5, 30))
+    out["otg_jerk_chain30"] = dict(robot="chain30", S=None, q0=q0, K=1500, vmax=np.pi / 3, amax=2 * np.pi, jmax=10 * np.pi,
+                                   events=[(0, "goal", (g1, np.zeros((B5, 30)))), (320, "goal", (g2, np.zeros((B5, 30))))])
     return out
 
 
@@ -131,6 +176,18 @@ def cart_scenarios():
     out["otg_cart_limits_reinit"] = dict(kind="cartesian", robot="panda_arm", q0=q0, K=2400, limits=(0.2, 1.0, 0.8, 3.0),
                                          events=[(0, "goal", g1), (200, "limits", (0.08, 0.6, 0.3, 1.5)), (600, "reinit", (q0, 1)),
                                                  (1000, "reinit", (q_re, 3)), (1000, "goal", g2), (1700, "goal", g3)])
+
+    # 3: jerk-limited mode (MotionForceTask::enableInternalOtgJerkLimited; limits = linear v / a / j, angular v / a / j, the defaults of
+    #    MotionForceTask.h:68-73): pose goals from rest and in flight, limits lowered in flight
+    rngj = np.random.default_rng(0x0C4A)
+    q0 = q_nom + rngj.uniform(-0.2, 0.2, (B, 7))
+    p0, R0 = cart_pose(q0)
+    g1 = (p0 + rngj.uniform(-0.15, 0.15, (B, 3)), W._expm_so3(rngj.uniform(-0.6, 0.6, (B, 3))) @ R0, z3, z3)
+    g1[0][0], g1[1][1] = p0[0], R0[1]
+    g2 = (g1[0] + rngj.uniform(-0.1, 0.1, (B, 3)), W._expm_so3(rngj.uniform(-0.5, 0.5, (B, 3))) @ g1[1], z3, z3)
+    g3 = (p0 + rngj.uniform(-0.05, 0.05, (B, 3)), W._expm_so3(rngj.uniform(-0.2, 0.2, (B, 3))) @ R0, z3, z3)
+    out["otg_cart_jerk_pose_goals"] = dict(kind="cartesian", robot="panda_arm", q0=q0, K=5200, limits=(0.3, 2.0, 10.0, np.pi / 3, 2 * np.pi, 10 * np.pi),
+                                           events=[(0, "goal", g1), (400, "goal", g2), (800, "limits", (0.15, 1.0, 6.0, 0.5, 3.0, 15.0)), (1500, "goal", g3)])
     return out
 
 
@@ -139,7 +196,12 @@ def run_reference_cart(sc):
     q0 = sc["q0"]
     B = q0.shape[0]
     p0, R0 = cart_pose(q0)
-    otg = [R.CartesianOtgRef(p0[i], R0[i], DT, sc["limits"]) for i in range(B)]
+    jerk = len(sc["limits"]) == 6
+    otg = [R.CartesianOtgRef(p0[i], R0[i], DT, sc["limits"] if not jerk else (0.3, 2.0, np.pi / 3, 2 * np.pi)) for i in range(B)]
+    if jerk:   # enableInternalOtgJerkLimited on the default (acceleration-limited) OTG: re-initialised at the current pose first (MotionForceTask.cpp:530-532)
+        for i, o in enumerate(otg):
+            o.reinitialize(p0[i], R0[i], 3)
+            o.set_jerk_limits(sc["limits"])
     goal = [p0.copy(), R0.copy(), np.zeros((B, 3)), np.zeros((B, 3))]   # MotionForceTask::reInitializeTask: goal = current pose
     steps = sample_steps(sc["K"], sc["events"])
     want = set(steps.tolist())
@@ -154,7 +216,10 @@ def run_reference_cart(sc):
                 goal = [np.array(x, float) for x in payload]
             elif kind == "limits":
                 for o in otg:
-                    o.set_limits(payload)
+                    if len(payload) == 6:
+                        o.set_jerk_limits(payload)
+                    else:
+                        o.set_limits(payload)
             elif kind == "reinit":
                 q, mask = payload
                 pr, Rr = cart_pose(q)
@@ -222,6 +287,10 @@ def run_reference(sc):
     vm = np.broadcast_to(np.asarray(sc["vmax"], float), (m,))
     am = np.broadcast_to(np.asarray(sc["amax"], float), (m,))
     otg = [R.JointsOtgRef(x0[i], DT, vm, am) for i in range(B)]
+    if sc.get("jmax") is not None:   # enableInternalOtgJerkLimited on the default OTG: re-initialised at the current position first (JointTask.cpp:400-402)
+        for i, o in enumerate(otg):
+            o.reinitialize(x0[i])
+            o.set_jerk_limits(vm, am, np.broadcast_to(np.asarray(sc["jmax"], float), (m,)))
     gp, gv = x0.copy(), np.zeros_like(x0)   # JointTask::reInitializeTask: goal = current position, zero velocity
     steps = sample_steps(sc["K"], sc["events"])
     want = set(steps.tolist())
@@ -237,7 +306,20 @@ def run_reference(sc):
                 gp, gv = payload[0].copy(), payload[1].copy()
             elif kind == "limits":
                 for o in otg:
-                    o.set_limits(np.broadcast_to(payload[0], (m,)), np.broadcast_to(payload[1], (m,)))
+                    if len(payload) == 3:
+                        o.set_jerk_limits(*(np.broadcast_to(x, (m,)) for x in payload))
+                    else:
+                        o.set_limits(np.broadcast_to(payload[0], (m,)), np.broadcast_to(payload[1], (m,)))
+            elif kind == "mode":   # enableInternalOtg{Jerk,Acceleration}Limited from the other mode: re-initialised at the task's current position
+                which, qcur, lim = payload
+                xc = qcur if S is None else qcur @ S.T
+                for i, o in enumerate(otg):
+                    o.reinitialize(xc[i])
+                    if which == "jerk":
+                        o.set_jerk_limits(*(np.broadcast_to(x, (m,)) for x in lim))
+                    else:
+                        o.set_limits(np.broadcast_to(lim[0], (m,)), np.broadcast_to(lim[1], (m,)))
+                gp, gv = xc.copy(), np.zeros_like(xc)
             elif kind == "reinit":
                 xr = payload if S is None else payload @ S.T
                 for i, o in enumerate(otg):
@@ -258,13 +340,20 @@ def pack(sc, steps, out, reached, moving):
     d = dict(robot=sc["robot"], S=np.zeros((0, 0)) if sc["S"] is None else sc["S"], q0=sc["q0"], K=sc["K"], dt=DT,
              vmax=np.asarray(sc["vmax"], float), amax=np.asarray(sc["amax"], float), steps=steps, desired=out, goal_reached=reached,
              finished_with_velocity=moving, reference_throws=bool(sc.get("reference_throws", False)), n_events=len(sc["events"]))
+    if "jmax" in sc:   # fixtures of the jerk-limited mode only (the acceleration-limited ones keep their round-1 format bit for bit)
+        d["jerk_fixture"] = 1
+        d["jmax"] = np.zeros(0) if sc["jmax"] is None else np.asarray(sc["jmax"], float)
     for i, (st, kind, payload) in enumerate(sc["events"]):
         d[f"ev{i}_step"] = st
         d[f"ev{i}_kind"] = kind
         if kind == "reinit":
             d[f"ev{i}_a"] = payload
+        elif kind == "mode":
+            d[f"ev{i}_a"], d[f"ev{i}_b"], d[f"ev{i}_c"] = payload[0], np.asarray(payload[1], float), np.asarray(payload[2], float)
         else:
             d[f"ev{i}_a"], d[f"ev{i}_b"] = np.asarray(payload[0], float), np.asarray(payload[1], float)
+            if len(payload) == 3:
+                d[f"ev{i}_c"] = np.asarray(payload[2], float)
     return d
 
 
@@ -274,10 +363,20 @@ def load(path):
     ev = []
     for i in range(int(z["n_events"])):
         kind = str(z[f"ev{i}_kind"])
-        ev.append((int(z[f"ev{i}_step"]), kind, z[f"ev{i}_a"] if kind == "reinit" else (z[f"ev{i}_a"], z[f"ev{i}_b"])))
+        if kind == "reinit":
+            pl = z[f"ev{i}_a"]
+        elif kind == "mode":
+            pl = (str(z[f"ev{i}_a"]), z[f"ev{i}_b"], tuple(z[f"ev{i}_c"]))
+        elif f"ev{i}_c" in z:
+            pl = (z[f"ev{i}_a"], z[f"ev{i}_b"], z[f"ev{i}_c"])
+        else:
+            pl = (z[f"ev{i}_a"], z[f"ev{i}_b"])
+        ev.append((int(z[f"ev{i}_step"]), kind, pl))
     S = z["S"]
     sc = dict(robot=str(z["robot"]), S=None if S.size == 0 else S, q0=z["q0"], K=int(z["K"]), vmax=z["vmax"], amax=z["amax"], events=ev,
               reference_throws=bool(z["reference_throws"]))
+    if "jerk_fixture" in z:
+        sc["jmax"] = None if z["jmax"].size == 0 else z["jmax"]
     return sc, z["steps"], z["desired"], z["goal_reached"], dict(finished_with_velocity=int(z["finished_with_velocity"]), dt=float(z["dt"]))
 
 

@@ -44,7 +44,18 @@ def _apply(ev, k, robot, ctrl, jt, state):
         if kind == "goal":
             state["gp"], state["gv"] = payload
         elif kind == "limits":
-            jt.enableInternalOtgAccelerationLimited(payload[0], payload[1])
+            if len(payload) == 3:
+                jt.enableInternalOtgJerkLimited(payload[0], payload[1], payload[2])
+            else:
+                jt.enableInternalOtgAccelerationLimited(payload[0], payload[1])
+        elif kind == "mode":   # the other OTG mode: the wrapper re-initialises the OTG at the task's current position (JointTask.cpp:374-376, 400-402)
+            which, qcur, lim = payload
+            if which == "jerk":
+                jt.enableInternalOtgJerkLimited(*lim)
+            else:
+                jt.enableInternalOtgAccelerationLimited(*lim)
+            xc = qcur if jt.getTaskDof() == qcur.shape[1] else state["gp"] * 0 + (qcur @ state["S"].T)
+            state["gp"], state["gv"] = xc, np.zeros_like(state["gv"])
         elif kind == "reinit":
             robot.setQ(payload)
             robot.updateModel()
@@ -56,9 +67,12 @@ def _apply(ev, k, robot, ctrl, jt, state):
 def test_otg_matches_reference_fixture(path):
     sc, steps, desired, reached, meta = G.load(path)
     robot, ctrl, jt = _controller(sc["robot"], sc["S"], sc["q0"])
-    jt.enableInternalOtgAccelerationLimited(sc["vmax"], sc["amax"])
+    if sc.get("jmax") is not None:
+        jt.enableInternalOtgJerkLimited(sc["vmax"], sc["amax"], sc["jmax"])
+    else:
+        jt.enableInternalOtgAccelerationLimited(sc["vmax"], sc["amax"])
     x0 = sc["q0"] if sc["S"] is None else sc["q0"] @ sc["S"].T
-    state = dict(gp=x0.copy(), gv=np.zeros_like(x0))
+    state = dict(gp=x0.copy(), gv=np.zeros_like(x0), S=sc["S"])
     want = {int(s): r for r, s in enumerate(steps)}
     worst = 0.0
     for k in range(sc["K"]):
@@ -116,6 +130,47 @@ def test_otg_matches_reference_build_random():
             assert g == gr[i] and (r == res[i] or g), (k, i, r, res[i])
             worst = max(worst, err)
     print("random scenarios: max |desired - reference|", worst)
+
+
+def test_jerk_limited_otg_matches_reference_build_random():
+    """jerk-limited mode (third-order profiles) against the reference build on fresh random scenarios: new goals mostly in flight (non-zero
+    velocity and acceleration at the switch), a third with goal velocities, per-joint limits"""
+    import otg_ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libsaip_otg_ref.so did not travel to this box")
+    rng = np.random.default_rng(23)
+    B = 64
+    q_nom = np.array([0.0, -0.436, 0.0, -2.356, 0.0, 1.833, 0.0])
+    q0 = q_nom + rng.uniform(-0.3, 0.3, (B, 7))
+    vm = np.array([1.0, 0.8, 1.2, 0.9, 1.5, 1.1, 2.0])
+    am = np.array([4.0, 3.0, 6.0, 5.0, 8.0, 7.0, 9.0])
+    jm = np.array([30.0, 20.0, 50.0, 40.0, 60.0, 45.0, 80.0])
+    robot, ctrl, jt = _controller("panda_arm", None, q0)
+    jt.enableInternalOtgJerkLimited(vm, am, jm)
+    refs = [R.JointsOtgRef(q0[i], 1e-3, np.pi / 3, 2 * np.pi) for i in range(B)]
+    for i, o in enumerate(refs):
+        o.reinitialize(q0[i])
+        o.set_jerk_limits(vm, am, jm)
+    goal = q0.copy()
+    gvel = np.zeros((B, 7))
+    worst = 0.0
+    for k in range(1200):
+        if k % 170 == 0:
+            goal = q_nom + rng.uniform(-0.9, 0.9, (B, 7))
+            gvel = np.where(rng.uniform(size=(B, 1)) < 0.33, rng.uniform(-0.3, 0.3, (B, 7)), 0.0)
+        jt.setGoalPosition(goal)
+        jt.setGoalVelocity(gvel)
+        ctrl.updateControllerTaskModels()
+        ctrl.computeControlTorques()
+        got = np.stack([jt.getDesiredPosition(), jt.getDesiredVelocity(), jt.getDesiredAcceleration()], axis=1)
+        gr, fl, res = jt.getInternalOtgStatus()
+        for i in range(B):
+            p, v, a, g, r = refs[i].step(goal[i], gvel[i])
+            err = max(np.abs(p - got[i, 0]).max(), np.abs(v - got[i, 1]).max(), np.abs(a - got[i, 2]).max())
+            assert err < TOL, (k, i, err, r, res[i])
+            assert g == gr[i] and (r == res[i] or g), (k, i, r, res[i])
+            worst = max(worst, err)
+    print("jerk-limited random scenarios: max |desired - reference|", worst)
 
 
 def test_control_law_tracks_otg_output():
@@ -191,7 +246,10 @@ def _set_cart_goal(mf, goal):
 def test_cartesian_otg_matches_reference_fixture(path):
     sc, steps, desired, reached, meta = G.load_cart(path)
     robot, ctrl, mf = _cart_controller(sc["q0"])
-    mf.enableInternalOtgAccelerationLimited(*sc["limits"])
+    if len(sc["limits"]) == 6:
+        mf.enableInternalOtgJerkLimited(*sc["limits"])
+    else:
+        mf.enableInternalOtgAccelerationLimited(*sc["limits"])
     B = sc["q0"].shape[0]
     p0, R0 = G.cart_pose(sc["q0"])
     goal = [p0, R0, np.zeros((B, 3)), np.zeros((B, 3))]
@@ -204,7 +262,10 @@ def test_cartesian_otg_matches_reference_fixture(path):
             if kind == "goal":
                 goal = [np.array(x, float) for x in payload]
             elif kind == "limits":
-                mf.enableInternalOtgAccelerationLimited(*payload)
+                if len(payload) == 6:
+                    mf.enableInternalOtgJerkLimited(*payload)
+                else:
+                    mf.enableInternalOtgAccelerationLimited(*payload)
             elif kind == "reinit":
                 q, mask = payload
                 robot.setQ(q)

@@ -493,10 +493,14 @@ def test_call_order_and_otg_are_loud():
     with pytest.raises(sp.SaipError):  # compute before update
         ctrl.computeControlTorques()
     ctrl.updateControllerTaskModels()
-    with pytest.raises(sp.SaipUnsupported):           # jerk-limited OTG (third-order Ruckig profiles): not on the device
-        tasks[1].enableInternalOtgJerkLimited(1.0, 2.0, 10.0)
-    with pytest.raises(sp.SaipUnsupported):
-        tasks[0].enableInternalOtgJerkLimited(0.3, 2.0, 10.0, 1.0, 6.0, 30.0)
+    with pytest.raises(ValueError):                    # OTG_joints::setMaxJerk: "max jerk cannot be 0 or negative" (OTG_joints.cpp:79-83)
+        tasks[1].enableInternalOtgJerkLimited(1.0, 2.0, 0.0)
+    with pytest.raises(ValueError):                    # JointTask.cpp:391-397: vector sizes
+        tasks[1].enableInternalOtgJerkLimited([1.0, 2.0], [1.0, 2.0], [1.0, 2.0])
+    with pytest.raises(ValueError):                    # OTG_6dof_cartesian::setMaxJerk (OTG_6dof_cartesian.cpp:128-132)
+        tasks[0].enableInternalOtgJerkLimited(0.3, 2.0, 10.0, 1.0, 6.0, -30.0)
+    tasks[1].disableInternalOtg()
+    tasks[0].disableInternalOtg()
     ctrl.setGoals(d["goals"])
     assert np.isfinite(ctrl.computeControlTorques()).all()
 

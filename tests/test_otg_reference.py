@@ -42,8 +42,9 @@ def test_cartesian_trajectory_invariants(path):
     assert np.abs(R @ R.transpose(0, 1, 3, 2) - np.eye(3)).max() < 1e-12        # desired orientations are rotations
     lim = np.array(sc["limits"])
     changed = [p for s, k, p in sc["events"] if k == "limits"]
+    ia = 3 if len(lim) == 4 else 4                                               # jerk-limited fixtures: (v, a, j) linear, (v, a, j) angular
     amax_lin = max([lim[1]] + [p[1] for p in changed])
-    amax_ang = max([lim[3]] + [p[3] for p in changed])
+    amax_ang = max([lim[ia]] + [p[ia] for p in changed])
     # per-axis limits: each Cartesian / rotation-vector axis is its own Ruckig dof
     assert np.abs(desired[:, :, 18:21]).max() <= amax_lin + 1e-9
     ang_acc_ref = np.abs(desired[:, :, 21:24]).max()
@@ -75,6 +76,8 @@ def test_fixture_scenarios_match_generator(path):
         assert s1 == s2 and k1 == k2
         if k1 == "reinit":
             assert np.array_equal(p1, p2)
+        elif k1 == "mode":
+            assert p1[0] == p2[0] and np.array_equal(p1[1], p2[1]) and np.allclose(p1[2], p2[2], rtol=0, atol=0)
         else:
             assert np.array_equal(p1[0], np.asarray(p2[0], float)) and np.array_equal(p1[1], np.asarray(p2[1], float))
 
@@ -91,12 +94,14 @@ def test_trajectory_invariants(path):
         vm, am = vmax, amax
         for s, p in lim_events:
             if k >= s:
-                am = np.broadcast_to(p[1], (m,))
+                # (jerk-limited mode: an acceleration above a newly lowered limit comes down at the jerk limit -- the brake
+                # pre-trajectory -- so only the old bound holds right away)
+                am = np.broadcast_to(p[1], (m,)) if len(p) == 2 else np.maximum(amax, np.broadcast_to(p[1], (m,)))
         assert (np.abs(acc[r]) <= am + 1e-9).all()
         if not lim_events:
             assert (np.abs(vel[r]) <= vm + 1e-9).all()
     # acceleration-limited profiles are continuous in position and velocity: |dp| <= vmax_ever * dt * stride
-    if not any(k == "reinit" for _, k, _ in sc["events"]):
+    if not any(k in ("reinit", "mode") for _, k, _ in sc["events"]):   # (a re-initialisation, also the one of a mode switch, jumps)
         dstep = np.diff(steps)[:, None, None]
         assert (np.abs(np.diff(pos, axis=0)) <= np.abs(vel).max() * meta["dt"] * dstep * (1 + 1e-9) + 1e-12).all()
     # where the goal is reached the state sits on the last goal with zero velocity
@@ -104,3 +109,42 @@ def test_trajectory_invariants(path):
     done = reached[-1]
     assert done.sum() >= done.size - 1
     assert np.abs(pos[-1][done] - last_goal[0][done]).max() < 1e-9 and np.abs(vel[-1][done]).max() < 1e-3
+
+
+@pytest.mark.parametrize("path", [p for p in FIX if "jerk" in p], ids=[i for i in IDS if "jerk" in i])
+def test_jerk_limited_trajectories_respect_the_jerk_limit(path):
+    """third-order profiles: the acceleration is continuous and changes by at most max_jerk * dt per control cycle (while the jerk-limited
+    mode is on and away from re-initialisations, which reset the state)"""
+    sc, steps, desired, reached, meta = G.load(path)
+    acc = desired[:, 2]
+    m = acc.shape[-1]
+    jm = None if sc["jmax"] is None else np.broadcast_to(sc["jmax"], (m,)).copy()
+    resets = [s for s, k, _ in sc["events"] if k in ("mode", "reinit")]
+    checked = 0
+    for r in range(1, len(steps)):
+        if steps[r] != steps[r - 1] + 1:
+            continue
+        k = int(steps[r])
+        jcur = jm
+        for s, kind, p in sc["events"]:
+            if s <= k and kind == "limits" and len(p) == 3:
+                jcur = np.maximum(jcur, np.broadcast_to(p[2], (m,))) if jcur is not None else np.broadcast_to(p[2], (m,))
+            if s <= k and kind == "mode":
+                jcur = np.broadcast_to(p[2][2], (m,)) if p[0] == "jerk" else None
+        if jcur is None or any(s - 1 <= k <= s + 1 for s in resets):
+            continue
+        assert (np.abs(acc[r] - acc[r - 1]) <= jcur * meta["dt"] * (1 + 1e-9) + 1e-9).all(), k
+        checked += 1
+    assert checked > 5
+
+
+def test_jerk_limited_core_matches_the_reference_classes():
+    """function level: the product's third-order solver (csrc/saip_otg3.h compiled for the host) against the reference's
+    PositionThirdOrderStep1 / Step2 / BrakeProfile on 60 000 random inputs (oracle/_ref/otg3_compare, built by `make -C oracle ref`)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "otg3_compare")
+    if otg_ref.build() is None or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/otg3_compare not present (built only where /root/reference exists)")
+    r = subprocess.run([exe, "60000"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-400:])
+    assert r.returncode == 0 and "mismatches 0" in r.stdout
