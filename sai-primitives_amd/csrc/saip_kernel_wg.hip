@@ -1265,7 +1265,9 @@ __global__ void saip_reinit_kernel(const CycleParams P) {
 
 // ---------------------------------------------------------------- host-callable launchers
 hipError_t launch_cycle_wg_list(const CycleParams& P, hipStream_t stream) {
-	const int grid = P.B < 256 ? P.B : 256;  // one workgroup per CU: an empty list (the usual case) costs 256 scalar loads, not 1024 workgroup launches (4.6 us measured)
+	// one workgroup per CU.  An empty list (the usual case) still costs a dependent launch: 4.4 - 4.6 us by rocprofv3 whatever the grid (4, 16, 64
+	// or 256 workgroups measured alike, round 3: tools/ab_listgrid.sh) -- the price is the launch, not the 256 scalar loads
+	const int grid = P.B < 256 ? P.B : 256;
 	if (P.n <= 8) {
 		hipLaunchKernelGGL((saip_cycle_wg_list<8, 64>), dim3(grid), dim3(64), 0, stream, P);
 	} else {
