@@ -26,35 +26,57 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (FP32 vector 1
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md:36 (spec; 6290 measured)
 
 
-def cpu_baseline(d, seconds_target=12.0):
-    """The CPU oracle (literal restatement of the reference path, -O2) timed on this box's host cores.
-    Bounded sample of the same workload; this is the ONLY place bench.py touches oracle/."""
+def cpu_baseline(d, seconds_multi=10.0, seconds_single=4.0, passes=1000, warm=100):
+    """The CPU oracle timed on this box's host cores: the LITERAL restatement of the reference path (SVDs, duplicate Jacobians,
+    the JLA model every cycle) and its LEAN variant (closed forms behind certificates, oracle.set_lean), each on all cores and on one thread;
+    `passes` batch-steps after `warm` warm-up steps, MEDIAN pass time.  Bounded: every leg runs on a prefix of the workload sized so that its
+    `warm + passes` steps take about 10 s (all cores) or 4 s (one thread).  This is the ONLY place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     from oracle import Oracle
     cores = min(os.cpu_count() or 1, 16)
-    o = Oracle(d["model"], d["tasks"])
-    q, dq = np.ascontiguousarray(d["q"].T), np.ascontiguousarray(d["dq"].T)
-    goals = [np.ascontiguousarray(g.T) for g in d["goals"]]
-    B = q.shape[1]
-    o.step_soa(q, dq, goals, nthreads=cores)  # warm
-    t0 = time.perf_counter()
-    o.step_soa(q, dq, goals, nthreads=cores)
-    one = max(time.perf_counter() - t0, 1e-4)
-    reps = max(3, min(2000, int(seconds_target / one)))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        o.step_soa(q, dq, goals, nthreads=cores)
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    r1 = max(1, reps // (4 * cores))
-    for _ in range(r1):
-        o.step_soa(q, dq, goals, nthreads=1)
-    dt1 = time.perf_counter() - t0
-    return {"value": B * reps / dt, "unit": "control-cycles/s", "cores": cores, "kind": "port",
-            "sample": f"{B} instances x {reps} passes of the literal CPU restatement (oracle/saip_oracle.c, gcc -O2, pthreads), "
-                      f"{dt:.1f} s; not the Eigen/sai-model binary (cannot be built: Eigen3, sai-model, RBDL absent)",
-            "single_thread_value": B * r1 / dt1}
+    B = d["q"].shape[0]
+
+    def leg(lean, nthreads):
+        o = Oracle(d["model"], d["tasks"])
+        o.set_lean(lean)
+        def slab(bs):
+            return (np.ascontiguousarray(d["q"][:bs].T), np.ascontiguousarray(d["dq"][:bs].T), [np.ascontiguousarray(g[:bs].T) for g in d["goals"]])
+        # all cores: the whole batch per pass (short passes do not spread over the cores: a pass of 256 instances on 8 threads measured SLOWER than
+        # on one), fewer passes when 1000 of them do not fit the budget; one thread: a prefix sized to the budget
+        seconds = seconds_multi if nthreads > 1 else seconds_single
+        q, dq, goals = slab(B if nthreads > 1 else min(B, 256))
+        o.step_soa(q, dq, goals, nthreads=nthreads)
+        one = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            o.step_soa(q, dq, goals, nthreads=nthreads)
+            one = min(one, max(time.perf_counter() - t0, 1e-5))
+        bs, n_pass = q.shape[1], passes
+        if nthreads > 1:
+            n_pass = int(max(20, min(passes, seconds / one / 1.1)))
+        else:
+            bs = int(min(B, max(1, bs / one * seconds / (passes + warm))))
+            q, dq, goals = slab(bs)
+        for _ in range(max(2, n_pass // 10)):
+            o.step_soa(q, dq, goals, nthreads=nthreads)
+        ts = np.empty(n_pass)
+        for i in range(n_pass):
+            t0 = time.perf_counter()
+            o.step_soa(q, dq, goals, nthreads=nthreads)
+            ts[i] = time.perf_counter() - t0
+        return bs / float(np.median(ts)), (bs, n_pass)
+
+    lit, bs_lit = leg(False, cores)
+    lean, bs_lean = leg(True, cores)
+    lit1, bs1 = leg(False, 1)
+    lean1, bs1l = leg(True, 1)
+    return {"value": lit, "unit": "control-cycles/s", "cores": cores, "kind": "port", "statistic": "median pass time; passes/10 warm-up passes before each leg",
+            "lean_value": lean, "single_thread_value": lit1, "lean_single_thread_value": lean1,
+            "sample": f"literal CPU restatement of the reference path (oracle/saip_oracle.c, gcc -O2, pthreads over instances) on {bs_lit[0]} instances "
+                      f"x {bs_lit[1]} passes; lean variant (no SVD where certified, no duplicate Jacobians, no unused JLA model) on {bs_lean[0]} x {bs_lean[1]}; "
+                      f"single-thread legs on the first {bs1[0]} / {bs1l[0]} instances x {bs1[1]} passes; not the Eigen/sai-model binary (cannot be built: Eigen3, "
+                      f"sai-model, RBDL absent)"}
 
 
 def _spawn_ranks(n: int) -> int:

@@ -50,6 +50,7 @@ def lib():
         L.orc_set_passivity.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_set_velocity_saturation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, dp]
         L.orc_reset_state.argtypes = [C.c_void_p]
+        L.orc_set_lean.argtypes = [C.c_void_p, C.c_int]
         L.orc_step_batch.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(dp), dp, C.POINTER(C.c_ubyte), C.c_int]
         L.orc_step_details.argtypes = [C.c_void_p, dp, dp, C.POINTER(dp), dp, dp, dp, dp, dp, dp]
         L.orc_task_step.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
@@ -148,6 +149,11 @@ class Oracle:
 
     def reset_state(self):
         lib().orc_reset_state(self._h)
+
+    def set_lean(self, lean: bool = True):
+        """Lean CPU variant (SURVEY 8(d)): the closed forms of App. A-4 / A-5 behind certificates, no duplicate Jacobians, no unused JLA model;
+        the literal path still runs for every instance a certificate does not cover.  Same results to rounding (tests/test_oracle_lean.py)."""
+        lib().orc_set_lean(self._h, int(bool(lean)))
 
     def set_type1_posture(self, task, q_des):
         """setType1Posture (SingularityHandler.h:140); q_des (n,) or (B,n)"""

@@ -91,6 +91,7 @@ typedef struct {
 	void* popc;    /* [B][popc_tasks] passivity observer states (tasks with enablePassivity), lazily sized */
 	int popc_tasks, popc_slot[MAXT];
 	void* sh;      /* [B][MAXT] blended-strategy states (sh_state), allocated when a task has sing_strategies */
+	int lean;      /* orc_set_lean: the closed forms of SURVEY App. A-4 / A-5 where a certificate allows them (see there), literal path otherwise */
 } orc_ctx;
 
 /* ------------------------------------------------------------------ small dense helpers (row-major) */
@@ -258,6 +259,74 @@ static int matrix_range_basis(const double* A, int rows, int cols, double* U, do
 	for (int i = 0; i < rows; i++)
 		for (int j = 0; j < task_dof; j++) U[i * task_dof + j] = Uf[i * r + j];
 	return task_dof;
+}
+
+/* LEAN variant of matrixRangeBasis (SURVEY 8(d) "lean", App. A-5): column-pivoted Gram-Schmidt instead of the SVD.  Every use of U downstream is
+ * of the form U(...)U^T, so any orthonormal basis of the same range gives the same torques; what has to agree with the literal function is the RANK
+ * decision sigma_i / sigma_0 >= tol.  It is taken only when certified from both sides:
+ *   dropped part:  sigma_{r+1} <= ||A - A_r||_F (residual after r columns) and sigma_0 >= largest column norm  => ratio < tol / 4
+ *   kept part:     sigma_r >= sigma_min(R11) >= 1 / ||R11^-1||_F (the r chosen columns are Q R11) and sigma_0 <= ||A||_F  => ratio > 4 tol
+ * Returns -1 when the certificate fails (the caller then runs the literal SVD form). */
+static int matrix_range_basis_lean(const double* A, int rows, int cols, double* U, double tol) {
+	if (rows == 0 || cols == 0) return -1;
+	double W[MAXN * MAXN], Q[MAXN * MAXN], R[MAXN * MAXN];
+	double nA = fro(A, rows * cols);
+	if (nA < 4 * tol) return -1; /* near the "empty range" test: literal */
+	memcpy(W, A, sizeof(double) * rows * cols);
+	int r = 0, rmax = rows < cols ? rows : cols, piv[MAXN];
+	double first = 0;
+	for (; r < rmax; r++) {
+		int best = -1;
+		double bn = 0, res = 0;
+		for (int j = 0; j < cols; j++) {
+			double a = 0;
+			for (int i = 0; i < rows; i++) a += W[i * cols + j] * W[i * cols + j];
+			res += a;
+			if (a > bn) { bn = a; best = j; }
+		}
+		bn = sqrt(bn);
+		if (r == 0) first = bn;
+		if (sqrt(res) < 0.25 * tol * first) break; /* everything left is certified below the tolerance */
+		if (best < 0) return -1;
+		piv[r] = best;
+		for (int i = 0; i < rows; i++) Q[i * rmax + r] = W[i * cols + best] / bn;
+		for (int j = 0; j < cols; j++) {
+			double d = 0;
+			for (int i = 0; i < rows; i++) d += Q[i * rmax + r] * W[i * cols + j];
+			for (int i = 0; i < rows; i++) W[i * cols + j] -= d * Q[i * rmax + r];
+		}
+	}
+	if (r == 0) return -1;
+	if (r < rmax) { /* residual certificate held at the break; re-check it is not a fall-through */
+		double res = fro(W, rows * cols);
+		if (!(res < 0.25 * tol * first)) return -1;
+	}
+	/* R11 = Q^T A[:, piv] (r x r, upper triangular up to rounding); its inverse by back substitution */
+	for (int a = 0; a < r; a++)
+		for (int b = 0; b < r; b++) {
+			double d = 0;
+			for (int i = 0; i < rows; i++) d += Q[i * rmax + a] * A[i * cols + piv[b]];
+			R[a * r + b] = b >= a ? d : 0;
+		}
+	double inv2 = 0;
+	for (int b = 0; b < r; b++) { /* column b of R11^-1 */
+		double x[MAXN];
+		for (int a = r - 1; a >= 0; a--) {
+			double d = a == b ? 1.0 : 0.0;
+			for (int k2 = a + 1; k2 < r; k2++) d -= R[a * r + k2] * x[k2];
+			if (R[a * r + a] == 0) return -1;
+			x[a] = d / R[a * r + a];
+			inv2 += x[a] * x[a];
+		}
+	}
+	if (!(1.0 / sqrt(inv2) > 4 * tol * nA)) return -1;
+	if (r == rows) {
+		eye(U, rows);
+		return rows;
+	}
+	for (int i = 0; i < rows; i++)
+		for (int j = 0; j < r; j++) U[i * r + j] = Q[i * rmax + j];
+	return r;
 }
 
 /* ------------------------------------------------------------------ robot model (sai-model restatement) */
@@ -595,6 +664,23 @@ static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	int n = c->n, k = t->pos_range + t->ori_range;
 	double U[36], s[6], V[MAXN * 6];
 	tm->k = k;
+	if (c->lean && k == 6 && n >= 6) {
+		/* LEAN: for a full task U_ns is square orthogonal and cancels; the singular values only feed the branch predicates
+		 * s_0 >= s_abs_tol and s_i / s_0 >= s_max.  With G = Jp Jp^T: lambda_max <= tr G, lambda_max >= tr G / 6, 1 / lambda_min <= tr G^-1,
+		 * so tr G >= 6 tol^2 and tr G * tr G^-1 <= 1 / s_max^2 certify the fully non-singular branch; anything else runs the literal code. */
+		double G[36], Gi[36], trG = 0, trGi = 0;
+		mmT(tm->projected_jacobian, tm->projected_jacobian, G, 6, n, 6);
+		if (inverse(G, Gi, 6) == 0) {
+			for (int i = 0; i < 6; i++) { trG += G[i * 7]; trGi += Gi[i * 7]; }
+			if (trG >= 6 * t->s_abs_tol * t->s_abs_tol && trGi > 0 && trG * trGi * t->s_max * t->s_max <= 1.0) {
+				tm->singular = tm->truncated = tm->skip = tm->blend = 0;
+				for (int i = 0; i < 6; i++) tm->sv[i] = NAN; /* not computed on this path */
+				eye(tm->task_range_ns, 6);
+				memcpy(tm->projected_jacobian_ns, tm->projected_jacobian, sizeof(double) * 6 * n);
+				goto nonsingular;
+			}
+		}
+	}
 	svd_thin(tm->projected_jacobian, 6, n, U, s, V); /* :78-81 */
 	int r = n < 6 ? n : 6;
 	for (int i = 0; i < 6; i++) tm->sv[i] = i < r ? s[i] : 0;
@@ -642,6 +728,7 @@ static void sh_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	for (int i = 0; i < 6; i++)
 		for (int j = 0; j < k; j++) tm->task_range_ns[i * k + j] = U[i * r + j]; /* _svd_U.leftCols(...) */
 	mTm(tm->task_range_ns, tm->projected_jacobian, tm->projected_jacobian_ns, 6, k, n);
+nonsingular:;
 	double Jbar[MAXN * 6];
 	op_space_matrices(rs, n, tm->projected_jacobian_ns, k, tm->Lambda_ns, Jbar, tm->N); /* _N = _N_ns :146-148 */
 	switch (t->decoupling) {
@@ -692,9 +779,11 @@ static void mf_compute_torques(const orc_ctx* c, const orc_task* t, const robot_
 	int n = c->n, k = tm->k;
 	double p[3], Jw[6 * MAXN], Rc[9];
 	position_in_world(rs, t->link, t->pos_in_link, p);         /* :286-287 */
-	jacobian_world(c, rs, t->link, p, Jw);
-	mm(t->P, Jw, tm->jacobian, 6, 6, n);                       /* :280-282 (recomputed) */
-	mm(tm->jacobian, tm->N_prec, tm->projected_jacobian, 6, n, n); /* :283 */
+	if (!c->lean) { /* LEAN keeps the Jacobians of updateTaskModel (same model state, same values) */
+		jacobian_world(c, rs, t->link, p, Jw);
+		mm(t->P, Jw, tm->jacobian, 6, 6, n);                       /* :280-282 (recomputed) */
+		mm(tm->jacobian, tm->N_prec, tm->projected_jacobian, 6, n, n); /* :283 */
+	}
 	mm(rs->R[t->link], t->rot_in_link, Rc, 3, 3, 3);           /* :288-289 */
 	const double *xd = goal, *Rd = goal + 3, *vd = goal + 12, *wd = goal + 15, *ad = goal + 18, *ald = goal + 21;
 	double v[3] = {0, 0, 0}, w[3] = {0, 0, 0};
@@ -896,7 +985,8 @@ static void jt_update_task_model(const orc_ctx* c, const orc_task* t, const robo
 	int n = c->n, m = t->m;
 	memcpy(tm->N_prec, N_prec, sizeof(double) * n * n);
 	mm(t->S, tm->N_prec, tm->jt_projected_jacobian, m, n, n); /* :231 */
-	tm->r = matrix_range_basis(tm->jt_projected_jacobian, m, n, tm->current_task_range, 1e-3); /* :233 */
+	tm->r = c->lean ? matrix_range_basis_lean(tm->jt_projected_jacobian, m, n, tm->current_task_range, 1e-3) : -1;
+	if (tm->r < 0) tm->r = matrix_range_basis(tm->jt_projected_jacobian, m, n, tm->current_task_range, 1e-3); /* :233 */
 	tm->empty = 0;
 	if (fro(tm->current_task_range, m * tm->r) == 0) {         /* :234-239 */
 		eye(tm->N, n);
@@ -1130,7 +1220,8 @@ static int orc_instance_cycle(const orc_ctx* c, const double* q, const double* d
 	double N_prec[MAXN * MAXN], N_constraints[MAXN * MAXN], T[MAXN * MAXN];
 	eye(N_prec, n);
 	jla_model jm;
-	jla_update_task_model(c, &rs, N_prec, N_constraints, &jm); /* :71-72, runs even when JLA is disabled */
+	if (c->lean && !c->jla_enabled) eye(N_constraints, n); /* LEAN: the result is unused when JLA is disabled (:96) */
+	else jla_update_task_model(c, &rs, N_prec, N_constraints, &jm); /* :71-72, runs even when JLA is disabled */
 	int status = ST_OK, info = ST_OK;
 	for (int t = 0; t < c->nt; t++) {
 		const orc_task* tk = &c->task[t];
@@ -1388,6 +1479,8 @@ void orc_set_velocity_saturation(orc_ctx* c, int task, int enabled, double lin_s
 	t->vel_sat = enabled; t->lin_sat = lin_sat; t->ang_sat = ang_sat;
 	if (joint_sat) for (int i = 0; i < t->m; i++) t->sat[i] = joint_sat[i];
 }
+/* 1 = lean variant (closed forms of SURVEY App. A-4 / A-5 behind certificates, duplicate Jacobians and the unused JLA model skipped); 0 = literal */
+void orc_set_lean(orc_ctx* c, int lean) { c->lean = lean != 0; }
 void orc_reset_state(orc_ctx* c) {
 	free(c->integ);
 	c->integ = NULL;

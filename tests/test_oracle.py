@@ -296,3 +296,18 @@ def test_matrix_range_basis_decision_at_the_tolerance():
         assert np.abs(tau[b] - tref).max() <= 1e-8 * scale * np.abs(tref).max(), (s, tau[b], tref)
     # dropping the direction changes the answer by orders of magnitude: the two sides of the tolerance are not confusable
     assert np.abs(tau[0]).max() > 50 * np.abs(tau[1]).max() or np.abs(tau[0] - tau[1]).max() > 0.5 * np.abs(tau[0]).max()
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 96), (3, 96), (5, 6), (8, 48), (12, 96), (14, 48)])
+def test_lean_variant_equals_literal(cfg, B):
+    """the lean CPU variant timed by bench.py's cpu_baseline (closed forms behind certificates) gives the literal path's
+    torques and statuses; near-singular instances (config 12 holds them) fail the certificates and run the literal code"""
+    d = W.make_inputs(cfg, B, shard=5)
+    model, tasks = W.load_robot(W.CONFIGS[cfg]["robot"]), W.config_tasks(cfg)
+    lit, lean = Oracle(model, tasks), Oracle(model, tasks)
+    lean.set_lean(True)
+    ta, sa = lit.step(d["q"], d["dq"], d["goals"])
+    tb, sb = lean.step(d["q"], d["dq"], d["goals"])
+    assert np.array_equal(sa, sb)
+    ok = sa != 1
+    assert ok.any() and W.torque_error(tb[ok], ta[ok]) < 1e-9
