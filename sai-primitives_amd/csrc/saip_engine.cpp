@@ -20,6 +20,7 @@ hipError_t launch_reinit(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_lane(const CycleParams& P, hipStream_t stream, bool* supported);
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream);
 hipError_t launch_cycle_wave(const CycleParams& P, hipStream_t stream);
+hipError_t launch_cycle_octjf(const CycleParams& P, hipStream_t stream);
 hipError_t launch_pose(const CycleParams& P, int task, double* out, hipStream_t stream);
 hipError_t launch_otg_joints(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
 hipError_t launch_otg_cartesian(const OtgDev& O, int B, int ld, int mode, hipStream_t stream);
@@ -1434,6 +1435,35 @@ static bool oct_eligible(const saip_batch* b, CycleParams& P) {
 	P.oct_partial_mf = full_mf ? 0 : 1;
 	return true;
 }
+// eight-lanes-per-instance kernel for hierarchies that START with a joint task (saip_kernel_octjf.hip): 7- or 8-dof chain,
+// { JointTask of <= 4 rows, each selecting one joint; full 6-dof MotionForceTask in its nullspace } -- the stack of examples/06.
+// Default or general (open-loop) control laws, any decoupling type, gravity compensation, torque saturation; joint limit avoidance and
+// closed-loop force control keep the stack on the lane kernel.
+static bool octjf_eligible(const saip_batch* b, const CycleParams& P) {
+	const int n = b->model->n;
+	if ((n != 7 && n != 8) || b->tasks.size() != 2 || P.jla) return false;
+	const TaskDev& jt = b->tasks[0].dev;
+	const TaskDev& mf = b->tasks[1].dev;
+	if (jt.type != saip::TASK_JOINT || mf.type != saip::TASK_MOTION_FORCE) return false;
+	if (jt.m < 1 || jt.m > 4 || n - jt.m < 6) return false;  // (fewer than six joints left: the 6-dof task behind is always singular)
+	unsigned seen = 0;
+	for (int a = 0; a < jt.m; a++) {  // rows of S: distinct unit vectors (S then has full row rank: matrixRangeBasis returns the identity)
+		int hit = -1;
+		for (int l = 0; l < n; l++) {
+			const double v = jt.S[a * n + l];
+			if (v == 1.0 && hit < 0) hit = l;
+			else if (v != 0.0) return false;
+		}
+		if (hit < 0 || (seen >> hit & 1u)) return false;
+		seen |= 1u << hit;
+	}
+	if (mf.k != 6 || !mf.bm_identity || mf.cl_force || mf.cl_moment) return false;  // (goal rows 30..35, the sensed force and moment, are only read by the closed-loop laws)
+	for (int i = 0; i < 9; i++) {
+		const double id = (i % 4 == 0) ? 1.0 : 0.0;
+		if (mf.Ppos[i] != id || mf.Pori[i] != id) return false;
+	}
+	return lane_eligible(b);
+}
 // both OTGs of a { MotionForceTask, JointTask } stack on, initialised and with clean limits: their cycle-mode steps share one launch
 static bool otg_pair_ready(saip_batch* b) {
 	if (!(b->tasks.size() == 2 && b->tasks[0].otg_enabled && b->tasks[1].otg_enabled && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE &&
@@ -1477,7 +1507,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		if (!diag && (st = run_otg(b, (int)t, 0))) return st;  // a diagnostic re-launch must not advance the trajectory
 	}
 	bool lane_ok = false;
-	if (!diag && b->kernel_choice == 3 && !oct_eligible(b, P)) return fail(SAIP_ERR_UNSUPPORTED, "the eight-lanes-per-instance kernel does not cover this robot/task stack");
+	if (!diag && b->kernel_choice == 3 && !oct_eligible(b, P) && !octjf_eligible(b, P)) return fail(SAIP_ERR_UNSUPPORTED, "the eight-lanes-per-instance kernel does not cover this robot/task stack");
 	if (!diag && b->kernel_choice != 1 && lane_eligible(b)) {
 		// slow path: instances the lane / eight-lane kernel flags (outside the fully non-singular branch) are recomputed by the general kernel
 		// when a task can handle them there (blended strategies -- the reference default -- or singularity handling disabled: the task is
@@ -1497,6 +1527,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
 		const int oct_max = oct_env ? atoi(oct_env) : 8192;  // four wavefronts per CU (35 KB of LDS each): beyond that the lane kernel wins (measured)
 		const bool oct = oct_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
+		const bool octjf = !oct && octjf_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
 		// the eight-lane kernel runs the blended singularity strategies of the headline stack itself (and passes a fully singular task
 		// through): with the handling enforced nothing is left for a slow path, and what it still refuses the general kernel would too
 		if (oct && P.oct_general_joint == 0 && b->tasks[0].dev.sing_handling) {
@@ -1517,8 +1548,8 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 			HIP_TRY(hipMemsetAsync(P.flag_count, 0, sizeof(int), b->stream));
 			b->flag_clean[b->flag_parity & 1u] = true;
 		}
-		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok);
-		if (oct) lane_ok = true;
+		hipError_t e = oct ? saip::launch_cycle_oct(P, b->stream) : (octjf ? saip::launch_cycle_octjf(P, b->stream) : saip::launch_cycle_lane(P, b->stream, &lane_ok));
+		if (oct || octjf) lane_ok = true;
 		if (slow && lane_ok && e == hipSuccess) {  // the kernel appends to the current pair and zeroes the other one
 			b->flag_clean[b->flag_parity & 1u] = false;
 			b->flag_clean[(b->flag_parity + 1u) & 1u] = true;
@@ -1526,7 +1557,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		}
 		if (lane_ok) {
 			if (e != hipSuccess) return fail(SAIP_ERR_DEVICE, "lane kernel launch failed: %s", hipGetErrorString(e));
-			b->kernel_name = oct ? "saip_cycle_oct" : "saip_cycle_lane";
+			b->kernel_name = oct ? "saip_cycle_oct" : (octjf ? "saip_cycle_octjf" : "saip_cycle_lane");
 			if (slow) {
 				hipError_t e2 = saip::launch_cycle_wg_list(P, b->stream);
 				if (e2 != hipSuccess) return fail(SAIP_ERR_DEVICE, "slow-path kernel launch failed: %s", hipGetErrorString(e2));

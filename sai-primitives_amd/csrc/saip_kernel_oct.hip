@@ -63,46 +63,6 @@ struct OctInst {
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU (one LDS block each, also with two wavefronts per instance group)");
 
-// cyclic Jacobi eigen-solve of a symmetric n x n matrix in LDS by ONE lane (rare exact path): eigenvalues on the diagonal of A,
-// eigenvectors in the columns of V (optional)
-__device__ void oct_serial_jacobi(double* A, double* V, const int n, const int ld) {
-	if (V)
-		for (int i = 0; i < n; i++)
-			for (int j = 0; j < n; j++) V[i * ld + j] = (i == j) ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 14; sweep++) {
-		double off = 0.0, dg = 0.0;
-		for (int p = 0; p < n; p++) {
-			dg = fma(A[p * ld + p], A[p * ld + p], dg);
-			for (int q = p + 1; q < n; q++) off = fma(A[p * ld + q], A[p * ld + q], off);
-		}
-		if (!(off > 1e-36 * dg)) break;
-		for (int p = 0; p < n - 1; p++)
-			for (int q = p + 1; q < n; q++) {
-				const double apq = A[p * ld + q];
-				if (apq == 0.0) continue;
-				const double theta = (A[q * ld + q] - A[p * ld + p]) / (2.0 * apq);
-				const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-				const double c = rsqrt(fma(t, t, 1.0)), s = t * c;
-				for (int k = 0; k < n; k++) {  // A <- A R (columns p, q)
-					const double akp = A[k * ld + p], akq = A[k * ld + q];
-					A[k * ld + p] = c * akp - s * akq;
-					A[k * ld + q] = s * akp + c * akq;
-				}
-				for (int k = 0; k < n; k++) {  // A <- R^T A (rows p, q)
-					const double apk = A[p * ld + k], aqk = A[q * ld + k];
-					A[p * ld + k] = c * apk - s * aqk;
-					A[q * ld + k] = s * apk + c * aqk;
-				}
-				if (V)
-					for (int k = 0; k < n; k++) {
-						const double vkp = V[k * ld + p], vkq = V[k * ld + q];
-						V[k * ld + p] = c * vkp - s * vkq;
-						V[k * ld + q] = s * vkp + c * vkq;
-					}
-			}
-	}
-}
-
 // eigen-decomposition of a symmetric R x R matrix (R = 4, 6) held, identically, by all eight lanes of an instance: round-robin Jacobi.
 // The R/2 rotations of a round touch disjoint index pairs, so they are computed at the same time in different lanes (lane m of each
 // quad takes pair m; the reciprocal / rsqrt chains are most of a rotation's cost), broadcast inside the quad by DPP quad_perm and applied
@@ -176,18 +136,6 @@ __device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R
 		UNR for (int c = 0; c < R; c++) V[i][c] = __shfl(vrow[c], (lane & ~7) | i);
 }
 __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4], const int lane) { oct_jacobi_n<4>(A, V, lane); }
-// inverse of an SPD R x R matrix given by its lower triangle
-template <int R>
-__device__ __forceinline__ void oct_spd_inverse_n(const double (&A)[R][R], double (&Ainv)[R][R]) {
-	double L[R][R], dinv[R], x[R];
-	UNR for (int i = 0; i < R; i++)
-		UNR for (int j = 0; j <= i; j++) L[i][j] = A[i][j];
-	oct_cholesky<R>(L, dinv);
-	UNR for (int col = 0; col < R; col++) {
-		oct_solve_unit<R>(L, dinv, col, x);
-		UNR for (int i = 0; i < R; i++) Ainv[i][col] = x[i];
-	}
-}
 __device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) { oct_spd_inverse_n<4>(A, Ainv); }
 
 
