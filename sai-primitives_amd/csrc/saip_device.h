@@ -20,7 +20,7 @@ static_assert(sizeof(JointRec) == 256, "JointRec must be exactly four cache line
 // one movable body of the serial chain (fixed links already merged on the host, engine.cpp: merge_fixed_links)
 struct ModelDev {
 	int n;
-	int pad_;
+	int all_axis_z;              // every joint axis == (0,0,1) (the usual URDF convention): the eight-lane kernels build R0 Rz(q) from two columns
 	int jtype[SAIP_MAXN];        // 1 revolute, 2 prismatic
 	int axis_is_z[SAIP_MAXN];    // joint axis == (0,0,1) exactly: the joint rotation touches two columns only
 	int iso_inertia[SAIP_MAXN];  // body inertia tensor = i * identity: invariant under rotation

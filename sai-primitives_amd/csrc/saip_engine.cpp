@@ -301,6 +301,9 @@ extern "C" saip_status saip_model_create_serial_chain(const saip_link_desc* link
 		r.axis_is_z = M->dev.axis_is_z[j];
 		r.iso_inertia = M->dev.iso_inertia[j];
 	}
+	M->dev.all_axis_z = 1;
+	for (int j = 0; j < M->n; j++)
+		if (!M->dev.axis_is_z[j]) M->dev.all_axis_z = 0;
 	*out = M;
 	return SAIP_OK;
 }

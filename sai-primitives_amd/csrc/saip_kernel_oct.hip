@@ -55,7 +55,7 @@ struct OctInst {
 		};
 	};
 	double M[8][8];      // lower triangle of M(q), row r by lane r; kept to the end (the blended singularity strategies want M z)
-	double zo[8][6];     // world joint axis z (3), joint origin o (3)
+	double zo[8][6];     // joint motion vector about the world origin S_r = (w, v): revolute (z, o x z), prismatic (0, z)
 	double J[6][8];
 	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3 / 4 row and scalar exchanges, 5 goal force + moment (general laws), 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
 	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
@@ -252,12 +252,20 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		if (md.jtype[rr] == 1) {
 			double s, c;
 			sincos_joint(q_r, &s, &c);
-			const double v = 1.0 - c;
-			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
-								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
-								  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
-			UNR for (int i = 0; i < 3; i++)
-				UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+			if (md.all_axis_z) {  // (batch-uniform) rotation about the local z axis: R0 Rz(q) mixes the first two columns of R0 only
+				UNR for (int i = 0; i < 3; i++) {
+					Tw[3 * i] = R0[3 * i] * c + R0[3 * i + 1] * s;
+					Tw[3 * i + 1] = R0[3 * i + 1] * c - R0[3 * i] * s;
+					Tw[3 * i + 2] = R0[3 * i + 2];
+				}
+			} else {
+				const double v = 1.0 - c;
+				const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+									  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+									  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+				UNR for (int i = 0; i < 3; i++)
+					UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+			}
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
 		} else {
 			UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
@@ -289,18 +297,22 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #undef OCT_PREFIX_STEP
 	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];  // the motion-force task reads its body's frame from here
 	// this lane's world frame is in Tw (padding lane 7: unused)
+	const bool rev = md.jtype[rr] == 1;
 	double z[3], o[3];
 	{
 		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
 		oct_mat3_vec(Tw, a, z);
 		UNR for (int e = 0; e < 3; e++) o[e] = Tw[9 + e];
 	}
-	const bool rev = md.jtype[rr] == 1;
 	// per-body spatial inertia about the world origin
 	double Ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	UNR for (int e = 0; e < 3; e++) {  // (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
-		sm.zo[r][e] = z[e];
-		sm.zo[r][3 + e] = o[e];
+	// this joint's motion vector about the world origin, S_r = (w, v): revolute (z, o x z), prismatic (0, z) -- what M_ir = S_i . (Ic_r S_r) needs
+	// of the other joints (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
+	const double sw[3] = {rev ? z[0] : 0.0, rev ? z[1] : 0.0, rev ? z[2] : 0.0};
+	const double sv[3] = {rev ? (o[1] * z[2] - o[2] * z[1]) : z[0], rev ? (o[2] * z[0] - o[0] * z[2]) : z[1], rev ? (o[0] * z[1] - o[1] * z[0]) : z[2]};
+	UNR for (int e = 0; e < 3; e++) {
+		sm.zo[r][e] = sw[e];
+		sm.zo[r][3 + e] = sv[e];
 	}
 	if (roleA) {
 		double c[3], Bd[10];
@@ -347,26 +359,18 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	STAMP(2);
 	// ---------------------------------------------------------------- M(q): column rr, M_i,rr = S_i . (Ic_rr S_rr), i <= rr
 	if (roleA) {
-		double w[3], v[3];
-		w[0] = rev ? z[0] : 0.0; w[1] = rev ? z[1] : 0.0; w[2] = rev ? z[2] : 0.0;
-		v[0] = rev ? (o[1] * z[2] - o[2] * z[1]) : z[0];
-		v[1] = rev ? (o[2] * z[0] - o[0] * z[2]) : z[1];
-		v[2] = rev ? (o[0] * z[1] - o[1] * z[0]) : z[2];
+		const double* w = sw;
+		const double* v = sv;
 		const double m = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
 		const double f[3] = {m * v[0] + (w[1] * hz - w[2] * hy), m * v[1] + (w[2] * hx - w[0] * hz), m * v[2] + (w[0] * hy - w[1] * hx)};
 		const double nO[3] = {Ic[4] * w[0] + Ic[7] * w[1] + Ic[8] * w[2] + (hy * v[2] - hz * v[1]),
 							  Ic[7] * w[0] + Ic[5] * w[1] + Ic[9] * w[2] + (hz * v[0] - hx * v[2]),
 							  Ic[8] * w[0] + Ic[9] * w[1] + Ic[6] * w[2] + (hx * v[1] - hy * v[0])};
-		// row r of the lower triangle, M[r][i] for i <= r (M_ir = S_i . (Ic_r S_r)); entries beyond the diagonal are written too but never read
+		// row r of the lower triangle, M[r][i] for i <= r: M_ir = S_i . (Ic_r S_r) with the motion vectors S_i = (w_i, v_i) the lanes left in
+		// LDS (one form for revolute and prismatic joints); entries beyond the diagonal are written too but never read
 		double mrow[N];
-		UNR for (int i = 0; i < N; i++) {
-			const double zi[3] = {sm.zo[i][0], sm.zo[i][1], sm.zo[i][2]}, oi[3] = {sm.zo[i][3], sm.zo[i][4], sm.zo[i][5]};
-			const bool revi = md.jtype[i] == 1;
-			const double vi[3] = {oi[1] * zi[2] - oi[2] * zi[1], oi[2] * zi[0] - oi[0] * zi[2], oi[0] * zi[1] - oi[1] * zi[0]};
-			const double vr = zi[0] * nO[0] + zi[1] * nO[1] + zi[2] * nO[2] + vi[0] * f[0] + vi[1] * f[1] + vi[2] * f[2];
-			const double vp = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
-			mrow[i] = revi ? vr : vp;
-		}
+		UNR for (int i = 0; i < N; i++)
+			mrow[i] = sm.zo[i][0] * nO[0] + sm.zo[i][1] * nO[1] + sm.zo[i][2] * nO[2] + sm.zo[i][3] * f[0] + sm.zo[i][4] * f[1] + sm.zo[i][5] * f[2];
 		UNR for (int i = 0; i < N; i++) sm.M[r][i] = mrow[i];
 	}
 	// ---------------------------------------------------------------- MotionForceTask: Jacobian column of this lane's joint

@@ -38,7 +38,7 @@ struct JfInst {
 			double A[6][8];   // Jp M_x^-1 Jp^T (rows 0..5, columns 0..5)
 		};
 	};
-	double zo[8][6];   // world joint axis z (3), joint origin o (3)
+	double zo[8][6];   // joint motion vector about the world origin: angular part w (3), linear part v (3)
 	double M[8][8];    // lower triangle of M(q), row r by lane r (7 dof: row 7 = e_7)
 	double Mi[8][8];   // M^-1
 	double Mb[8][8];   // M_BIE^-1 (= M^-1 when nothing is clamped)
@@ -98,12 +98,20 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 		if (md.jtype[rr] == 1) {
 			double s, c;
 			sincos_joint(q_r, &s, &c);
-			const double v = 1.0 - c;
-			const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
-								  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
-								  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
-			UNR for (int i = 0; i < 3; i++)
-				UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+			if (md.all_axis_z) {  // (batch-uniform) rotation about the local z axis: R0 Rz(q) mixes the first two columns of R0 only
+				UNR for (int i = 0; i < 3; i++) {
+					Tw[3 * i] = R0[3 * i] * c + R0[3 * i + 1] * s;
+					Tw[3 * i + 1] = R0[3 * i + 1] * c - R0[3 * i] * s;
+					Tw[3 * i + 2] = R0[3 * i + 2];
+				}
+			} else {
+				const double v = 1.0 - c;
+				const double Rq[9] = {c + ax * ax * v,      ax * ay * v - az * s, ax * az * v + ay * s,
+									  ay * ax * v + az * s, c + ay * ay * v,      ay * az * v - ax * s,
+									  az * ax * v - ay * s, az * ay * v + ax * s, c + az * az * v};
+				UNR for (int i = 0; i < 3; i++)
+					UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
+			}
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
 		} else {
 			UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
@@ -135,16 +143,20 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	JF_PREFIX_STEP(4)
 #undef JF_PREFIX_STEP
 	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];
+	const bool rev = md.jtype[rr] == 1;
 	double z[3], o[3];
 	{
 		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
 		oct_mat3_vec(Tw, a, z);
 		UNR for (int e = 0; e < 3; e++) o[e] = Tw[9 + e];
 	}
-	const bool rev = md.jtype[rr] == 1;
+	// this joint's motion vector about the world origin, S_r = (w, v): revolute (z, o x z), prismatic (0, z) -- what M_ir = S_i . (Ic_r S_r) needs
+	// of the other joints (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
+	const double sw[3] = {rev ? z[0] : 0.0, rev ? z[1] : 0.0, rev ? z[2] : 0.0};
+	const double sv[3] = {rev ? (o[1] * z[2] - o[2] * z[1]) : z[0], rev ? (o[2] * z[0] - o[0] * z[2]) : z[1], rev ? (o[0] * z[1] - o[1] * z[0]) : z[2]};
 	UNR for (int e = 0; e < 3; e++) {
-		sm.zo[r][e] = z[e];
-		sm.zo[r][3 + e] = o[e];
+		sm.zo[r][e] = sw[e];
+		sm.zo[r][3 + e] = sv[e];
 	}
 	// per-body spatial inertia about the world origin, then the composite inertias of the subtrees (suffix sums by DPP row_shl)
 	double Ic[10];
@@ -189,23 +201,15 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	jf_sync();
 	// ---------------------------------------------------------------- M(q): row r of the lower triangle, M_ir = S_i . (Ic_r S_r), i <= r
 	{
-		double w[3], v[3];
-		w[0] = rev ? z[0] : 0.0; w[1] = rev ? z[1] : 0.0; w[2] = rev ? z[2] : 0.0;
-		v[0] = rev ? (o[1] * z[2] - o[2] * z[1]) : z[0];
-		v[1] = rev ? (o[2] * z[0] - o[0] * z[2]) : z[1];
-		v[2] = rev ? (o[0] * z[1] - o[1] * z[0]) : z[2];
+		const double* w = sw;
+		const double* v = sv;
 		const double ms = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
 		const double f[3] = {ms * v[0] + (w[1] * hz - w[2] * hy), ms * v[1] + (w[2] * hx - w[0] * hz), ms * v[2] + (w[0] * hy - w[1] * hx)};
 		const double nO[3] = {Ic[4] * w[0] + Ic[7] * w[1] + Ic[8] * w[2] + (hy * v[2] - hz * v[1]),
 							  Ic[7] * w[0] + Ic[5] * w[1] + Ic[9] * w[2] + (hz * v[0] - hx * v[2]),
 							  Ic[8] * w[0] + Ic[9] * w[1] + Ic[6] * w[2] + (hx * v[1] - hy * v[0])};
-		UNR for (int i = 0; i < N; i++) {  // (entries beyond the diagonal are written too but never read)
-			const double zi[3] = {sm.zo[i][0], sm.zo[i][1], sm.zo[i][2]}, oi[3] = {sm.zo[i][3], sm.zo[i][4], sm.zo[i][5]};
-			const bool revi = md.jtype[i] == 1;
-			const double vi[3] = {oi[1] * zi[2] - oi[2] * zi[1], oi[2] * zi[0] - oi[0] * zi[2], oi[0] * zi[1] - oi[1] * zi[0]};
-			const double vr = zi[0] * nO[0] + zi[1] * nO[1] + zi[2] * nO[2] + vi[0] * f[0] + vi[1] * f[1] + vi[2] * f[2];
-			const double vp = zi[0] * f[0] + zi[1] * f[1] + zi[2] * f[2];
-			const double mri = revi ? vr : vp;
+		UNR for (int i = 0; i < N; i++) {  // S_i = (w_i, v_i) from LDS; entries beyond the diagonal are written too but never read
+			const double mri = sm.zo[i][0] * nO[0] + sm.zo[i][1] * nO[1] + sm.zo[i][2] * nO[2] + sm.zo[i][3] * f[0] + sm.zo[i][4] * f[1] + sm.zo[i][5] * f[2];
 			sm.M[r][i] = act ? mri : ((i == r) ? 1.0 : 0.0);  // 7 dof: row 7 of the padded matrix is e_7
 		}
 	}

@@ -54,7 +54,11 @@ def test_oct_is_the_default_for_the_headline_batch():
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
     _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert ctrl.kernelName() == "saip_cycle_oct"
-    d = W.make_inputs(6, 64)   # 8-dof chain, joint task first: not covered
+    d = W.make_inputs(6, 64)   # 8-dof chain, joint task first: the joint-first eight-lane kernel (tests/test_gpu_octjf.py)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
+    _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.kernelName() == "saip_cycle_octjf"
+    d = W.make_inputs(13, 64)   # closed-loop force control: not covered by the eight-lane kernels
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 64)
     _cycle(robot, ctrl, d["q"], d["dq"], d["goals"])
     assert ctrl.kernelName() == "saip_cycle_lane"
