@@ -539,15 +539,11 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			}
 			// computeTorques(tau_prec): the reference's _Lambda is never written => no compensation
 			WSTAMP(14 + 10 * t);
-			if (need_N) {  // N_prec <- N N_prec, N^T = I - Jh^T (Lambda T1)
-				double Lm2[2][1] = {{Lam[0][0]}, {Lam[1][0]}}, Jbart[2][2], Nt[8][2], Np2[8][2];
+			if (need_N) {  // N_prec <- N N_prec = N_prec - Jbar (Jh N_prec) with Jbar^T = Lambda T1: a rank-k update in place (24 MFMAs, no n x n temporaries)
+				double Lm2[2][1] = {{Lam[0][0]}, {Lam[1][0]}}, Jbart[2][2], JhN[2][2];
 				wv_mm<false, false>(Lm2, T1, Jbart);
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) Nt[ks][tt] = (4 * ks + hi == 16 * tt + lo) ? 1.0 : 0.0;
-				wv_mm<true, true>(Jh, Jbart, Nt);
-				wv_mm<false, false>(Nt, Np, Np2);
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = Np2[ks][tt];
+				wv_mm<false, false>(Jht, Np, JhN);
+				wv_mm<true, true>(Jbart, JhN, Np);
 			}
 			wv_sync();
 			WSTAMP(15 + 10 * t);
@@ -918,7 +914,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 						wv_mm<false, false>(A, T1, Jbart);   // Lambda T1
 					}
 					__builtin_amdgcn_sched_barrier(0);
-					double Jh[8][2], Nt[8][2], gr[8], y[2];
+					double Jh[8][2], gr[8], y[2];
 					load_Jh(Jh);
 					wv_load_rows(sm.vd, hi, gr);
 					wv_matvec(Jh, gr, y);  // tau += Jh^T g
@@ -927,16 +923,14 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 						sm.tau[16 + lo] += y[1];
 					}
 					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) {
-							Nt[ks][tt] = (4 * ks + hi == 16 * tt + lo) ? 1.0 : 0.0;
+						UNR for (int tt = 0; tt < 2; tt++)
 							if (4 * ks + hi >= r) Jbart[ks][tt] = 0.0;  // the identity padding of Lambda is not part of it
-						}
-					wv_mm<true, true>(Jh, Jbart, Nt);
 					__builtin_amdgcn_sched_barrier(0);
-					double Np2[8][2];
-					wv_mm<false, false>(Nt, Np, Np2);
-					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = Np2[ks][tt];
+					// N_prec <- N N_prec = N_prec - Jbar (Jh N_prec), in place
+					double Jht[8][2], JhN[8][2];
+					load_Jht(Jht);
+					wv_mm<false, false>(Jht, Np, JhN);
+					wv_mm<true, true>(Jbart, JhN, Np);
 				}
 			}
 			// r == 0: no controllable direction left, N = I (JointTask.cpp:234-239)
