@@ -226,6 +226,8 @@ def main():
         raise SystemExit(f"bench: --gpus {args.gpus} but the communicator counts {counted} ranks: no line is printed")
 
     def final_gather():
+        if world == 1:                    # one rank: there is nothing to gather (config.gather says so); no copy is issued
+            return tau_t.unsqueeze(0)
         if native is not None:
             native.gather(gather_out)
             ctrl.synchronize()

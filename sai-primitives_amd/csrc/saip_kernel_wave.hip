@@ -79,6 +79,9 @@ __device__ __forceinline__ double wv_dot6(const double* S, const double* F) {  /
 #ifndef SAIP_WAVE_OCC
 #define SAIP_WAVE_OCC 2  // wavefronts per SIMD the register allocation aims at (A/B knob of tools/oct_variant.sh)
 #endif
+// JLA: RobotController::enableJointLimitAvoidance.  A separate instantiation because the wrap needs M^-1 once more AFTER the task loop: without it
+// the stored M^-1 (32 registers) is dead as soon as the last task has used it.
+template <bool JLA>
 __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const CycleParams P) {
 	__shared__ WaveSmem sm;
 	const int b = blockIdx.x;
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				}
 				wv_sync();
 				WSTAMP(13 + 10 * t);
-				continue;
+				break;  // (!need_N: this was the last task -- leaving the loop here tells the register allocator that M^-1 and N_prec are dead)
 			}
 			// Jp = S N_prec (JointTask.cpp:231)
 			double Wc[8][2];
@@ -945,7 +948,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		const double lim = md.effort[j];
 		tv = tv > lim ? lim : (tv < -lim ? -lim : tv);
 	}
-	if (P.jla && !flagged) {
+	if (JLA && P.jla && !flagged) {
 		// tau = JLA.computeTorques(tau) + N_constraints^T tau,  N_constraints^T = I - S^T (S M^-1 S^T)^-1 S M^-1 (padded to n x n)
 		bool actj = false;
 		double jl = 0.0;
@@ -1018,7 +1021,8 @@ extern "C" int saip_debug_stamps_wave(unsigned long long* out) {
 }
 #endif
 hipError_t launch_cycle_wave(const CycleParams& P, hipStream_t stream) {
-	hipLaunchKernelGGL(saip_cycle_wave, dim3(P.B), dim3(64), 0, stream, P);
+	if (P.jla) hipLaunchKernelGGL(saip_cycle_wave<true>, dim3(P.B), dim3(64), 0, stream, P);
+	else hipLaunchKernelGGL(saip_cycle_wave<false>, dim3(P.B), dim3(64), 0, stream, P);
 	return hipGetLastError();
 }
 
