@@ -20,6 +20,15 @@
  *   - errors: status codes; saip_last_error() returns the text the reference would have thrown as
  *     std::invalid_argument (thread-local).  Nothing is computed on the CPU: every compute entry point
  *     fails with SAIP_ERR_NO_DEVICE when no HIP device is usable.
+ *
+ * Limits (what the reference accepts and this engine does not: every one fails loudly with SAIP_ERR_INVALID_ARGUMENT / _UNSUPPORTED)
+ *   - robots are SERIAL CHAINS (link i's parent is link i - 1; sai-model also reads trees) with at most SAIP_MAX_DOF = 32 movable
+ *     joints, revolute or prismatic; fixed links are merged into their parents.
+ *   - a hierarchy holds at most SAIP_MAX_TASKS = 8 tasks (MotionForceTask / JointTask; RobotController's joint-limit-avoidance task is
+ *     the controller option of saip_batch_enable_joint_limit_avoidance, not a ninth task).
+ *   - a motion-force task of rank 1 (a single controlled direction) is refused: SingularityHandler's own loop leaves such a task with
+ *     stale state in the reference.
+ *   - haptic / teleoperation tasks and everything around the control path (Redis, logging, UI) are out of scope.
  */
 #ifndef SAIP_H_
 #define SAIP_H_
