@@ -59,8 +59,14 @@ __device__ __forceinline__ void jf_sync() {  // one wavefront per workgroup: its
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
-	__shared__ JfInst smem[8];
+// ROLE 0: the whole cycle in one wavefront.  ROLE 1 / 2: wavefronts A / B of the two-wavefront form (batches that fit the chip in one
+// round: <= 2 workgroups per CU): B runs what depends on the frames only -- the motion-force task's control point, the task velocity
+// vw = J dq and the control law (one lane per instance: 150 instructions under a one-lane exec mask) -- and hands (F_um, F_f) over through
+// A's LDS block at the ONE workgroup barrier of the kernel, which A reaches only when it needs the force (behind the factor of Lambda_mod^-1).
+// B keeps its frames in its own small block `bx`; every other synchronisation point is wavefront-local.
+template <int ROLE>
+__device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, double (*bx)[8][12]) {
+	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = 8;
 	const int lane = threadIdx.x & 63;
 	const int r = lane & 7, grp = lane >> 3;
@@ -85,10 +91,17 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
 	const int ra = r < m ? r : 0;
-	const double jg_q = jt.goal[(size_t)ra * ld + b], jg_dq = jt.goal[(size_t)(m + ra) * ld + b], jg_ddq = jt.goal[(size_t)(2 * m + ra) * ld + b];
+	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
+	if (roleA) {
+		jg_q = jt.goal[(size_t)ra * ld + b];
+		jg_dq = jt.goal[(size_t)(m + ra) * ld + b];
+		jg_ddq = jt.goal[(size_t)(2 * m + ra) * ld + b];
+	}
 	const int gc = mf.goal_comps < 32 ? mf.goal_comps : 32;
-	double gl[4];
-	UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? mf.goal[(size_t)(8 * c + r) * ld + b] : 0.0;
+	double gl[4] = {0.0, 0.0, 0.0, 0.0};
+	if (roleB) {
+		UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? mf.goal[(size_t)(8 * c + r) * ld + b] : 0.0;
+	}
 
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
 	double Tw[12];
@@ -121,12 +134,16 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
 		}
 	}
-	sm.vec[0][r] = q_r;
-	sm.vec[1][r] = dq_r;
-	sm.vec[2][r] = jg_q;
-	sm.vec[3][r] = jg_dq;
-	sm.vec[4][r] = jg_ddq;
-	UNR for (int c = 0; c < 4; c++) sm.goal[8 * c + r] = gl[c];
+	if (roleA) {
+		sm.vec[0][r] = q_r;
+		sm.vec[1][r] = dq_r;
+		sm.vec[2][r] = jg_q;
+		sm.vec[3][r] = jg_dq;
+		sm.vec[4][r] = jg_ddq;
+	}
+	if (roleB) {
+		UNR for (int c = 0; c < 4; c++) sm.goal[8 * c + r] = gl[c];
+	}
 #define JF_PREFIX_STEP(D)                                                                                                            \
 	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
 		double Xa[12], Tn[12];                                                                                                      \
@@ -142,7 +159,8 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	JF_PREFIX_STEP(2)
 	JF_PREFIX_STEP(4)
 #undef JF_PREFIX_STEP
-	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];
+	double (*Xf)[12] = (ROLE == 2) ? bx[grp] : sm.X;  // the frames of this wavefront (B: its own block)
+	UNR for (int e = 0; e < 12; e++) Xf[r][e] = Tw[e];
 	const bool rev = md.jtype[rr] == 1;
 	double z[3], o[3];
 	{
@@ -154,13 +172,15 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	// of the other joints (LDS stores are not guarded: the padding lane owns slot 7 of every row and nobody reads it)
 	const double sw[3] = {rev ? z[0] : 0.0, rev ? z[1] : 0.0, rev ? z[2] : 0.0};
 	const double sv[3] = {rev ? (o[1] * z[2] - o[2] * z[1]) : z[0], rev ? (o[2] * z[0] - o[0] * z[2]) : z[1], rev ? (o[0] * z[1] - o[1] * z[0]) : z[2]};
-	UNR for (int e = 0; e < 3; e++) {
-		sm.zo[r][e] = sw[e];
-		sm.zo[r][3 + e] = sv[e];
+	if (roleA) {
+		UNR for (int e = 0; e < 3; e++) {
+			sm.zo[r][e] = sw[e];
+			sm.zo[r][3 + e] = sv[e];
+		}
 	}
 	// per-body spatial inertia about the world origin, then the composite inertias of the subtrees (suffix sums by DPP row_shl)
-	double Ic[10];
-	{
+	double Ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	if (roleA) {
 		double c[3], Bd[10];
 		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
 		oct_mat3_vec(Tw, cl, c);
@@ -186,21 +206,23 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 		UNR for (int e = 0; e < 10; e++) Ic[e] = act ? Bd[e] : 0.0;
 	}
 	// (selects, not multiplications by 0: a neighbouring instance with non-finite state must not leak in)
-	UNR for (int e = 0; e < 10; e++) {
-		const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
-		Ic[e] += (r + 1 < 8) ? up : 0.0;
-	}
-	UNR for (int e = 0; e < 10; e++) {
-		const double up = oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
-		Ic[e] += (r + 2 < 8) ? up : 0.0;
-	}
-	UNR for (int e = 0; e < 10; e++) {
-		const double up = oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
-		Ic[e] += (r + 4 < 8) ? up : 0.0;
+	if (roleA) {
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
+			Ic[e] += (r + 1 < 8) ? up : 0.0;
+		}
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
+			Ic[e] += (r + 2 < 8) ? up : 0.0;
+		}
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
+			Ic[e] += (r + 4 < 8) ? up : 0.0;
+		}
 	}
 	jf_sync();
 	// ---------------------------------------------------------------- M(q): row r of the lower triangle, M_ir = S_i . (Ic_r S_r), i <= r
-	{
+	if (roleA) {
 		const double* w = sw;
 		const double* v = sv;
 		const double ms = Ic[0], hx = Ic[1], hy = Ic[2], hz = Ic[3];
@@ -218,7 +240,7 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	{
 		const int bd = mf.body;
 		double Rb[12];
-		UNR for (int e = 0; e < 12; e++) Rb[e] = sm.X[bd][e];
+		UNR for (int e = 0; e < 12; e++) Rb[e] = Xf[bd][e];
 		oct_mat3_vec(Rb, mf.pos, pw);
 		UNR for (int e = 0; e < 3; e++) pw[e] += Rb[9 + e];
 		UNR for (int i = 0; i < 3; i++)
@@ -232,21 +254,25 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 		jw[3] = (on && rev) ? z[0] : 0.0;
 		jw[4] = (on && rev) ? z[1] : 0.0;
 		jw[5] = (on && rev) ? z[2] : 0.0;
-		UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
-		// the task velocities use the UNprojected Jacobian (MotionForceTask.cpp:293-298): vw = J dq
-		UNR for (int a = 0; a < 6; a++) {
-			const double s = oct_group_sum(jw[a] * dq_r);
-			if (r == 0) sm.vw[a] = s;
+		if (roleA) {
+			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
 		}
-		if (r == 0) {
-			UNR for (int e = 0; e < 3; e++) sm.xp[e] = pw[e];
-			UNR for (int e = 0; e < 9; e++) sm.Rc[e] = Rc[e];
+		if (roleB) {
+			// the task velocities use the UNprojected Jacobian (MotionForceTask.cpp:293-298): vw = J dq
+			UNR for (int a = 0; a < 6; a++) {
+				const double s = oct_group_sum(jw[a] * dq_r);
+				if (r == 0) sm.vw[a] = s;
+			}
+			if (r == 0) {
+				UNR for (int e = 0; e < 3; e++) sm.xp[e] = pw[e];
+				UNR for (int e = 0; e < 9; e++) sm.Rc[e] = Rc[e];
+			}
 		}
 	}
 	jf_sync();
 	// ---------------------------------------------------------------- motion-force control law, one lane per instance (MotionForceTask.cpp:286-509)
 	const bool track_mf = mf.has_ki || P.integ_always;
-	if (r == 0) {
+	if (roleB && r == 0) {
 		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
 		if (track_mf)
 			for (int i = 0; i < 3; i++) {
@@ -285,6 +311,10 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 				mf.integ_new[(size_t)i * ld + b] = ip[i];
 				mf.integ_new[(size_t)(3 + i) * ld + b] = io[i];
 			}
+	}
+	if (ROLE == 2) {  // B is done: (F_um, F_f) are in A's block (and the advanced integrators in HBM) behind this barrier
+		__syncthreads();
+		return;
 	}
 	// ---------------------------------------------------------------- M^-1 (and M_BIE^-1): Cholesky factor in every lane, own column of the inverse
 	// M_BIE = M with the diagonal clamped from below (SingularityHandler.cpp:176-182, JointTask.cpp:253-259); factored a second time only
@@ -464,6 +494,7 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 		}
 	}
 	// ---- Lambda_mod = (Jp M_x^-1 Jp^T)^-1 by its Cholesky factor; tau_mf = Jp^T (Lambda_mod F_um + F_f)  (SingularityHandler.cpp:175-193, 307-309)
+	if (ROLE == 1) __syncthreads();  // the one workgroup barrier: B's force (it has been waiting here for a while)
 	double Fum[6], g[6];
 	UNR for (int a = 0; a < 6; a++) Fum[a] = sm.Fum[a];
 	if (mf.decoupling == DEC_IMPEDANCE) {
@@ -529,9 +560,31 @@ __global__ void __launch_bounds__(64) saip_cycle_octjf(const CycleParams P) {
 	}
 }
 
+template <bool DUO>
+__global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_octjf(const CycleParams P) {
+	__shared__ JfInst smem[8];
+	__shared__ double bx[DUO ? 8 : 1][8][12];  // wavefront B's frames
+	if (DUO) {
+		const bool wave_b = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
+		if (wave_b) jf_body<2>(P, smem, bx);
+		else jf_body<1>(P, smem, bx);
+	} else {
+		jf_body<0>(P, smem, bx);
+	}
+}
+
+// two wavefronts per group of eight instances while the launch fits the chip in one round (<= 2 workgroups per CU), as in saip_kernel_oct.hip
 hipError_t launch_cycle_octjf(const CycleParams& P, hipStream_t stream) {
-	const dim3 grid((P.B + 7) / 8), block(64);
-	hipLaunchKernelGGL(saip_cycle_octjf, grid, block, 0, stream, P);
+	const dim3 grid((P.B + 7) / 8);
+	static const bool duo_on = getenv("SAIP_OCT_NO_DUO") == nullptr;
+	static int cus = 0;
+	if (cus == 0) {
+		int dev = 0, n = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+		cus = n;
+	}
+	if (duo_on && (int)grid.x <= 2 * cus) hipLaunchKernelGGL(saip_cycle_octjf<true>, grid, dim3(128), 0, stream, P);
+	else hipLaunchKernelGGL(saip_cycle_octjf<false>, grid, dim3(64), 0, stream, P);
 	return hipGetLastError();
 }
 
