@@ -168,3 +168,62 @@ def test_non_unit_selection_rows_stay_on_the_lane_kernel():
     goals = [np.concatenate([d["q"] @ S.T, np.zeros((64, 4))], axis=1), d["goals"][1]]
     _run(robot, ctrl, d["q"], d["dq"], goals)
     assert ctrl.kernelName() == "saip_cycle_lane"
+
+
+def _random_joint_first_spec(rng):
+    """every scalar option of the { partial JointTask, full MotionForceTask } stack drawn at random (the style of tests/test_gpu_fuzz.py)"""
+    rows = [[0, 7], [7, 0], [0], [7], [7, 1], [0, 3]][rng.integers(6)]
+    m = len(rows)
+    aniso = rng.random() < 0.5
+    jt = W.joint_task("partial_joint_task", S=rows, kp=list(rng.uniform(20, 120, m)) if aniso else float(rng.uniform(20, 120)),
+                      kv=list(rng.uniform(8, 25, m)) if aniso else float(rng.uniform(8, 25)))
+    mf = W.motion_force_task("motion_force_task", "end-effector", tuple(rng.uniform(-0.05, 0.1, 3)))
+    mf["kp_pos"] = list(rng.uniform(50, 200, 3)) if aniso else float(rng.uniform(50, 200))
+    mf["kv_pos"] = list(rng.uniform(10, 30, 3)) if aniso else float(rng.uniform(10, 30))
+    mf["kp_ori"] = list(rng.uniform(100, 300, 3)) if aniso else float(rng.uniform(100, 300))
+    mf["kv_ori"] = list(rng.uniform(15, 35, 3)) if aniso else float(rng.uniform(15, 35))
+    if rng.random() < 0.5:
+        mf["ki_pos"], mf["ki_ori"] = float(rng.uniform(0, 8)), float(rng.uniform(0, 8))
+        jt["ki"] = float(rng.uniform(0, 5))
+    dec = [W.FULL_DYNAMIC_DECOUPLING, W.BOUNDED_INERTIA_ESTIMATES, W.BOUNDED_INERTIA_ESTIMATES, W.IMPEDANCE]
+    mf["decoupling"], jt["decoupling"] = dec[rng.integers(4)], dec[rng.integers(4)]
+    mf["bie_threshold"] = jt["bie_threshold"] = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
+    if rng.random() < 0.4:
+        jt.update(vel_sat=True, sat=float(rng.uniform(0.2, 1.0)))
+    if rng.random() < 0.3:
+        mf.update(vel_sat=True, lin_sat=float(rng.uniform(0.02, 0.3)), ang_sat=float(rng.uniform(0.1, 1.0)))
+    mf["dt"] = jt["dt"] = float(rng.choice([5e-4, 1e-3, 2e-3]))
+    smax = float(rng.uniform(3e-2, 9e-2))
+    mf["s_max"], mf["s_min"] = smax, smax * float(rng.uniform(0.05, 0.5))
+    return [jt, mf], dict(gravity_comp=bool(rng.random() < 0.5), torque_saturation=bool(rng.random() < 0.5))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_option_combinations_match_oracle(seed):
+    """random option combinations on the 8-dof arm, a quarter of the batch with the elbow nearly straight (flagged, recomputed behind by the
+    blended strategies), three cycles of a drifting state, batches on both sides of the two- / one-wavefront boundary"""
+    from oracle import Oracle
+    rng = np.random.default_rng(4200 + seed)
+    B = int(rng.choice([96, 1000, 4100]))
+    spec, opts = _random_joint_first_spec(rng)
+    d = W.make_inputs(6, B, shard=1)
+    model = d["model"]
+    q0 = d["q"].copy()
+    q0[0::4, 4] = rng.uniform(-0.04, 0.04, q0[0::4, 4].shape)
+    S = W.joint_selection(spec[0], 8)
+    goals = [np.concatenate([q0 @ S.T + rng.uniform(-0.3, 0.3, (B, S.shape[0])), rng.uniform(-0.1, 0.1, (B, S.shape[0])), rng.uniform(-0.5, 0.5, (B, S.shape[0]))], axis=1),
+             d["goals"][1]]
+    robot, ctrl, _ = _engine(model.name, spec, B, 0)
+    ctrl.enableGravityCompensation(opts["gravity_comp"])
+    ctrl.enableTorqueSaturation(opts["torque_saturation"])
+    orc = Oracle(model, spec, **opts)
+    for cyc in range(3):
+        q = q0 + 0.004 * cyc
+        tau = _run(robot, ctrl, q, d["dq"], goals).copy()
+        assert ctrl.kernelName() == "saip_cycle_octjf"
+        ref, st = orc.step(q, d["dq"], goals, nthreads=8)
+        ok, plain = st != 1, st == 0
+        assert np.array_equal(ctrl.status & 9, st & 9)
+        e0, e1 = W.torque_error(tau[plain], ref[plain]), W.torque_error(tau[ok], ref[ok])
+        print(f"seed {seed} B {B} rows {spec[0]['S']} cycle {cyc}: err {e0:.2e} (with blended instances {e1:.2e}), blended {int(((st & 8) > 0).sum())}, refused {int((~ok).sum())}")
+        assert plain.sum() > B // 2 and e0 < TOL and e1 < 1e-6
