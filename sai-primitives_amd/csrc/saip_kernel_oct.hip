@@ -58,7 +58,9 @@ struct OctInst {
 	double zo[8][6];     // joint motion vector about the world origin S_r = (w, v): revolute (z, o x z), prismatic (0, z)
 	double J[6][8];
 	double vec[13][8];   // 0 dq, 1 tau, 2 g, 3 / 4 row and scalar exchanges, 5 goal force + moment (general laws), 7 u, 8 d, 9 flags, 10..12 motion-force goal (24)
-	double pad_[10];     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+	double ist[10];      // integrator state, fetched with the inputs: 0..5 motion-force task (position, orientation), 6..9 the rows of a Gram-path joint
+	                     // task; the control law leaves the advanced motion-force values here for the epilogue.  (Also the padding that makes the
+	                     // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks.)
 };
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU (one LDS block each, also with two wavefronts per instance group)");
@@ -243,6 +245,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
 	}
 
+	// integrator state: requested with the inputs, committed from registers / LDS in the epilogue (the loads used to sit in front of the control
+	// laws and the commit re-read a shadow copy from HBM: 3.1 us per launch with the integrators on, measured; now 0.3)
+	const bool track_mf = (mf.has_ki || P.integ_always), track_jt = (jt.has_ki || P.integ_always);
+	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;
+	if (roleB && track_mf && r < 6) mfi_pre = mf.integ[(size_t)r * ld + b];
+	if (roleA && track_jt) jti_pre = jt.integ[(size_t)(GJ == 1 ? rj : rr) * ld + b];
+
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
 	double Tw[12];
@@ -280,6 +289,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
 	sm.vec[5][r] = gl3;
+	if (roleB && r < 6) sm.ist[r] = mfi_pre;
+	if (roleA && GJ == 1 && r < 4) sm.ist[6 + r] = jti_pre;
 #define OCT_PREFIX_STEP(D)                                                                                                          \
 	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
 		double Xa[12], Tn[12];                                                                                                      \
@@ -760,14 +771,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	STAMP(9);
 	double Fum6[6], Ff6[6] = {0, 0, 0, 0, 0, 0};  // GJ == 0: the task forces, identical in every lane of the instance
 	// ---- control law (MotionForceTask.cpp:286-509 with sigma_force = sigma_moment = 0, OTG off), every lane alike
-	const bool track_mf = (mf.has_ki || P.integ_always);
 	if (roleB) {
 		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, Fum[6], G24[24];
 		UNR for (int e = 0; e < 24; e++) G24[e] = sm.vec[10 + (e >> 3)][e & 7];
 		if (track_mf) {
 			UNR for (int i = 0; i < 3; i++) {
-				ip[i] = mf.integ[(size_t)i * ld + b];
-				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
+				ip[i] = sm.ist[i];
+				io[i] = sm.ist[3 + i];
 			}
 		}
 		if (FULL && mf.general_law) {
@@ -822,10 +832,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		UNR for (int i = 0; i < 3; i++) io[i] = fma(oe[i], mf.dt, io[i]);
 		UNR for (int i = 0; i < 3; i++) Fum[3 + i] = G24[21 + i] - mf.kp_ori[i] * oe[i] - mf.kv_ori[i] * (vw[3 + i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
 		}
-		if (track_mf && live && r == 0) {  // shadow copy: committed in the epilogue once the final status is known (the joint task may still flag the instance)
+		if (track_mf && r == 0) {  // left in LDS: committed in the epilogue once the final status is known (the joint task may still flag the instance)
 			UNR for (int i = 0; i < 3; i++) {
-				mf.integ_new[(size_t)i * ld + b] = ip[i];
-				mf.integ_new[(size_t)(3 + i) * ld + b] = io[i];
+				sm.ist[i] = ip[i];
+				sm.ist[3 + i] = io[i];
 			}
 		}
 		if (trunc_mode) {  // task_range_ns^T F_um (SingularityHandler.cpp:321-322); the identity for instances that were not reduced
@@ -990,10 +1000,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		// control law of this lane's joint (JointTask.cpp:299-345)
 		const bool track = (jt.has_ki || P.integ_always);
 		const double e = q_r - jg_q;
-		double ie = 0.0;
-		if (track) ie = jt.integ[(size_t)rr * ld + b];
+		double ie = track ? jti_pre : 0.0;
 		ie += e * jt.dt;  // :323-324
-		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
+		jt_ie_new = ie;
 		if (jt.vel_sat) {  // :327-341
 			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
 			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
@@ -1677,10 +1686,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			const bool row = i < mj;
 			const double gq = row ? sm.vec[7][i] : 0.0, gdq = row ? sm.vec[8][i] : 0.0, gddq = row ? sm.vec[3][i] : 0.0;
 			const double e = cur - gq;
-			double ie = 0.0;
-			if (track && row) ie = jt.integ[(size_t)i * ld + b];
+			double ie = (track && row) ? sm.ist[6 + i] : 0.0;
 			ie += e * jt.dt;  // :323-324
-			if (track && row && live && r == 0) jt.integ_new[(size_t)i * ld + b] = ie;
+			jt_ie_new = (r == i) ? ie : jt_ie_new;  // lane i keeps row i for the epilogue
 			double fi;
 			if (jt.vel_sat) {  // :327-341
 				double vdes = -jt.kp[i] * jt.kvinv[i] * e - jt.ki[i] * jt.kvinv[i] * ie;
@@ -1820,10 +1828,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		// control law of this lane's joint (JointTask.cpp:285-356), its range coordinates by sums over the lanes
 		const bool track = (jt.has_ki || P.integ_always);
 		const double e = q_r - jg_q;
-		double ie = 0.0;
-		if (track) ie = jt.integ[(size_t)rr * ld + b];
+		double ie = track ? jti_pre : 0.0;
 		ie += e * jt.dt;
-		if (track && live && act) jt.integ_new[(size_t)r * ld + b] = ie;
+		jt_ie_new = ie;
 		double fi;
 		if (jt.vel_sat) {
 			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
@@ -1922,19 +1929,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}  // work list of the device-side slow path
 	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;                       // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged (then nothing advances: the slow path
-	// launched behind recomputes it from the untouched state, or it stays invalid); the lanes that wrote the shadow rows copy them
+	// launched behind recomputes it from the untouched state, or it stays invalid).  Motion-force rows from the LDS block of the wavefront
+	// that ran the law (B's block outlives B), joint rows from the lane that owns them.
 	if (live && !singular) {
-		if (track_mf && r == 0) {
-			UNR for (int i = 0; i < 6; i++) mf.integ[(size_t)i * ld + b] = mf.integ_new[(size_t)i * ld + b];
-		}
-		if (jt.has_ki || P.integ_always) {
-			if (GJ == 1) {
-				if (r == 0)
-					for (int i = 0; i < mj; i++) jt.integ[(size_t)i * ld + b] = jt.integ_new[(size_t)i * ld + b];
-			} else if (act) {
-				jt.integ[(size_t)r * ld + b] = jt.integ_new[(size_t)r * ld + b];
-			}
-		}
+		if (track_mf && r < 6) mf.integ[(size_t)r * ld + b] = (ROLE == 1 ? smB : sm).ist[r];
+		if (track_jt && (GJ == 1 ? r < mj : act)) jt.integ[(size_t)r * ld + b] = jt_ie_new;
 	}
 	STAMP(15);
 }

@@ -48,7 +48,9 @@ struct JfInst {
 	double vec[8][8];  // 0 q, 1 dq, 2..4 joint goal (position, velocity, acceleration rows), 5 flags
 	double goal[32];   // motion-force goal: x3 R9 v3 w3 a3 alpha3 (+ f3 m3 of the general laws)
 	double vw[8], xp[4], Rc[12], Fum[8], Ff[8];
-	double pad_[10];   // instance stride = 2 (mod 32) doubles: the eight instances of a wavefront hit different LDS banks
+	double ist[10];    // integrator state, fetched with the inputs: 0..5 motion-force task, 6..9 joint task rows; the control laws leave the advanced
+	                   // values for the epilogue (motion-force: here; joint: in the owning lane).  (Also the padding that makes the instance stride = 2
+	                   // (mod 32) doubles: the eight instances of a wavefront hit different LDS banks.)
 };
 static_assert(sizeof(JfInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(JfInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU");
@@ -97,6 +99,10 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		jg_dq = jt.goal[(size_t)(m + ra) * ld + b];
 		jg_ddq = jt.goal[(size_t)(2 * m + ra) * ld + b];
 	}
+	const bool track_mf = mf.has_ki || P.integ_always, track_jt = jt.has_ki || P.integ_always;
+	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;  // integrator state: requested with the inputs, committed from LDS / registers in the epilogue
+	if (roleB && track_mf && r < 6) mfi_pre = mf.integ[(size_t)r * ld + b];
+	if (roleA && track_jt) jti_pre = jt.integ[(size_t)ra * ld + b];
 	const int gc = mf.goal_comps < 32 ? mf.goal_comps : 32;
 	double gl[4] = {0.0, 0.0, 0.0, 0.0};
 	if (roleB) {
@@ -140,9 +146,11 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		sm.vec[2][r] = jg_q;
 		sm.vec[3][r] = jg_dq;
 		sm.vec[4][r] = jg_ddq;
+		if (r < 4) sm.ist[6 + r] = jti_pre;
 	}
 	if (roleB) {
 		UNR for (int c = 0; c < 4; c++) sm.goal[8 * c + r] = gl[c];
+		if (r < 6) sm.ist[r] = mfi_pre;
 	}
 #define JF_PREFIX_STEP(D)                                                                                                            \
 	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
@@ -271,13 +279,12 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	}
 	jf_sync();
 	// ---------------------------------------------------------------- motion-force control law, one lane per instance (MotionForceTask.cpp:286-509)
-	const bool track_mf = mf.has_ki || P.integ_always;
 	if (roleB && r == 0) {
 		double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0};
 		if (track_mf)
 			for (int i = 0; i < 3; i++) {
-				ip[i] = mf.integ[(size_t)i * ld + b];
-				io[i] = mf.integ[(size_t)(3 + i) * ld + b];
+				ip[i] = sm.ist[i];
+				io[i] = sm.ist[3 + i];
 			}
 		if (mf.general_law) {  // velocity saturation, force / moment spaces with open-loop force control
 			const double(&G)[32] = sm.goal;
@@ -306,10 +313,10 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 			UNR for (int i = 0; i < 3; i++) sm.Fum[3 + i] = mf.sig_o[3 * i] * tmp[0] + mf.sig_o[3 * i + 1] * tmp[1] + mf.sig_o[3 * i + 2] * tmp[2];
 			UNR for (int i = 0; i < 6; i++) sm.Ff[i] = 0.0;
 		}
-		if (track_mf && live)
+		if (track_mf)
 			for (int i = 0; i < 3; i++) {
-				mf.integ_new[(size_t)i * ld + b] = ip[i];
-				mf.integ_new[(size_t)(3 + i) * ld + b] = io[i];
+				sm.ist[i] = ip[i];
+				sm.ist[3 + i] = io[i];
 			}
 	}
 	if (ROLE == 2) {  // B is done: (F_um, F_f) are in A's block (and the advanced integrators in HBM) behind this barrier
@@ -369,17 +376,15 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 			sm.W[r][a] = (a < m) ? s : 0.0;
 		}
 		// control law of the task rows (JointTask.cpp:294-356); tau_prec = 0, nothing to compensate (:285-292)
-		const bool track = jt.has_ki || P.integ_always;
 		double ai[4], fi[4];
 		UNR for (int a = 0; a < 4; a++) {
 			const bool row = a < m;
 			const double cur = sm.vec[0][idx[a]], vel = sm.vec[1][idx[a]];
 			const double gq = sm.vec[2][a], gdq = sm.vec[3][a], gddq = sm.vec[4][a];
 			const double e = cur - gq;
-			double ie = 0.0;
-			if (track && row) ie = jt.integ[(size_t)a * ld + b];
+			double ie = (track_jt && row) ? sm.ist[6 + a] : 0.0;
 			ie += e * jt.dt;  // :323-324
-			if (track && row && live && r == 0) jt.integ_new[(size_t)a * ld + b] = ie;
+			jt_ie_new = (r == a) ? ie : jt_ie_new;  // lane a keeps row a for the epilogue
 			double f;
 			if (jt.vel_sat) {  // :327-341
 				double vdes = -jt.kp[a] * jt.kvinv[a] * e - jt.ki[a] * jt.kvinv[a] * ie;
@@ -552,11 +557,9 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	}  // work list of the device-side slow path
 	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;  // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged
-	if (live && !singular && r == 0) {
-		if (track_mf)
-			for (int i = 0; i < 6; i++) mf.integ[(size_t)i * ld + b] = mf.integ_new[(size_t)i * ld + b];
-		if (jt.has_ki || P.integ_always)
-			for (int i = 0; i < m; i++) jt.integ[(size_t)i * ld + b] = jt.integ_new[(size_t)i * ld + b];
+	if (live && !singular) {
+		if (track_mf && r < 6) mf.integ[(size_t)r * ld + b] = sm.ist[r];
+		if (track_jt && r < m) jt.integ[(size_t)r * ld + b] = jt_ie_new;
 	}
 }
 
