@@ -251,6 +251,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;
 	if (roleB && track_mf && r < 6) mfi_pre = mf.integ[(size_t)r * ld + b];
 	if (roleA && track_jt) jti_pre = jt.integ[(size_t)(GJ == 1 ? rj : rr) * ld + b];
+	double jkp_r = 0.0, jkv_r = 0.0, jki_r = 0.0;  // this lane's joint gains (per-lane loads: requested here, used by the control law behind M)
+	if (roleA && GJ != 1) {
+		jkp_r = jt.kp[rr];
+		jkv_r = jt.kv[rr];
+		jki_r = jt.ki[rr];
+	}
 
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -409,6 +415,23 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 		} else {
 			UNR for (int a = 0; a < 6; a++) sm.J[a][r] = jw[a];
+		}
+	}
+	// control law of this lane's joint (JointTask.cpp:299-345; full joint task, GJ != 1): it depends on the inputs only, so it runs here, behind the
+	// mass matrix (its operands -- requested with the inputs -- have long arrived), and not in the tail of the cycle where its gain loads -- per-lane loads that cannot be hoisted above
+	// the fences in between -- would sit on the critical path
+	double fi_pre = 0.0;
+	if (roleA && GJ != 1) {
+		const double e = q_r - jg_q;
+		double ie = track_jt ? jti_pre : 0.0;
+		ie += e * jt.dt;  // :323-324
+		jt_ie_new = ie;
+		if (jt.vel_sat) {  // :327-341
+			double vdes = -jkp_r * jt.kvinv[rr] * e - jki_r * jt.kvinv[rr] * ie;
+			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
+			fi_pre = -jkv_r * (dq_r - vdes);
+		} else {
+			fi_pre = -jkp_r * e - jkv_r * (dq_r - jg_dq) - jki_r * ie;  // :342-345
 		}
 	}
 	if (DUO && !trunc_mode) __syncthreads();  // workgroup barrier: B's Jacobian is complete (A arrives ~1 k clocks after B)
@@ -997,19 +1020,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}  // roleB
 		double fi = 0.0;
 		if (roleA) {
-		// control law of this lane's joint (JointTask.cpp:299-345)
-		const bool track = (jt.has_ki || P.integ_always);
-		const double e = q_r - jg_q;
-		double ie = track ? jti_pre : 0.0;
-		ie += e * jt.dt;  // :323-324
-		jt_ie_new = ie;
-		if (jt.vel_sat) {  // :327-341
-			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
-			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
-			fi = -jt.kv[rr] * (dq_r - vdes);
-		} else {
-			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;  // :342-345
-		}
+		fi = fi_pre;  // (the joint control law ran behind the frames)
 		}
 		double tvo = 0.0;
 		bool ovr = false;
@@ -1825,20 +1836,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			UNR for (int c = 0; c < 5; c++)
 				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = fma(gamma * lt[c], lt[k5], Lam5[c][k5]);
 		}
-		// control law of this lane's joint (JointTask.cpp:285-356), its range coordinates by sums over the lanes
-		const bool track = (jt.has_ki || P.integ_always);
-		const double e = q_r - jg_q;
-		double ie = track ? jti_pre : 0.0;
-		ie += e * jt.dt;
-		jt_ie_new = ie;
-		double fi;
-		if (jt.vel_sat) {
-			double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
-			vdes = fmin(fmax(vdes, -jt.sat[rr]), jt.sat[rr]);
-			fi = -jt.kv[rr] * (dq_r - vdes);
-		} else {
-			fi = -jt.kp[rr] * e - jt.kv[rr] * (dq_r - jg_dq) - jt.ki[rr] * ie;
-		}
+		// (the control law of this lane's joint ran behind the frames: fi_pre); its range coordinates by sums over the lanes
+		const double fi = fi_pre;
 		const double ai = jg_ddq - wr;
 		double a1[5], b1[5];
 		UNR for (int c = 0; c < 5; c++) {
