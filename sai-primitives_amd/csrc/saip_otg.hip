@@ -674,18 +674,16 @@ __device__ __noinline__ void o3_phase_check(otg3::P3& ph, const int cs, const do
 	*ok = (cs == otg3::UDDU) ? otg3::o3_check_jf<otg3::UDDU, otg3::L_NONE>(ph, jf, vMax, vMin, aMax, aMin, jMax)
 							 : otg3::o3_check_jf<otg3::UDUD, otg3::L_NONE>(ph, jf, vMax, vMin, aMax, aMin, jMax);
 }
+// the trajectory calculation (only lane groups whose input changed get here): out of line, on a COPY of the lane state -- a state struct whose
+// address escapes into a call cannot be kept in registers, and the per-cycle sampling path around this call must not pay for that
 template <int GS>
-__device__ __noinline__ int ruckig_update3(const Grp<GS>& g, bool act, bool run, int m, double vMax, double aMax, double jMax, bool new_limits, double dt, Lane& L,
-										   int& flags, double& time, double& duration, bool* new_traj) {
+__device__ __noinline__ int ruckig_calc3(const Grp<GS>& g, bool act, bool need_calc, int m, double vMax, double aMax, double jMax, Lane& L, int& flags, double& time,
+										 double& duration, bool* new_traj) {
 	using namespace otg3;
 	const int dof = g.dof;
 	const double vMin = -vMax, aMin = -aMax;
 	int result = 0;
-	*new_traj = false;
-	const bool differs = act && !(L.in_p == L.ci_p && L.in_v == L.ci_v && L.in_a == L.ci_a && L.tg_p == L.ci_tp && L.tg_v == L.ci_tv);
-	const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
-
-	if (g.any(need_calc)) {
+	{
 		// validate_input (input_parameter.hpp:155-330, check_target_state_within_limits only; the target acceleration is always 0 here)
 		bool bad = act && need_calc && (isnan(L.in_p) || isnan(L.in_v) || isnan(L.in_a) || isnan(L.tg_p) || isnan(L.tg_v) || L.tg_v > vMax || L.tg_v < vMin);
 		int err = g.any(bad) ? -100 : 0;
@@ -830,6 +828,29 @@ __device__ __noinline__ int ruckig_update3(const Grp<GS>& g, bool act, bool run,
 				*new_traj = true;
 			}
 		}
+	}
+	return result;
+}
+
+template <int GS>
+__device__ __forceinline__ int ruckig_update3(const Grp<GS>& g, bool act, bool run, int m, double vMax, double aMax, double jMax, bool new_limits, double dt, Lane& L,
+											  int& flags, double& time, double& duration, bool* new_traj) {
+	using namespace otg3;
+	int result = 0;
+	*new_traj = false;
+	const bool differs = act && !(L.in_p == L.ci_p && L.in_v == L.ci_v && L.in_a == L.ci_a && L.tg_p == L.ci_tp && L.tg_v == L.ci_tv);
+	const bool need_calc = run && (g.any(differs) || !(flags & OTG_FLAG_RUCKIG_INIT) || new_limits);
+	if (g.any(need_calc)) {
+		Lane Lc = L;
+		int fl = flags;
+		double tm = time, du = duration;
+		bool nt = false;
+		result = ruckig_calc3<GS>(g, act, need_calc, m, vMax, aMax, jMax, Lc, fl, tm, du, &nt);
+		L = Lc;
+		flags = fl;
+		time = tm;
+		duration = du;
+		*new_traj = nt;
 	}
 
 	if (run && result == 0) {
