@@ -58,6 +58,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(oct_exact_obj), exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", "-DSAIP_OCT_FORCE_EXACT", "-o", oct_exact_obj] + sched[oct_rel] + extra + [os.path.join(_DIR, oct_rel)]
     procs.append((cmd, subprocess.Popen(cmd)))
+    jf_rel = "csrc/saip_kernel_octjf.hip"   # the joint-first eight-lane kernel has the same kind of fallback: same treatment
+    jf_exact_obj = os.path.join(_DIR, "build", "saip_kernel_octjf_exact.o")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-x", "hip", "-c", "-DSAIP_OCT_FORCE_EXACT", "-o", jf_exact_obj] + sched[jf_rel] + extra + [os.path.join(_DIR, jf_rel)]
+    procs.append((cmd, subprocess.Popen(cmd)))
     for rel in SOURCES:
         obj = os.path.join(_DIR, "build", os.path.basename(rel) + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
@@ -70,7 +74,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
-    exact_objs = [oct_exact_obj if os.path.basename(o) == "saip_kernel_oct.hip.o" else o for o in objs]
+    exact_objs = [oct_exact_obj if os.path.basename(o) == "saip_kernel_oct.hip.o" else (jf_exact_obj if os.path.basename(o) == "saip_kernel_octjf.hip.o" else o) for o in objs]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", exact_lib] + exact_objs)
     return LIB_PATH
 

@@ -454,6 +454,9 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		// stage 1: lambda_max(Gs) <= trace(Gs) = 1 and lambda_max(G) >= trace(G) / 6, so a positive definite Gs - s_max^2 I and
 		// trace(G) >= 6 s_abs_tol^2 certify the fully non-singular branch
 		bool need_exact = !((tr > 0.0) && (tr >= 6.0 * tol2) && ldl_positive(smax2));
+#if defined(SAIP_OCT_FORCE_EXACT)  // test-only build (libsaip_octexact.so): every instance takes the exact eigen fallback
+		need_exact = true;
+#endif
 		if (__any(need_exact)) {
 			// stage 2: the trace-power bound u = trace(Gs^8)^(1/8) in [lambda_max, 6^(1/8) lambda_max] tightens both tests
 			double G2[6][6], Gt[6][6];
@@ -479,6 +482,36 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 			const bool ok_s0 = (u * mf.cert_kroot * tr >= tol2);
 			const bool pos = ldl_positive(smax2 * u);
 			need_exact = need_exact && !(ok_s0 && pos && tr > 0.0);
+			if (need_exact) {
+				// stage 3, the opposite certificate: with l = max_i Gs_ii <= lambda_max(Gs), a NEGATIVE LDL^T pivot of Gs - s_max^2 l I (all earlier
+				// pivots positive: Sylvester) proves lambda_min < s_max^2 lambda_max, i.e. the instance is outside the non-singular branch for
+				// sure; so does trace(G) < s_abs_tol^2.  A batch with many near-singular postures does not queue up for the one-lane eigen-solve.
+				double lmx = 0.0;
+				UNR for (int a = 0; a < 6; a++) lmx = fmax(lmx, G[a][a] * itr);
+				double Gs[6][6];
+				UNR for (int a = 0; a < 6; a++)
+					UNR for (int c = 0; c <= a; c++) Gs[a][c] = G[a][c] * itr;
+				UNR for (int a = 0; a < 6; a++) Gs[a][a] -= smax2 * lmx;
+				bool neg = false, clean = true;
+				UNR for (int kk = 0; kk < 6; kk++) {
+					const double dpv = Gs[kk][kk];
+					neg = neg || (clean && dpv < -1e-12);
+					clean = clean && (dpv > 1e-13);
+					const double id = oct_rcp(dpv);
+					UNR for (int i = kk + 1; i < 6; i++) {
+						const double lik = Gs[i][kk] * id;
+						UNR for (int j = kk + 1; j <= i; j++) Gs[i][j] = fma(-lik, Gs[j][kk], Gs[i][j]);
+					}
+				}
+				if ((tr > 0.0 && neg) || tr < tol2) {
+					singular = true;
+					need_exact = false;
+				}
+			}
+#if defined(SAIP_OCT_FORCE_EXACT)
+			need_exact = true;
+			singular = false;
+#endif
 			if (__any(need_exact)) {  // exact (rare): singular values from the Gram eigenvalues, one lane per instance
 				if (need_exact && r == 0) {
 					for (int a = 0; a < 6; a++)

@@ -227,3 +227,39 @@ def test_random_option_combinations_match_oracle(seed):
         e0, e1 = W.torque_error(tau[plain], ref[plain]), W.torque_error(tau[ok], ref[ok])
         print(f"seed {seed} B {B} rows {spec[0]['S']} cycle {cyc}: err {e0:.2e} (with blended instances {e1:.2e}), blended {int(((st & 8) > 0).sum())}, refused {int((~ok).sum())}")
         assert plain.sum() > B // 2 and e0 < TOL and e1 < 1e-6
+
+
+def test_exact_fallback_when_forced():
+    """the one-lane Gram eigen-solve behind the certificates is rare on real data; the test-only build libsaip_octexact.so (-DSAIP_OCT_FORCE_EXACT)
+    sends EVERY instance of this kernel through it and must give the oracle's answers and statuses too (child process: the library is chosen
+    at load time through SAIP_LIB)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "sai-primitives_amd", "libsaip_octexact.so")
+    assert os.path.exists(lib), "build() links the test-only variant next to libsaip.so"
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import workloads as W
+from oracle import Oracle
+from sai_primitives_amd.controller import controller_from_specs
+B = 256
+d = W.make_inputs(6, B)
+q = d["q"].copy()
+q[0::3, 4] = np.random.default_rng(2).uniform(-0.03, 0.03, q[0::3, 4].shape)   # a third of the batch inside the singular region
+ref, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
+ctrl.setFlaggedTorquePolicy(True)
+ctrl.setKernel(3)
+robot.setQ(q); robot.setDq(d["dq"]); robot.updateModel(); ctrl.updateControllerTaskModels(); ctrl.setGoals(d["goals"])
+tau = ctrl.computeControlTorques()
+assert ctrl.kernelName() == "saip_cycle_octjf" and np.array_equal(ctrl.status & 9, st & 9)
+ok = st == 0
+err = W.torque_error(tau[ok], ref[ok])
+print("forced exact path, config 6:", int(ok.sum()), "plain instances, err", err, "blended", int(((st & 8) > 0).sum()))
+assert err < 1e-9 and ((st & 8) > 0).sum() > B // 6
+''' % (root, os.path.join(root, "oracle"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAIP_LIB=lib), capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr[-2000:])
+    assert out.returncode == 0
