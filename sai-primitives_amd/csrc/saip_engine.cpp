@@ -1434,13 +1434,30 @@ static bool wave_eligible(const saip_batch* b) {
 // (full 6-dof motion-force task + full joint task: the joint task has rank <= 1) or any motion-force task of rank >= 2 with a joint
 // task of at most four rows (general range basis); default or general control laws, no closed-loop force control.
 static bool oct_eligible(const saip_batch* b, CycleParams& P) {
-	if (b->model->n != 7 || b->tasks.size() != 2) return false;
+	const int n = b->model->n;
+	if (n < 6 || n > 8 || b->tasks.size() != 2) return false;
 	const TaskDev& mf = b->tasks[0].dev;
 	const TaskDev& jt = b->tasks[1].dev;
 	if (mf.type != saip::TASK_MOTION_FORCE || jt.type != saip::TASK_JOINT) return false;
 	if (mf.cl_force || mf.cl_moment || mf.k < 2) return false;
 	const bool full_mf = mf.k == 6 && mf.bm_identity;
-	const bool full_jt = jt.m == 7 && jt.s_identity;
+	const bool full_jt = jt.m == n && jt.s_identity;
+	if (n != 7) {
+		// 6- and 8-dof chains: the general instantiation only -- full joint task behind a motion-force task, Jp = N_1 of rank n - k (<= 5) by the
+		// multi-pivot Gram-Schmidt path; singularity handling on (a reduced task would need the 7-dof bookkeeping), no joint limit avoidance
+		if (!full_jt || n - mf.k > 5 || n - mf.k < 0 || !mf.sing_handling || P.jla) return false;
+		if (!full_mf && mf.general_law) return false;
+		if (full_mf)
+			for (int i = 0; i < 9; i++) {
+				const double id = (i % 4 == 0) ? 1.0 : 0.0;
+				if (mf.Ppos[i] != id || mf.Pori[i] != id) return false;
+				if (!mf.general_law && (mf.sig_p[i] != id || mf.sig_o[i] != id)) return false;
+			}
+		if (!lane_eligible(b)) return false;
+		P.oct_general_joint = 2;
+		P.oct_partial_mf = full_mf ? 0 : 1;
+		return true;
+	}
 	if (!full_mf && mf.general_law) return false;  // the general laws are wired for the full task only
 	if (full_mf) {
 		for (int i = 0; i < 9; i++) {  // full task: the projections are identities; the short control law also relies on identity sigma matrices

@@ -202,11 +202,14 @@ __device__ __forceinline__ void oct_sync() {
 
 // ROLE 0: the whole cycle in one wavefront; 1 / 2: wavefront A / B of the two-wavefront form (compile-time, so that neither carries the
 // other's registers: as run-time branches of one body the merged live ranges spilled)
-template <bool FULL, int GJ, int ROLE>
+// NN: dof of the chain.  7 everywhere except the general instantiation <true, 2, ...> (full joint task behind a motion-force task, rank
+// n - k by multi-pivot Gram-Schmidt), which also exists for 6 and 8 dof: with 8 no lane is padding, with 6 two are.
+template <bool FULL, int GJ, int ROLE, int NN = 7>
 __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
-	constexpr int N = 7;
+	constexpr int N = NN;
+	static_assert(NN == 7 || (FULL && GJ == 2), "6- and 8-dof chains: the general instantiation only");
 	const int lane = threadIdx.x & 63;
 	const int r = lane & 7, grp = lane >> 3;
 	const int rr = r < N ? r : N - 1;  // padding lane mirrors joint 6 and never writes
@@ -443,7 +446,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	// beta = c / (1 + c m_e), M_BIE^-1 = M^-1 - beta m m^T, hence J M_BIE^-1 J^T = A - beta t t^T (t = J m) and, by Sherman-Morrison,
 	// Lambda_mod = Lambda + gamma (Lambda t)(Lambda t)^T with gamma = beta / (1 - beta t^T Lambda t).  Several clamped entries in some
 	// instance of the wavefront (wave-uniform): M_BIE is factored alongside M and everything is formed twice.
-	double mi[N] = {0, 0, 0, 0, 0, 0, 0}, mb[N] = {0, 0, 0, 0, 0, 0, 0};
+	double mi[N] = {}, mb[N] = {};
 	int eclamp = 0;
 	double cclamp = 0.0;
 	bool general_bie = false;
@@ -984,7 +987,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		//   tau_joint = Jh^T (Lambda a1 + Lambda_mod b1) = v / |z'|^2 (z'.a + rho z'.f),   a = ddq_d - M^-1 tau_prec, f = the PD(I) force,
 		// rho = Lambda_mod / Lambda: 1 (full decoupling), |z'|^2 / z'.v (impedance), z'.v / (z'.v - beta z'_e^2) (bounded inertia, one
 		// clamped entry e: M_BIE^-1 = M^-1 - beta m m^T and m^T M z' = z'_e), z'.v / (v^T M_BIE^-1 v) (several clamped entries).
-		double v[N] = {0, 0, 0, 0, 0, 0, 0}, zr = 0.0, v_own = 0.0, zz = 0.0, zv = 0.0;
+		double v[N] = {}, zr = 0.0, v_own = 0.0, zz = 0.0, zv = 0.0;
 		if (roleB) {
 		double x6[6], rowv[N], nr = 0.0;
 		oct_solve<6>(L6, dinv6, t1c, x6);
@@ -1940,16 +1943,17 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 // SIM (rollouts of stacks without internal OTGs and without a slow path behind): the wavefront that finished the cycle of its eight
 // instances goes on to integrate them (saip_dynamics_oct_body.h) -- same lane layout, the torques it has just written, the LDS block
 // the cycle no longer needs: one launch per closed-loop period.  A separate instantiation, so that the benchmarked kernel does not carry it.
-template <bool FULL, int GJ, bool DUO = false, bool SIM = false>
+template <bool FULL, int GJ, bool DUO = false, bool SIM = false, int NN = 7>
 __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CycleParams P) {
+	static_assert(!SIM || NN == 7, "the fused integration step is the 7-dof one");
 	__shared__ OctInst smem[DUO ? 16 : 8];
 	static_assert(sizeof(OctInst) >= sizeof(OctDynInst), "the integration step reuses the cycle's LDS blocks");
 	const bool wave_b = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
 	if (DUO) {
-		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0>(P, smem + 8, smem, smem + 8);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0>(P, smem, smem, smem + 8);
+		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8);
 	} else {
-		oct_cycle_body<FULL, GJ, 0>(P, smem, smem, smem);
+		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem);
 	}
 	if (SIM && !wave_b) {
 		SimParams S;
@@ -1989,7 +1993,13 @@ static bool oct_duo_enabled(const int workgroups) {
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
 	const bool duo = oct_duo_enabled((int)grid.x);
-	if (P.oct_general_joint == 2) {
+	if (P.oct_general_joint == 2 && P.n == 8) {
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 8>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 8>), grid, block, 0, stream, P);
+	} else if (P.oct_general_joint == 2 && P.n == 6) {
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 6>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 6>), grid, block, 0, stream, P);
+	} else if (P.oct_general_joint == 2) {
 		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, P);
 		else hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
 	} else if (P.oct_general_joint == 1) {

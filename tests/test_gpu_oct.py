@@ -393,3 +393,87 @@ def test_oct_options_on_blended_postures(variant, B):
         print("oct blended", variant, "B", B, "cycle", c, "err", err)
         assert err < TOL
         q = q + 1e-3 * rng.standard_normal(q.shape)
+
+
+def _six_dof_chain(rng):
+    """a 6-dof arm with general axes (5 revolute joints + one prismatic), the generator of tests/test_gpu_wave.py at n = 6"""
+    links = []
+    for i in range(6):
+        prismatic = i == 2
+        ax = rng.standard_normal(3)
+        ax /= np.linalg.norm(ax)
+        if i % 2 == 0:
+            ax = np.eye(3)[i // 2]
+        ine = rng.uniform(0.004, 0.03, 3)
+        off = rng.uniform(-0.002, 0.002, 3)
+        links.append(dict(name=f"link{i + 1}", joint_type="prismatic" if prismatic else "revolute",
+                          origin_xyz=list(rng.uniform(-0.05, 0.25, 3)) if i else [0.0, 0.0, 0.2], origin_rpy=list(rng.uniform(-1.0, 1.0, 3)), axis=list(ax),
+                          mass=float(rng.uniform(0.5, 3.0)), com=list(rng.uniform(-0.05, 0.05, 3)), inertia=[ine[0], ine[1], ine[2], off[0], off[1], off[2]],
+                          q_lower=-0.3 if prismatic else -2.5, q_upper=0.3 if prismatic else 2.5, velocity_limit=3.0, effort_limit=float(rng.uniform(20, 60)),
+                          q_nominal_deg=0.0))
+    return dict(name="arm6", links=links)
+
+
+@pytest.mark.parametrize("case", ["arm8_full_task", "arm8_position_task", "arm8_planar_task_impedance", "arm6_full_task", "arm6_position_task_gains"])
+def test_six_and_eight_dof_chains(case):
+    """{ MotionForceTask, full JointTask } on chains of 6 and 8 dof: the general instantiation of this kernel (Jp = N_1 of rank n - k, 0 .. 5)
+    with N = 6 / 8 against the lane kernel (their path before) and the oracle; three cycles, integrators on in one case"""
+    from oracle import Oracle
+    rng = np.random.default_rng(len(case))
+    B = 200
+    if case.startswith("arm8"):
+        model = W.load_robot("panda_sliding_base")
+        desc = model.name
+        base = W.make_inputs(6, B, shard=4)
+        q, dq = base["q"], base["dq"]
+        link, pos = "end-effector", (0.0, 0.0, 0.07)
+    else:
+        desc = _six_dof_chain(rng)
+        model = W.RobotModel(desc)
+        q = rng.uniform(0.7 * model.q_lower, 0.7 * model.q_upper, (B, 6))
+        dq = rng.uniform(-0.5, 0.5, (B, 6))
+        link, pos = "link6", (0.02, 0.0, 0.1)
+    n = model.dof
+    if case == "arm8_full_task":
+        tasks = [W.motion_force_task("hand", link, pos), W.joint_task("posture")]
+    elif case == "arm8_position_task":
+        tasks = [W.motion_force_task("hand", link, pos, dirs_trans=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], dirs_rot=None, decoupling=W.FULL_DYNAMIC_DECOUPLING),
+                 W.joint_task("posture", decoupling=W.FULL_DYNAMIC_DECOUPLING)]
+    elif case == "arm8_planar_task_impedance":
+        tasks = [W.motion_force_task("hand", link, pos, dirs_trans=[[1, 0, 0], [0, 1, 1]], dirs_rot=[[0, 0, 1], [1, 0, 0]], decoupling=W.IMPEDANCE),
+                 W.joint_task("posture", decoupling=W.IMPEDANCE, vel_sat=True, sat=0.5)]
+    elif case == "arm6_full_task":
+        tasks = [W.motion_force_task("hand", link, pos), W.joint_task("posture")]
+    else:
+        tasks = [W.motion_force_task("hand", link, pos, dirs_trans=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], dirs_rot=None, kp_pos=[120.0, 90.0, 150.0], ki_pos=3.0, bie_threshold=0.4),
+                 W.joint_task("posture", kp=list(rng.uniform(20, 90, 6)), ki=1.5, bie_threshold=0.4)]
+    opts = dict(gravity_comp=case != "arm8_full_task", torque_saturation=case.endswith("gains"))
+    frames = W.fk(model, q)
+    goals = []
+    for t in tasks:
+        if t["type"] == "motion_force":
+            li = model.link_index(t["link"])
+            R, o = frames[li]
+            x = o + np.einsum("bij,j->bi", R, np.asarray(t["pos_in_link"], float))
+            Rg = W._expm_so3(rng.uniform(-0.2, 0.2, (B, 3))) @ (R @ np.asarray(t["rot_in_link"], float))
+            goals.append(np.concatenate([x + rng.uniform(-0.05, 0.05, (B, 3)), Rg.reshape(B, 9), rng.uniform(-0.1, 0.1, (B, 6)), rng.uniform(-0.5, 0.5, (B, 6))], axis=1))
+        else:
+            goals.append(np.concatenate([q + rng.uniform(-0.3, 0.3, (B, n)), rng.uniform(-0.1, 0.1, (B, n)), rng.uniform(-0.5, 0.5, (B, n))], axis=1))
+    out = {}
+    for kernel in (OCT, 2):
+        robot, ctrl, _ = _engine(desc, tasks, B)
+        ctrl.setKernel(kernel)
+        ctrl.enableGravityCompensation(opts["gravity_comp"])
+        ctrl.enableTorqueSaturation(opts["torque_saturation"])
+        taus = [_cycle(robot, ctrl, q + 0.01 * cyc, dq, goals).copy() for cyc in range(3)]
+        out[kernel] = (np.array(taus), ctrl.status.copy(), ctrl.kernelName())
+    assert out[OCT][2] == "saip_cycle_oct" and out[2][2] == "saip_cycle_lane"
+    orc = Oracle(model, tasks, **opts)
+    for cyc in range(3):
+        ref, st = orc.step(q + 0.01 * cyc, dq, goals, nthreads=4)
+        plain = (st == 0) & (out[2][1] == 0)
+        assert plain.sum() > (B // 2 if n == 8 else 20)   # (a random 6-dof arm with a 6-dof task: most postures sit inside the handler's singular region)
+        e8, e1 = W.torque_error(out[OCT][0][cyc][plain], ref[plain]), W.torque_error(out[2][0][cyc][plain], ref[plain])
+        print(f"{case} cycle {cyc}: eight-lane err {e8:.2e}, lane err {e1:.2e}, plain {int(plain.sum())} of {B}, status set {sorted(set(out[OCT][1]))}")
+        assert e8 < TOL and e1 < TOL
+    assert np.array_equal(out[OCT][1], out[2][1])

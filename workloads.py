@@ -304,6 +304,7 @@ CONFIGS = {
              "force sensor, PI feedback with saturation, feed-forward gains; full JointTask in the nullspace"),
     14: dict(robot="panda_arm", batch=256, desc="config-2 tasks with the blended singularity strategies switched on; every third instance has the elbow nearly "
              "straight (type-1 singularity), every third the wrist nearly aligned next to the joint limit (type-2)"),
+    15: dict(robot="panda_sliding_base", batch=256, desc="8-DoF sliding-base Panda, full MotionForceTask + full JointTask in its nullspace (rank 2): the headline stack on an 8-dof arm"),
     12: dict(robot="panda_arm", batch=256, desc="config-2 tasks with disableSingularityHandling(); every third instance has the elbow nearly straight "
              "(inside SingularityHandler's blending region): the motion-force task is reduced to its non-singular subspace"),
 }
@@ -332,6 +333,8 @@ def config_tasks(cfg: int):
     if cfg == 6:
         return [joint_task("partial_joint_task", S=[0, 7]),                                   # examples/06:107-112
                 motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07))]
+    if cfg == 15:
+        return [motion_force_task("motion_force_task", "end-effector", (0, 0, 0.07)), joint_task("joint_task")]
     if cfg == 7:
         return [motion_force_task("ori_task", "end-effector", (0, 0, 0.07), dirs_trans=None,
                                   dirs_rot=[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
