@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}  // roleB
 		double fi = 0.0;
 		if (roleA) {
-		fi = fi_pre;  // (the joint control law ran behind the frames)
+		fi = fi_pre;  // (the joint control law ran behind M(q), see fi_pre)
 		}
 		double tvo = 0.0;
 		bool ovr = false;
@@ -1839,7 +1839,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			UNR for (int c = 0; c < 5; c++)
 				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = fma(gamma * lt[c], lt[k5], Lam5[c][k5]);
 		}
-		// (the control law of this lane's joint ran behind the frames: fi_pre); its range coordinates by sums over the lanes
+		// (the control law of this lane's joint ran behind M(q): fi_pre); its range coordinates by sums over the lanes
 		const double fi = fi_pre;
 		const double ai = jg_ddq - wr;
 		double a1[5], b1[5];
