@@ -65,6 +65,79 @@ struct OctInst {
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU (one LDS block each, also with two wavefronts per instance group)");
 
+// ---------------------------------------------------------------- lane layout
+// Eight lanes per instance, eight instances per wavefront, two instances per 16-lane DPP row.  INTERLEAVED (default): the two instances of a
+// row take its even and its odd lanes (joint r of instance 2 row + parity sits in lane 16 row + 2 r + parity).  Every boundary of a scan along
+// the chain is then a ROW boundary, which DPP handles by itself (bound_ctrl zero fill, or the untouched `old` operand for an identity) --
+// with the two instances side by side (lanes 0-7 / 8-15, SAIP_OCT_ILV=0) every scan step needed a select per moved register: a third of the
+// instructions of the wavefront's longest phase (doubling them cost 4.5 % of the launch, measured).
+#ifndef SAIP_OCT_ILV
+#define SAIP_OCT_ILV 1
+#endif
+constexpr bool OCT_ILV = SAIP_OCT_ILV != 0;
+__device__ __forceinline__ int octl_r(const int lane) { return OCT_ILV ? ((lane >> 1) & 7) : (lane & 7); }
+__device__ __forceinline__ int octl_grp(const int lane) { return OCT_ILV ? (((lane >> 4) << 1) | (lane & 1)) : (lane >> 3); }
+// the lane that holds joint j of this lane's instance
+__device__ __forceinline__ int octl_src(const int lane, const int j) { return OCT_ILV ? ((lane & 0x31) | (j << 1)) : ((lane & ~7) | j); }
+// the votes of the eight lanes of this lane's instance, bit r = joint r
+__device__ __forceinline__ unsigned octl_votes(const unsigned long long ballot, const int lane) {
+	if (!OCT_ILV) return (unsigned)((ballot >> ((lane >> 3) * 8)) & 0xffull);
+	unsigned x = (unsigned)((ballot >> (16 * (lane >> 4))) & 0xffffull) >> (lane & 1);  // the row's votes, this instance's on the even bits
+	x &= 0x5555u;
+	x = (x | (x >> 1)) & 0x3333u;
+	x = (x | (x >> 2)) & 0x0f0fu;
+	x = (x | (x >> 4)) & 0x00ffu;
+	return x;
+}
+enum { DPP_ROW_ROR = 0x120 };
+// sum / maximum over the eight lanes of an instance, every lane gets the result (rotations by 4 and 8 inside the row keep the parity)
+__device__ __forceinline__ double octl_sum(double x) {
+	if (!OCT_ILV) return oct_group_sum(x);
+	x += oct_dpp<DPP_QUAD_XOR2>(x);
+	x += oct_dpp<DPP_ROW_ROR + 4>(x);
+	return x + oct_dpp<DPP_ROW_ROR + 8>(x);
+}
+__device__ __forceinline__ double octl_max(double x) {
+	if (!OCT_ILV) return oct_group_max(x);
+	x = fmax(x, oct_dpp<DPP_QUAD_XOR2>(x));
+	x = fmax(x, oct_dpp<DPP_ROW_ROR + 4>(x));
+	return fmax(x, oct_dpp<DPP_ROW_ROR + 8>(x));
+}
+// the three exchange steps of a butterfly over the eight lanes of an instance (arg-max with its index, ...)
+constexpr int OCT_BFLY0 = OCT_ILV ? (int)DPP_QUAD_XOR2 : (int)DPP_QUAD_XOR1, OCT_BFLY1 = OCT_ILV ? DPP_ROW_ROR + 4 : (int)DPP_QUAD_XOR2,
+			  OCT_BFLY2 = OCT_ILV ? DPP_ROW_ROR + 8 : (int)DPP_HALF_MIRROR;
+// value of joint r - D (shr) / r + D (shl) of the same instance; lanes without such a joint get `fill` (0 or 1: the identity's diagonal).
+// Interleaved layout only (the side-by-side layout masks by selects at the call sites).
+template <int D, bool ONE>
+__device__ __forceinline__ double octl_shr(const double x) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, true);
+	const int hi = ONE ? __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, false)
+					   : __builtin_amdgcn_update_dpp(0, __double2hiint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ double octl_shl(const double x) {
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), DPP_ROW_SHL + 2 * D, 0xF, 0xF, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), DPP_ROW_SHL + 2 * D, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+// one step of the prefix product of the frames along the chain: T_r <- T_{r-D} o T_r, (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
+#define OCT_FRAME_STEP(D, Tw, r)                                                                                                     \
+	{                                                                                                                                \
+		double Xa[12], Tn[12];                                                                                                       \
+		if (OCT_ILV) {                                                                                                               \
+			UNR for (int e = 0; e < 12; e++) Xa[e] = (e == 0 || e == 4 || e == 8) ? octl_shr<D, true>(Tw[e]) : octl_shr<D, false>(Tw[e]); \
+		} else {                                                                                                                     \
+			UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                \
+		}                                                                                                                            \
+		UNR for (int i = 0; i < 3; i++) {                                                                                            \
+			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j];  \
+			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                            \
+		}                                                                                                                            \
+		const bool take = OCT_ILV || r >= D;  /* (interleaved: lanes without a predecessor composed with the identity) */            \
+		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                               \
+	}
+
 // eigen-decomposition of a symmetric R x R matrix (R = 4, 6) held, identically, by all eight lanes of an instance: round-robin Jacobi.
 // The R/2 rotations of a round touch disjoint index pairs, so they are computed at the same time in different lanes (lane m of each
 // quad takes pair m; the reciprocal / rsqrt chains are most of a rotation's cost), broadcast inside the quad by DPP quad_perm and applied
@@ -76,7 +149,22 @@ template <int R>
 __device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R], const int lane) {
 	static_assert(R == 4 || R == 6, "even sizes with at most three pairs per round");
 	constexpr int NP = R / 2, RM = R - 1;
-	const int r = lane & 7, m = (lane & 3) < NP ? (lane & 3) : 0;
+	// which pair of a round this lane computes.  Side by side: lane m of each quad takes pair m (quad_perm broadcasts 0x00 / 0x55 / 0xAA).
+	// Interleaved: a quad holds joints 2 q, 2 q + 1 of two instances -- even joints take pair 0, odd joints pair 1 (quad_perm [0,1,0,1] /
+	// [2,3,2,3] hands them to the quad's lanes of the same instance), and the third pair of a 6 x 6 round is computed by every lane itself.
+	const int r = octl_r(lane), m = OCT_ILV ? (r & 1) : ((lane & 3) < NP ? (lane & 3) : 0);
+	// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
+	// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
+	auto rotation = [](const double apq, const double app, const double aqq, double& cs, double& sn, double& tn) {
+		const double d = aqq - app, b2 = 2.0 * apq;
+		const double x = fma(d, d, b2 * b2);
+		const bool rot = x > 1e-300;
+		const double h = rot ? x * oct_rsqrt(x) : 1.0;
+		const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
+		tn = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
+		cs = oct_rsqrt(fma(tn, tn, 1.0));
+		sn = tn * cs;
+	};
 	double vrow[R];
 	UNR for (int j = 0; j < R; j++) vrow[j] = (j == r) ? 1.0 : 0.0;
 	for (int sweep = 0; sweep < 12; sweep++) {
@@ -97,20 +185,22 @@ __device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R
 				app = mine ? A[p][p] : app;
 				aqq = mine ? A[q][q] : aqq;
 			}
-			// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
-			// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
-			const double d = aqq - app, b2 = 2.0 * apq;
-			const double x = fma(d, d, b2 * b2);
-			const bool rot = x > 1e-300;
-			const double h = rot ? x * oct_rsqrt(x) : 1.0;
-			const double tm = fabs(b2) * oct_rcp(fabs(d) + h);
-			const double tn = rot ? (((d >= 0.0) == (b2 >= 0.0)) ? tm : -tm) : 0.0;
-			const double cs = oct_rsqrt(fma(tn, tn, 1.0)), sn = tn * cs;
+			double cs, sn, tn, cs2 = 1.0, sn2 = 0.0, tn2 = 0.0;
+			rotation(apq, app, aqq, cs, sn, tn);
+			if (OCT_ILV && NP == 3) {  // the third pair of the round, in every lane
+				const int a_ = (t + 2) % RM, b_ = (t + RM - 2) % RM;
+				const int p = a_ < b_ ? a_ : b_, q = a_ < b_ ? b_ : a_;
+				rotation(A[p][q], A[p][p], A[q][q], cs2, sn2, tn2);
+			}
 			UNR for (int j = 0; j < NP; j++) {
 				const int a_ = j == 0 ? t : (t + j) % RM, b_ = j == 0 ? RM : (t + RM - j) % RM;
 				const int p = a_ < b_ ? a_ : b_, q = a_ < b_ ? b_ : a_;
 				double c, s_, tj;
-				if (j == 0) { c = oct_dpp<0x00>(cs); s_ = oct_dpp<0x00>(sn); tj = oct_dpp<0x00>(tn); }
+				if (OCT_ILV) {
+					if (j == 0) { c = oct_dpp<0x44>(cs); s_ = oct_dpp<0x44>(sn); tj = oct_dpp<0x44>(tn); }
+					else if (j == 1) { c = oct_dpp<0xEE>(cs); s_ = oct_dpp<0xEE>(sn); tj = oct_dpp<0xEE>(tn); }
+					else { c = cs2; s_ = sn2; tj = tn2; }
+				} else if (j == 0) { c = oct_dpp<0x00>(cs); s_ = oct_dpp<0x00>(sn); tj = oct_dpp<0x00>(tn); }
 				else if (j == 1) { c = oct_dpp<0x55>(cs); s_ = oct_dpp<0x55>(sn); tj = oct_dpp<0x55>(tn); }
 				else { c = oct_dpp<0xAA>(cs); s_ = oct_dpp<0xAA>(sn); tj = oct_dpp<0xAA>(tn); }
 				const double apq_j = A[p][q];
@@ -135,7 +225,7 @@ __device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R
 		}
 	}
 	UNR for (int i = 0; i < R; i++)
-		UNR for (int c = 0; c < R; c++) V[i][c] = __shfl(vrow[c], (lane & ~7) | i);
+		UNR for (int c = 0; c < R; c++) V[i][c] = __shfl(vrow[c], octl_src(lane, i));
 }
 __device__ __forceinline__ void oct_jacobi4(double (&A)[4][4], double (&V)[4][4], const int lane) { oct_jacobi_n<4>(A, V, lane); }
 __device__ __forceinline__ void oct_spd_inverse4(const double (&A)[4][4], double (&Ainv)[4][4]) { oct_spd_inverse_n<4>(A, Ainv); }
@@ -164,21 +254,9 @@ __device__ __forceinline__ void oct_fk_frame(const ModelDev& md, const int rr, c
 		oct_mat3_vec(R0, a, d);
 		UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q;
 	}
-#define OCT_FK_STEP(D)                                                                                                              \
-	{                                                                                                                               \
-		double Xa[12], Tn[12];                                                                                                      \
-		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
-		UNR for (int i = 0; i < 3; i++) {                                                                                           \
-			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
-			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
-		}                                                                                                                           \
-		const bool take = r >= D;                                                                                                   \
-		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
-	}
-	OCT_FK_STEP(1)
-	OCT_FK_STEP(2)
-	OCT_FK_STEP(4)
-#undef OCT_FK_STEP
+	OCT_FRAME_STEP(1, Tw, r)
+	OCT_FRAME_STEP(2, Tw, r)
+	OCT_FRAME_STEP(4, Tw, r)
 }
 
 
@@ -211,7 +289,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	constexpr int N = NN;
 	static_assert(NN == 7 || (FULL && GJ == 2), "6- and 8-dof chains: the general instantiation only");
 	const int lane = threadIdx.x & 63;
-	const int r = lane & 7, grp = lane >> 3;
+	const int r = octl_r(lane), grp = octl_grp(lane);
 	const int rr = r < N ? r : N - 1;  // padding lane mirrors joint 6 and never writes
 	const bool act = r < N;
 	OctInst& sm = smem[grp];
@@ -300,21 +378,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	sm.vec[5][r] = gl3;
 	if (roleB && r < 6) sm.ist[r] = mfi_pre;
 	if (roleA && GJ == 1 && r < 4) sm.ist[6 + r] = jti_pre;
-#define OCT_PREFIX_STEP(D)                                                                                                          \
-	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
-		double Xa[12], Tn[12];                                                                                                      \
-		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
-		UNR for (int i = 0; i < 3; i++) {                                                                                           \
-			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
-			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
-		}                                                                                                                           \
-		const bool take = r >= D;                                                                                                   \
-		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
-	}
-	OCT_PREFIX_STEP(1)
-	OCT_PREFIX_STEP(2)
-	OCT_PREFIX_STEP(4)
-#undef OCT_PREFIX_STEP
+	OCT_FRAME_STEP(1, Tw, r)
+	OCT_FRAME_STEP(2, Tw, r)
+	OCT_FRAME_STEP(4, Tw, r)
 	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];  // the motion-force task reads its body's frame from here
 	// this lane's world frame is in Tw (padding lane 7: unused)
 	const bool rev = md.jtype[rr] == 1;
@@ -363,16 +429,16 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	if (roleA) {
 		// (selects, not multiplications by 0: a neighbouring instance with non-finite state must not leak in)
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
-			Ic[e] += (r + 1 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<1>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 1 < 8) ? up : 0.0;
 		}
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
-			Ic[e] += (r + 2 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<2>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 2 < 8) ? up : 0.0;
 		}
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
-			Ic[e] += (r + 4 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<4>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 4 < 8) ? up : 0.0;
 		}
 	}
 	oct_sync<DUO>();
@@ -506,7 +572,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			vw[a] = s;
 		}
 		if (FULL && !mf.bm_identity) {  // the task velocities use the UNprojected Jacobian (MotionForceTask.cpp:293-298): vw = Jw dq
-			UNR for (int a = 0; a < 6; a++) vw[a] = oct_group_sum(jwc[a] * dq_r);
+			UNR for (int a = 0; a < 6; a++) vw[a] = octl_sum(jwc[a] * dq_r);
 		}
 	}
 	STAMP(5);
@@ -1007,19 +1073,19 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		bestw = take ? ob : bestw;                                                                              \
 		jbw = take ? oj : jbw;                                                                                  \
 	}
-		OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
-		OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
-		OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+		OCT_ARGMAX_STEP(OCT_BFLY0)
+		OCT_ARGMAX_STEP(OCT_BFLY1)
+		OCT_ARGMAX_STEP(OCT_BFLY2)
 #undef OCT_ARGMAX_STEP
-		const int src = (lane & ~7) | jbw;
+		const int src = octl_src(lane, jbw);
 		UNR for (int j = 0; j < N; j++) {
 			v[j] = __shfl(rowv[j], src);
 			zr = fma(mi[j], v[j], zr);
 			v_own = (j == rr) ? v[j] : v_own;
 		}
 		zr = act ? zr : 0.0;
-		zz = oct_group_sum(zr * zr);
-		zv = oct_group_sum(zr * v_own);
+		zz = octl_sum(zr * zr);
+		zv = octl_sum(zr * v_own);
 		}  // roleB
 		double fi = 0.0;
 		if (roleA) {
@@ -1029,8 +1095,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		bool ovr = false;
 		if (ROLE == 0) {
 		const double ai = jg_ddq - wr;
-		const double za = oct_group_sum(zr * ai);
-		const double zf = oct_group_sum(zr * fi);
+		const double za = octl_sum(zr * ai);
+		const double zf = octl_sum(zr * fi);
 		double rho = 1.0;
 		if (jt.decoupling == DEC_IMPEDANCE) {
 			rho = zz * oct_rcp(zv);
@@ -1041,10 +1107,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				}
 				double mbv = 0.0;
 				UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], v[j], mbv);  // (M_BIE^-1 v)_rr
-				const double qb = oct_group_sum(act ? v_own * mbv : 0.0);
+				const double qb = octl_sum(act ? v_own * mbv : 0.0);
 				rho = zv * oct_rcp(qb);
 			} else {
-				const double ze = oct_group_sum((act && r == eclamp) ? zr : 0.0);
+				const double ze = octl_sum((act && r == eclamp) ? zr : 0.0);
 				rho = zv * oct_rcp(fma(-beta * ze, ze, zv));
 			}
 		}
@@ -1141,7 +1207,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				double acc = 0.0;
 				const double af = jg_ddq, ff = fi;  // tau_prec = 0: no disturbance compensation
 				UNR for (int j = 0; j < N; j++) {
-					const int src = (lane & ~7) | j;
+					const int src = octl_src(lane, j);
 					const double aj = __shfl(af, src), fj = __shfl(ff, src);
 					const double mrj = (j <= rr) ? smA.M[rr][j] : smA.M[j][rr];
 					double mmod = mrj;
@@ -1171,7 +1237,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				{
 					double T0[12], Rb[12];
 					oct_fk_frame(md, rr, r, q_r, T0);
-					const int srcb = (lane & ~7) | mf.body;
+					const int srcb = octl_src(lane, mf.body);
 					UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T0[e2], srcb);
 					oct_mat3_vec(Rb, mf.pos, pw0);
 					UNR for (int i = 0; i < 3; i++) pw0[i] += Rb[9 + i];
@@ -1198,7 +1264,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					for (int sg = 0; sg < 2; sg++) {
 						double T1w[12], Rb[12], x1[3], R1[9];
 						oct_fk_frame(md, rr, r, q_r + (sg ? -5.0 : 5.0) * vc, T1w);
-						const int srcb = (lane & ~7) | mf.body;
+						const int srcb = octl_src(lane, mf.body);
 						UNR for (int e2 = 0; e2 < 12; e2++) Rb[e2] = __shfl(T1w[e2], srcb);
 						oct_mat3_vec(Rb, mf.pos, x1);
 						UNR for (int i = 0; i < 3; i++) x1[i] += Rb[9 + i];
@@ -1237,7 +1303,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					const bool part = act && jstar != 0.0;
 					const bool setb = part && fabs(q_r - md.q_upper[rr]) < 5.0 * M_PI / 180.0;
 					const bool clrb = part && !setb && fabs(q_r - md.q_lower[rr]) < 5.0 * M_PI / 180.0;
-					const unsigned sets = (unsigned)((__ballot(setb) >> (grp * 8)) & 0x7full), clrs = (unsigned)((__ballot(clrb) >> (grp * 8)) & 0x7full);
+					const unsigned sets = octl_votes(__ballot(setb), lane) & 0x7fu, clrs = octl_votes(__ballot(clrb), lane) & 0x7fu;
 					if (!type1) dir_neg = (dir_neg | sets) & ~clrs;
 				}
 				if (blend && live) {
@@ -1396,8 +1462,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				double w1[6], w2[6], lw[6];
 				UNR for (int c = 0; c < 6; c++) {
 					const double vc = (keep[c] || !act) ? 0.0 : ju[c] * oct_rcp(sig[c]);
-					w1[c] = oct_group_sum(vc * u1);
-					w2[c] = type1 ? 0.0 : oct_group_sum(vc * u2);
+					w1[c] = octl_sum(vc * u1);
+					w2[c] = type1 ? 0.0 : octl_sum(vc * u2);
 				}
 				double tjs = 0.0, wsel[6];
 				UNR for (int c = 0; c < 6; c++) wsel[c] = type1 ? w1[c] : w2[c];  // (element-wise: never a run-time choice between two private arrays)
@@ -1427,36 +1493,36 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		bestw = take ? ob : bestw;                                                                              \
 		jbw = take ? oj : jbw;                                                                                  \
 		}
-				OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
-				OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
-				OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+				OCT_ARGMAX_STEP(OCT_BFLY0)
+				OCT_ARGMAX_STEP(OCT_BFLY1)
+				OCT_ARGMAX_STEP(OCT_BFLY2)
 	#undef OCT_ARGMAX_STEP
-				const int srcp = (lane & ~7) | jbw;
+				const int srcp = octl_src(lane, jbw);
 				double zb = (r == jbw) ? 1.0 : 0.0;
 				UNR for (int c = 0; c < 6; c++) zb = fma(-vown[c], __shfl(vown[c], srcp), zb);
 				zb = act ? zb : 0.0;
 				double mz = 0.0, wq = 0.0;
 				UNR for (int j = 0; j < N; j++) {
-					const int srcj = (lane & ~7) | j;
+					const int srcj = octl_src(lane, j);
 					const double zj = __shfl(zb, srcj), tj = __shfl(tmf, srcj);
 					const double mrj = (j <= rr) ? smA.M[rr][j] : smA.M[j][rr];
 					mz = fma(mrj, zj, mz);   // (M z)_rr
 					wq = fma(mi[j], tj, wq);  // (M^-1 tau_prec)_rr
 				}
 				const double aib = jg_ddq - wq;
-				const double zzb = oct_group_sum(zb * zb), sb = oct_group_sum(act ? zb * mz : 0.0);
-				const double zab = oct_group_sum(zb * aib), zfb = oct_group_sum(zb * fi);
+				const double zzb = octl_sum(zb * zb), sb = octl_sum(act ? zb * mz : 0.0);
+				const double zab = octl_sum(zb * aib), zfb = octl_sum(zb * fi);
 				double rhob = 1.0;  // rho |z|^2 in the notation above: tau = (M z)_r / |z|^2 (z.a + rho' z.f), rho' = Lambda_mod / Lambda
 				if (jt.decoupling == DEC_IMPEDANCE) {
 					rhob = zzb * oct_rcp(sb);
 				} else if (jt.decoupling == DEC_BIE) {
 					if (general_bie) {
 						double mbv = 0.0;
-						UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], __shfl(mz, (lane & ~7) | j), mbv);
-						const double qb = oct_group_sum(act ? mz * mbv : 0.0);
+						UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], __shfl(mz, octl_src(lane, j)), mbv);
+						const double qb = octl_sum(act ? mz * mbv : 0.0);
 						rhob = sb * oct_rcp(qb);
 					} else {
-						const double ze = oct_group_sum((act && r == eclamp) ? zb : 0.0);
+						const double ze = octl_sum((act && r == eclamp) ? zb : 0.0);
 						rhob = sb * oct_rcp(fma(-beta * ze, ze, sb));
 					}
 				}
@@ -1501,8 +1567,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}
 		if (ROLE == 1) {
 		const double ai = jg_ddq - wr;
-		const double za = oct_group_sum(zr * ai);
-		const double zf = oct_group_sum(zr * fi);
+		const double za = octl_sum(zr * ai);
+		const double zf = octl_sum(zr * fi);
 		double rho = 1.0;
 		if (jt.decoupling == DEC_IMPEDANCE) {
 			rho = zz * oct_rcp(zv);
@@ -1513,10 +1579,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				}
 				double mbv = 0.0;
 				UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], v[j], mbv);  // (M_BIE^-1 v)_rr
-				const double qb = oct_group_sum(act ? v_own * mbv : 0.0);
+				const double qb = octl_sum(act ? v_own * mbv : 0.0);
 				rho = zv * oct_rcp(qb);
 			} else {
-				const double ze = oct_group_sum((act && r == eclamp) ? zr : 0.0);
+				const double ze = octl_sum((act && r == eclamp) ? zr : 0.0);
 				rho = zv * oct_rcp(fma(-beta * ze, ze, zv));
 			}
 		}
@@ -1563,7 +1629,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		double Gp[4][4], V4[4][4], trp = 0.0;
 		UNR for (int i = 0; i < 4; i++)
 			UNR for (int k = 0; k <= i; k++) {
-				const double gs = oct_group_sum(cp[i] * cp[k]);
+				const double gs = octl_sum(cp[i] * cp[k]);
 				Gp[i][k] = gs;
 				Gp[k][i] = gs;
 				if (i == k) trp += gs;
@@ -1640,7 +1706,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}
 		UNR for (int c = 0; c < 4; c++)
 			UNR for (int k = 0; k <= c; k++) {
-				const double gs = oct_group_sum(t1v[c] * jh[k]);
+				const double gs = octl_sum(t1v[c] * jh[k]);
 				A4[c][k] = (c == k && !keep[c]) ? 1.0 : gs;
 			}
 		oct_spd_inverse4(A4, Lam4);
@@ -1659,7 +1725,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 			UNR for (int c = 0; c < 4; c++)
 				UNR for (int k = 0; k <= c; k++) {
-					const double gs = oct_group_sum(tbv[c] * jh[k]);
+					const double gs = octl_sum(tbv[c] * jh[k]);
 					A4[c][k] = (c == k && !keep[c]) ? 1.0 : gs;
 				}
 			oct_spd_inverse4(A4, Lmod4);
@@ -1750,12 +1816,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		bestw = take ? ob : bestw;                                                                              \
 		jbw = take ? oj : jbw;                                                                                  \
 	}
-				OCT_ARGMAX_STEP(DPP_QUAD_XOR1)
-				OCT_ARGMAX_STEP(DPP_QUAD_XOR2)
-				OCT_ARGMAX_STEP(DPP_HALF_MIRROR)
+				OCT_ARGMAX_STEP(OCT_BFLY0)
+				OCT_ARGMAX_STEP(OCT_BFLY1)
+				OCT_ARGMAX_STEP(OCT_BFLY2)
 #undef OCT_ARGMAX_STEP
 				if (s5 == 0) {
-					const double frob2 = oct_group_sum(act ? cnw : 0.0);
+					const double frob2 = octl_sum(act ? cnw : 0.0);
 					c0 = bestw;
 					if (frob2 < 1e-6) going = false;  // ||Jp||_F < 1e-3: empty range
 					else if (bestw < 1e-5) { going = false; bad = true; }
@@ -1765,7 +1831,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					else if (ratio < 1e-4 || s5 == rmax) { going = false; bad = true; }  // ambiguous gap, or more directions than 7 - k
 				}
 				if (s5 < rmax && s5 < 5) {
-					const int src = (lane & ~7) | jbw;
+					const int src = octl_src(lane, jbw);
 					const double inv = going ? oct_rsqrt(bestw) : 0.0;
 					double u[N], dd = 0.0;
 					UNR for (int i = 0; i < N; i++) {
@@ -1799,7 +1865,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}
 		UNR for (int c = 0; c < 5; c++)
 			UNR for (int k5 = 0; k5 <= c; k5++) {
-				const double gs = oct_group_sum(t1v[c] * jh[k5]);
+				const double gs = octl_sum(t1v[c] * jh[k5]);
 				A5[c][k5] = (c == k5 && c >= rank) ? 1.0 : gs;
 			}
 		oct_spd_inverse_n<5>(A5, Lam5);
@@ -1818,7 +1884,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 			UNR for (int c = 0; c < 5; c++)
 				UNR for (int k5 = 0; k5 <= c; k5++) {
-					const double gs = oct_group_sum(tbv[c] * jh[k5]);
+					const double gs = octl_sum(tbv[c] * jh[k5]);
 					A5[c][k5] = (c == k5 && c >= rank) ? 1.0 : gs;
 				}
 			oct_spd_inverse_n<5>(A5, Lmod5);
@@ -1844,8 +1910,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		const double ai = jg_ddq - wr;
 		double a1[5], b1[5];
 		UNR for (int c = 0; c < 5; c++) {
-			a1[c] = oct_group_sum(uown[c] * ai);
-			b1[c] = oct_group_sum(uown[c] * fi);
+			a1[c] = octl_sum(uown[c] * ai);
+			b1[c] = octl_sum(uown[c] * fi);
 		}
 		double tj = tau_r;
 		UNR for (int c = 0; c < 5; c++) {
