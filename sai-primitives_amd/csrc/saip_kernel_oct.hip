@@ -151,7 +151,8 @@ __device__ __forceinline__ void oct_jacobi_n(double (&A)[R][R], double (&V)[R][R
 	constexpr int NP = R / 2, RM = R - 1;
 	// which pair of a round this lane computes.  Side by side: lane m of each quad takes pair m (quad_perm broadcasts 0x00 / 0x55 / 0xAA).
 	// Interleaved: a quad holds joints 2 q, 2 q + 1 of two instances -- even joints take pair 0, odd joints pair 1 (quad_perm [0,1,0,1] /
-	// [2,3,2,3] hands them to the quad's lanes of the same instance), and the third pair of a 6 x 6 round is computed by every lane itself.
+	// [2,3,2,3] hands them to the quad's lanes of the same instance), and the third pair of a 6 x 6 round is computed by every lane itself
+	// (fetching all three by ds_bpermute from joints 0, 1, 2 measured the same or slower: config 12 27.4 vs 26.7 us; side by side 25.0).
 	const int r = octl_r(lane), m = OCT_ILV ? (r & 1) : ((lane & 3) < NP ? (lane & 3) : 0);
 	// t = tan of the rotation angle: sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the
 	// division by apq; hardware reciprocal / rsqrt estimates + Newton steps (arguments are positive and in range)
