@@ -65,79 +65,6 @@ struct OctInst {
 static_assert(sizeof(OctInst) % 256 == 16, "instance stride must be 2 (mod 32) doubles");
 static_assert(sizeof(OctInst) * 8 * 4 <= 160 * 1024, "four wavefronts per CU (one LDS block each, also with two wavefronts per instance group)");
 
-// ---------------------------------------------------------------- lane layout
-// Eight lanes per instance, eight instances per wavefront, two instances per 16-lane DPP row.  INTERLEAVED (default): the two instances of a
-// row take its even and its odd lanes (joint r of instance 2 row + parity sits in lane 16 row + 2 r + parity).  Every boundary of a scan along
-// the chain is then a ROW boundary, which DPP handles by itself (bound_ctrl zero fill, or the untouched `old` operand for an identity) --
-// with the two instances side by side (lanes 0-7 / 8-15, SAIP_OCT_ILV=0) every scan step needed a select per moved register: a third of the
-// instructions of the wavefront's longest phase (doubling them cost 4.5 % of the launch, measured).
-#ifndef SAIP_OCT_ILV
-#define SAIP_OCT_ILV 1
-#endif
-constexpr bool OCT_ILV = SAIP_OCT_ILV != 0;
-__device__ __forceinline__ int octl_r(const int lane) { return OCT_ILV ? ((lane >> 1) & 7) : (lane & 7); }
-__device__ __forceinline__ int octl_grp(const int lane) { return OCT_ILV ? (((lane >> 4) << 1) | (lane & 1)) : (lane >> 3); }
-// the lane that holds joint j of this lane's instance
-__device__ __forceinline__ int octl_src(const int lane, const int j) { return OCT_ILV ? ((lane & 0x31) | (j << 1)) : ((lane & ~7) | j); }
-// the votes of the eight lanes of this lane's instance, bit r = joint r
-__device__ __forceinline__ unsigned octl_votes(const unsigned long long ballot, const int lane) {
-	if (!OCT_ILV) return (unsigned)((ballot >> ((lane >> 3) * 8)) & 0xffull);
-	unsigned x = (unsigned)((ballot >> (16 * (lane >> 4))) & 0xffffull) >> (lane & 1);  // the row's votes, this instance's on the even bits
-	x &= 0x5555u;
-	x = (x | (x >> 1)) & 0x3333u;
-	x = (x | (x >> 2)) & 0x0f0fu;
-	x = (x | (x >> 4)) & 0x00ffu;
-	return x;
-}
-enum { DPP_ROW_ROR = 0x120 };
-// sum / maximum over the eight lanes of an instance, every lane gets the result (rotations by 4 and 8 inside the row keep the parity)
-__device__ __forceinline__ double octl_sum(double x) {
-	if (!OCT_ILV) return oct_group_sum(x);
-	x += oct_dpp<DPP_QUAD_XOR2>(x);
-	x += oct_dpp<DPP_ROW_ROR + 4>(x);
-	return x + oct_dpp<DPP_ROW_ROR + 8>(x);
-}
-__device__ __forceinline__ double octl_max(double x) {
-	if (!OCT_ILV) return oct_group_max(x);
-	x = fmax(x, oct_dpp<DPP_QUAD_XOR2>(x));
-	x = fmax(x, oct_dpp<DPP_ROW_ROR + 4>(x));
-	return fmax(x, oct_dpp<DPP_ROW_ROR + 8>(x));
-}
-// the three exchange steps of a butterfly over the eight lanes of an instance (arg-max with its index, ...)
-constexpr int OCT_BFLY0 = OCT_ILV ? (int)DPP_QUAD_XOR2 : (int)DPP_QUAD_XOR1, OCT_BFLY1 = OCT_ILV ? DPP_ROW_ROR + 4 : (int)DPP_QUAD_XOR2,
-			  OCT_BFLY2 = OCT_ILV ? DPP_ROW_ROR + 8 : (int)DPP_HALF_MIRROR;
-// value of joint r - D (shr) / r + D (shl) of the same instance; lanes without such a joint get `fill` (0 or 1: the identity's diagonal).
-// Interleaved layout only (the side-by-side layout masks by selects at the call sites).
-template <int D, bool ONE>
-__device__ __forceinline__ double octl_shr(const double x) {
-	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, true);
-	const int hi = ONE ? __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, false)
-					   : __builtin_amdgcn_update_dpp(0, __double2hiint(x), DPP_ROW_SHR + 2 * D, 0xF, 0xF, true);
-	return __hiloint2double(hi, lo);
-}
-template <int D>
-__device__ __forceinline__ double octl_shl(const double x) {
-	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), DPP_ROW_SHL + 2 * D, 0xF, 0xF, true);
-	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), DPP_ROW_SHL + 2 * D, 0xF, 0xF, true);
-	return __hiloint2double(hi, lo);
-}
-// one step of the prefix product of the frames along the chain: T_r <- T_{r-D} o T_r, (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob)
-#define OCT_FRAME_STEP(D, Tw, r)                                                                                                     \
-	{                                                                                                                                \
-		double Xa[12], Tn[12];                                                                                                       \
-		if (OCT_ILV) {                                                                                                               \
-			UNR for (int e = 0; e < 12; e++) Xa[e] = (e == 0 || e == 4 || e == 8) ? octl_shr<D, true>(Tw[e]) : octl_shr<D, false>(Tw[e]); \
-		} else {                                                                                                                     \
-			UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                \
-		}                                                                                                                            \
-		UNR for (int i = 0; i < 3; i++) {                                                                                            \
-			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j];  \
-			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                            \
-		}                                                                                                                            \
-		const bool take = OCT_ILV || r >= D;  /* (interleaved: lanes without a predecessor composed with the identity) */            \
-		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                               \
-	}
-
 // eigen-decomposition of a symmetric R x R matrix (R = 4, 6) held, identically, by all eight lanes of an instance: round-robin Jacobi.
 // The R/2 rotations of a round touch disjoint index pairs, so they are computed at the same time in different lanes (lane m of each
 // quad takes pair m; the reciprocal / rsqrt chains are most of a rotation's cost), broadcast inside the quad by DPP quad_perm and applied

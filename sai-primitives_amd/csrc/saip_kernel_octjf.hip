@@ -71,7 +71,7 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = 8;
 	const int lane = threadIdx.x & 63;
-	const int r = lane & 7, grp = lane >> 3;
+	const int r = octl_r(lane), grp = octl_grp(lane);  // (interleaved lane layout, saip_oct_common.h)
 	const int n = P.n;  // 7 or 8
 	const int rr = r < n ? r : n - 1;  // (7 dof) the padding lane mirrors joint 6
 	const bool act = r < n;
@@ -152,21 +152,9 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		UNR for (int c = 0; c < 4; c++) sm.goal[8 * c + r] = gl[c];
 		if (r < 6) sm.ist[r] = mfi_pre;
 	}
-#define JF_PREFIX_STEP(D)                                                                                                            \
-	{  /* T_r <- T_{r-D} o T_r,  (Ra,oa) o (Rb,ob) = (Ra Rb, oa + Ra ob); the partner's transform arrives by DPP row_shr */          \
-		double Xa[12], Tn[12];                                                                                                      \
-		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
-		UNR for (int i = 0; i < 3; i++) {                                                                                           \
-			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
-			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
-		}                                                                                                                           \
-		const bool take = r >= D;                                                                                                   \
-		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
-	}
-	JF_PREFIX_STEP(1)
-	JF_PREFIX_STEP(2)
-	JF_PREFIX_STEP(4)
-#undef JF_PREFIX_STEP
+	OCT_FRAME_STEP(1, Tw, r)
+	OCT_FRAME_STEP(2, Tw, r)
+	OCT_FRAME_STEP(4, Tw, r)
 	double (*Xf)[12] = (ROLE == 2) ? bx[grp] : sm.X;  // the frames of this wavefront (B: its own block)
 	UNR for (int e = 0; e < 12; e++) Xf[r][e] = Tw[e];
 	const bool rev = md.jtype[rr] == 1;
@@ -216,16 +204,16 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	// (selects, not multiplications by 0: a neighbouring instance with non-finite state must not leak in)
 	if (roleA) {
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
-			Ic[e] += (r + 1 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<1>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 1>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 1 < 8) ? up : 0.0;
 		}
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
-			Ic[e] += (r + 2 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<2>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 2>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 2 < 8) ? up : 0.0;
 		}
 		UNR for (int e = 0; e < 10; e++) {
-			const double up = oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
-			Ic[e] += (r + 4 < 8) ? up : 0.0;
+			const double up = OCT_ILV ? octl_shl<4>(Ic[e]) : oct_dpp<DPP_ROW_SHL + 4>(Ic[e]);
+			Ic[e] += (OCT_ILV || r + 4 < 8) ? up : 0.0;
 		}
 	}
 	jf_sync();
@@ -268,7 +256,7 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		if (roleB) {
 			// the task velocities use the UNprojected Jacobian (MotionForceTask.cpp:293-298): vw = J dq
 			UNR for (int a = 0; a < 6; a++) {
-				const double s = oct_group_sum(jw[a] * dq_r);
+				const double s = octl_sum(jw[a] * dq_r);
 				if (r == 0) sm.vw[a] = s;
 			}
 			if (r == 0) {
@@ -579,7 +567,7 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		tv += rev ? tgr : tgp;
 	}
 	if (!(tv == tv)) singular = true;  // non-finite inputs: refuse rather than write NaN as a valid torque
-	singular = __builtin_amdgcn_ballot_w64(singular && act) >> (8 * grp) & 0xffull ? true : singular;  // (one verdict per instance)
+	singular = octl_votes(__builtin_amdgcn_ballot_w64(singular && act), lane) != 0u;  // (one verdict per instance)
 	// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
 	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
 	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
