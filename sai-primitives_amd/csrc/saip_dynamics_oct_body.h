@@ -27,35 +27,30 @@ static_assert(sizeof(OctDynInst) % 256 == 16, "instance stride must be 2 (mod 32
 #define OCT_CROSS(a, b) {(a)[1] * (b)[2] - (a)[2] * (b)[1], (a)[2] * (b)[0] - (a)[0] * (b)[2], (a)[0] * (b)[1] - (a)[1] * (b)[0]}
 
 // inclusive prefix (towards higher joints) / suffix (towards lower joints) sums of K doubles over the 8 lanes of an instance
+// (interleaved lane layout of saip_oct_common.h: the scans need no masking)
 template <int K>
 __device__ __forceinline__ void oct_prefix_sum(double (&x)[K], const int r) {
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHR + 1>(x[e]);
-		x[e] += (r >= 1) ? v : 0.0;
+#define OCT_PSUM_STEP(D)                                                                              \
+	UNR for (int e = 0; e < K; e++) {                                                                 \
+		const double v = OCT_ILV ? octl_shr<D, false>(x[e]) : oct_dpp<DPP_ROW_SHR + D>(x[e]);         \
+		x[e] += (OCT_ILV || r >= D) ? v : 0.0;                                                        \
 	}
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHR + 2>(x[e]);
-		x[e] += (r >= 2) ? v : 0.0;
-	}
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHR + 4>(x[e]);
-		x[e] += (r >= 4) ? v : 0.0;
-	}
+	OCT_PSUM_STEP(1)
+	OCT_PSUM_STEP(2)
+	OCT_PSUM_STEP(4)
+#undef OCT_PSUM_STEP
 }
 template <int K>
 __device__ __forceinline__ void oct_suffix_sum(double (&x)[K], const int r) {
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHL + 1>(x[e]);
-		x[e] += (r + 1 < 8) ? v : 0.0;
+#define OCT_SSUM_STEP(D)                                                                              \
+	UNR for (int e = 0; e < K; e++) {                                                                 \
+		const double v = OCT_ILV ? octl_shl<D>(x[e]) : oct_dpp<DPP_ROW_SHL + D>(x[e]);                \
+		x[e] += (OCT_ILV || r + D < 8) ? v : 0.0;                                                     \
 	}
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHL + 2>(x[e]);
-		x[e] += (r + 2 < 8) ? v : 0.0;
-	}
-	UNR for (int e = 0; e < K; e++) {
-		const double v = oct_dpp<DPP_ROW_SHL + 4>(x[e]);
-		x[e] += (r + 4 < 8) ? v : 0.0;
-	}
+	OCT_SSUM_STEP(1)
+	OCT_SSUM_STEP(2)
+	OCT_SSUM_STEP(4)
+#undef OCT_SSUM_STEP
 }
 
 // one group of eight instances (block8 = its index) by the calling wavefront; smem = that wavefront's eight LDS blocks.  All
@@ -63,7 +58,7 @@ __device__ __forceinline__ void oct_suffix_sum(double (&x)[K], const int r) {
 // number of wavefronts -- saip_integrate_oct (one) and the fused integrate + next-period OTG launch of saip_otg.hip (four).
 __device__ __forceinline__ void integrate_oct_body(const SimParams& S, OctDynInst* smem, const int block8, const int lane) {
 	constexpr int N = 7;
-	const int r = lane & 7, grp = lane >> 3;
+	const int r = octl_r(lane), grp = octl_grp(lane);
 	const int rr = r < N ? r : N - 1;
 	const bool act = r < N;
 	OctDynInst& sm = smem[grp];
@@ -105,21 +100,9 @@ __device__ __forceinline__ void integrate_oct_body(const SimParams& S, OctDynIns
 			oct_mat3_vec(R0, ax, d);
 			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = p0[e] + d[e] * q_r;
 		}
-#define OCT_PREFIX_STEP(D)                                                                                                          \
-	{                                                                                                                               \
-		double Xa[12], Tn[12];                                                                                                      \
-		UNR for (int e = 0; e < 12; e++) Xa[e] = oct_dpp<DPP_ROW_SHR + D>(Tw[e]);                                                   \
-		UNR for (int i = 0; i < 3; i++) {                                                                                           \
-			UNR for (int j = 0; j < 3; j++) Tn[3 * i + j] = Xa[3 * i] * Tw[j] + Xa[3 * i + 1] * Tw[3 + j] + Xa[3 * i + 2] * Tw[6 + j]; \
-			Tn[9 + i] = Xa[9 + i] + Xa[3 * i] * Tw[9] + Xa[3 * i + 1] * Tw[10] + Xa[3 * i + 2] * Tw[11];                           \
-		}                                                                                                                           \
-		const bool take = r >= D;                                                                                                   \
-		UNR for (int e = 0; e < 12; e++) Tw[e] = take ? Tn[e] : Tw[e];                                                              \
-	}
-		OCT_PREFIX_STEP(1)
-		OCT_PREFIX_STEP(2)
-		OCT_PREFIX_STEP(4)
-#undef OCT_PREFIX_STEP
+	OCT_FRAME_STEP(1, Tw, r)
+	OCT_FRAME_STEP(2, Tw, r)
+	OCT_FRAME_STEP(4, Tw, r)
 		double z[3], o[3] = {Tw[9], Tw[10], Tw[11]};
 		oct_mat3_vec(Tw, ax, z);
 		// joint motion axis about the world origin
