@@ -254,18 +254,24 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
 	}
 
-	// integrator state: requested with the inputs, committed from registers / LDS in the epilogue (the loads used to sit in front of the control
-	// laws and the commit re-read a shadow copy from HBM: 3.1 us per launch with the integrators on, measured; now 0.3)
-	const bool track_mf = (mf.has_ki || P.integ_always), track_jt = (jt.has_ki || P.integ_always);
-	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;
-	if (roleB && track_mf && r < 6) mfi_pre = mf.integ[(size_t)r * ld + b];
-	if (roleA && track_jt) jti_pre = jt.integ[(size_t)(GJ == 1 ? rj : rr) * ld + b];
-	double jkp_r = 0.0, jkv_r = 0.0, jki_r = 0.0;  // this lane's joint gains (per-lane loads: requested here, used by the control law behind M)
-	if (roleA && GJ != 1) {
-		jkp_r = jt.kp[rr];
-		jkv_r = jt.kv[rr];
-		jki_r = jt.ki[rr];
+	// integrator state and this lane's joint gains: requested early, committed from registers / LDS in the epilogue (the loads used to sit in front
+	// of the control laws and the commit re-read a shadow copy from HBM: 3.1 us per launch with the integrators on, measured; now 0.6).  WHERE
+	// they are requested is measured too: the batch-uniform flags that decide about them are scalar loads from the task block, and asked for at
+	// the very start they make the wavefront wait before it has issued anything else -- the two-wavefront form asks behind the local transform
+	// (7.23 -> 7.00 us), the one-wavefront form, which has the motion-force goal loads in flight there anyway, at the start (9.18 vs 9.01 us).
+#define OCT_REQUEST_STATE(SFX)                                                                                          \
+	const bool track_mf##SFX = (mf.has_ki || P.integ_always), track_jt##SFX = (jt.has_ki || P.integ_always);            \
+	double mfi_pre##SFX = 0.0, jti_pre##SFX = 0.0;                                                                      \
+	if (roleB && track_mf##SFX && r < 6) mfi_pre##SFX = mf.integ[(size_t)r * ld + b];                                   \
+	if (roleA && track_jt##SFX) jti_pre##SFX = jt.integ[(size_t)(GJ == 1 ? rj : rr) * ld + b];                          \
+	double jkp_r##SFX = 0.0, jkv_r##SFX = 0.0, jki_r##SFX = 0.0; /* (per-lane gain loads: used by the control law behind M) */ \
+	if (roleA && GJ != 1) {                                                                                             \
+		jkp_r##SFX = jt.kp[rr];                                                                                         \
+		jkv_r##SFX = jt.kv[rr];                                                                                         \
+		jki_r##SFX = jt.ki[rr];                                                                                         \
 	}
+	double jt_ie_new = 0.0;
+	OCT_REQUEST_STATE(_e)  // (dead code in the two-wavefront form: nothing below uses the _e values there)
 
 	STAMP(1);
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -304,12 +310,17 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
 	sm.vec[5][r] = gl3;
-	if (roleB && r < 6) sm.ist[r] = mfi_pre;
-	if (roleA && GJ == 1 && r < 4) sm.ist[6 + r] = jti_pre;
+	OCT_REQUEST_STATE(_l)  // (dead code in the one-wavefront form)
+#undef OCT_REQUEST_STATE
+	const bool track_mf = ROLE == 0 ? track_mf_e : track_mf_l, track_jt = ROLE == 0 ? track_jt_e : track_jt_l;
+	const double mfi_pre = ROLE == 0 ? mfi_pre_e : mfi_pre_l, jti_pre = ROLE == 0 ? jti_pre_e : jti_pre_l;
+	const double jkp_r = ROLE == 0 ? jkp_r_e : jkp_r_l, jkv_r = ROLE == 0 ? jkv_r_e : jkv_r_l, jki_r = ROLE == 0 ? jki_r_e : jki_r_l;
 	OCT_FRAME_STEP(1, Tw, r)
 	OCT_FRAME_STEP(2, Tw, r)
 	OCT_FRAME_STEP(4, Tw, r)
 	UNR for (int e = 0; e < 12; e++) sm.X[r][e] = Tw[e];  // the motion-force task reads its body's frame from here
+	if (roleB && track_mf && r < 6) sm.ist[r] = mfi_pre;  // (behind the frames: the loads have had their time)
+	if (roleA && GJ == 1 && track_jt && r < 4) sm.ist[6 + r] = jti_pre;
 	// this lane's world frame is in Tw (padding lane 7: unused)
 	const bool rev = md.jtype[rr] == 1;
 	double z[3], o[3];
