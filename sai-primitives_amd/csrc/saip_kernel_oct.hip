@@ -238,20 +238,36 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
+	// this joint's constants, requested together with the state.  (Left where they are used, the loads of R0 / p0 / axis sat INSIDE the branch on the
+	// joint type -- a second memory round trip behind the one that fetched the type -- and those of the body's inertia behind the frames: two
+	// exposed round trips at the start of every wavefront.)
+	const int jtype_r = md.jtype[rr];
+	double R0v[9], p0v[3], axv[3];
+	UNR for (int e = 0; e < 9; e++) R0v[e] = md.R0[rr][e];
+	UNR for (int e = 0; e < 3; e++) {
+		p0v[e] = md.p0[rr][e];
+		axv[e] = md.axis[rr][e];
+	}
+	double comv[3] = {0, 0, 0}, inev[6] = {0, 0, 0, 0, 0, 0}, mass_r = 0.0;
+	if (ROLE == 0) {  // (the two-wavefront form asks for the body's inertia behind the local transform: more requests in front of the first wait made it slower)
+		UNR for (int e = 0; e < 3; e++) comv[e] = md.com[rr][e];
+		UNR for (int e = 0; e < 6; e++) inev[e] = md.inertia[rr][e];
+		mass_r = md.mass[rr];
+	}
 	double gl0 = 0.0, gl1 = 0.0, gl2 = 0.0;  // 24 goal rows, 3 per lane
 	if (roleB) {
-		gl0 = mf.goal[(size_t)r * ld + b];
-		gl1 = mf.goal[(size_t)(8 + r) * ld + b];
-		gl2 = mf.goal[(size_t)(16 + r) * ld + b];
+		gl0 = saip_ldg(mf.goal, (size_t)r * ld + b);
+		gl1 = saip_ldg(mf.goal, (size_t)(8 + r) * ld + b);
+		gl2 = saip_ldg(mf.goal, (size_t)(16 + r) * ld + b);
 	}
-	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? mf.goal[(size_t)(24 + r) * ld + b] : 0.0;  // goal force / moment of the general laws
+	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(mf.goal, (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
 	const int mj = GJ == 1 ? jt.m : N;                 // rows of the joint task (Gram path: <= 4)
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
 	if (roleA) {
-		jg_q = jt.goal[(size_t)rj * ld + b];
-		jg_dq = jt.goal[(size_t)(mj + rj) * ld + b];
-		jg_ddq = jt.goal[(size_t)(2 * mj + rj) * ld + b];
+		jg_q = saip_ldg(jt.goal, (size_t)rj * ld + b);
+		jg_dq = saip_ldg(jt.goal, (size_t)(mj + rj) * ld + b);
+		jg_ddq = saip_ldg(jt.goal, (size_t)(2 * mj + rj) * ld + b);
 	}
 
 	// integrator state and this lane's joint gains: requested early, committed from registers / LDS in the epilogue (the loads used to sit in front
@@ -262,8 +278,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #define OCT_REQUEST_STATE(SFX)                                                                                          \
 	const bool track_mf##SFX = (mf.has_ki || P.integ_always), track_jt##SFX = (jt.has_ki || P.integ_always);            \
 	double mfi_pre##SFX = 0.0, jti_pre##SFX = 0.0;                                                                      \
-	if (roleB && track_mf##SFX && r < 6) mfi_pre##SFX = mf.integ[(size_t)r * ld + b];                                   \
-	if (roleA && track_jt##SFX) jti_pre##SFX = jt.integ[(size_t)(GJ == 1 ? rj : rr) * ld + b];                          \
+	if (roleB && track_mf##SFX && r < 6) mfi_pre##SFX = saip_ldg(mf.integ, (size_t)r * ld + b);                                   \
+	if (roleA && track_jt##SFX) jti_pre##SFX = saip_ldg(jt.integ, (size_t)(GJ == 1 ? rj : rr) * ld + b);                          \
 	double jkp_r##SFX = 0.0, jkv_r##SFX = 0.0, jki_r##SFX = 0.0; /* (per-lane gain loads: used by the control law behind M) */ \
 	if (roleA && GJ != 1) {                                                                                             \
 		jkp_r##SFX = jt.kp[rr];                                                                                         \
@@ -277,9 +293,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
 	double Tw[12];
 	{
-		const double* R0 = md.R0[rr];
-		const double ax = md.axis[rr][0], ay = md.axis[rr][1], az = md.axis[rr][2];
-		if (md.jtype[rr] == 1) {
+		const double* R0 = R0v;
+		const double ax = axv[0], ay = axv[1], az = axv[2];
+		if (jtype_r == 1) {
 			double s, c;
 			sincos_joint(q_r, &s, &c);
 			if (md.all_axis_z) {  // (batch-uniform) rotation about the local z axis: R0 Rz(q) mixes the first two columns of R0 only
@@ -296,13 +312,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				UNR for (int i = 0; i < 3; i++)
 					UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
 			}
-			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = p0v[e];
 		} else {
 			UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
 			const double a[3] = {ax, ay, az};
 			double d[3];
 			oct_mat3_vec(R0, a, d);
-			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = p0v[e] + d[e] * q_r;
 		}
 	}
 	sm.vec[0][r] = dq_r;
@@ -311,6 +327,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	sm.vec[12][r] = gl2;
 	sm.vec[5][r] = gl3;
 	OCT_REQUEST_STATE(_l)  // (dead code in the one-wavefront form)
+	if (ROLE == 1) {
+		UNR for (int e = 0; e < 3; e++) comv[e] = md.com[rr][e];
+		UNR for (int e = 0; e < 6; e++) inev[e] = md.inertia[rr][e];
+		mass_r = md.mass[rr];
+	}
 #undef OCT_REQUEST_STATE
 	const bool track_mf = ROLE == 0 ? track_mf_e : track_mf_l, track_jt = ROLE == 0 ? track_jt_e : track_jt_l;
 	const double mfi_pre = ROLE == 0 ? mfi_pre_e : mfi_pre_l, jti_pre = ROLE == 0 ? jti_pre_e : jti_pre_l;
@@ -322,10 +343,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	if (roleB && track_mf && r < 6) sm.ist[r] = mfi_pre;  // (behind the frames: the loads have had their time)
 	if (roleA && GJ == 1 && track_jt && r < 4) sm.ist[6 + r] = jti_pre;
 	// this lane's world frame is in Tw (padding lane 7: unused)
-	const bool rev = md.jtype[rr] == 1;
+	const bool rev = jtype_r == 1;
 	double z[3], o[3];
 	{
-		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
+		const double a[3] = {axv[0], axv[1], axv[2]};
 		oct_mat3_vec(Tw, a, z);
 		UNR for (int e = 0; e < 3; e++) o[e] = Tw[9 + e];
 	}
@@ -341,17 +362,17 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}
 	if (roleA) {
 		double c[3], Bd[10];
-		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
+		const double cl[3] = {comv[0], comv[1], comv[2]};
 		oct_mat3_vec(Tw, cl, c);
 		UNR for (int e = 0; e < 3; e++) c[e] += o[e];
-		const double* I6 = md.inertia[rr];
+		const double* I6 = inev;
 		const double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
 		double RI[9], Iw[9];
 		UNR for (int i = 0; i < 3; i++)
 			UNR for (int j = 0; j < 3; j++) RI[3 * i + j] = Tw[3 * i] * Il[j] + Tw[3 * i + 1] * Il[3 + j] + Tw[3 * i + 2] * Il[6 + j];
 		UNR for (int i = 0; i < 3; i++)
 			UNR for (int j = 0; j < 3; j++) Iw[3 * i + j] = RI[3 * i] * Tw[3 * j] + RI[3 * i + 1] * Tw[3 * j + 1] + RI[3 * i + 2] * Tw[3 * j + 2];
-		const double m = md.mass[rr], cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+		const double m = mass_r, cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
 		Bd[0] = m;
 		Bd[1] = m * c[0];
 		Bd[2] = m * c[1];
@@ -1073,12 +1094,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				const bool r1b = P.any_bie && !general_bie;
 				UNR for (int j = 0; j < N; j++) mcol[j] = r1b ? smA.vec[3][j] : 0.0;
 				UNR for (int j = 0; j < N; j++) mb[j] = general_bie ? smA.Lam[r][j] : mi[j];
-				jg_q = jt.goal[(size_t)rr * ld + b];
-				jg_dq = jt.goal[(size_t)(N + rr) * ld + b];
-				jg_ddq = jt.goal[(size_t)(2 * N + rr) * ld + b];
+				jg_q = saip_ldg(jt.goal, (size_t)rr * ld + b);
+				jg_dq = saip_ldg(jt.goal, (size_t)(N + rr) * ld + b);
+				jg_ddq = saip_ldg(jt.goal, (size_t)(2 * N + rr) * ld + b);
 				const double e = q_r - jg_q;
 				double ie = 0.0;
-				if (jt.has_ki || P.integ_always) ie = jt.integ[(size_t)rr * ld + b];
+				if (jt.has_ki || P.integ_always) ie = saip_ldg(jt.integ, (size_t)rr * ld + b);
 				ie += e * jt.dt;
 				if (jt.vel_sat) {
 					double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;

@@ -92,29 +92,45 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	// ---------------------------------------------------------------- inputs
 	const double q_r = P.q[(size_t)rr * ld + b];
 	const double dq_r = P.dq[(size_t)rr * ld + b];
+	// this joint's constants, requested together with the state.  (Left where they are used, the loads of R0 / p0 / axis sat INSIDE the branch on the
+	// joint type -- a second memory round trip behind the one that fetched the type -- and those of the body's inertia behind the frames: two
+	// exposed round trips at the start of every wavefront.)
+	const int jtype_r = md.jtype[rr];
+	double R0v[9], p0v[3], axv[3];
+	UNR for (int e = 0; e < 9; e++) R0v[e] = md.R0[rr][e];
+	UNR for (int e = 0; e < 3; e++) {
+		p0v[e] = md.p0[rr][e];
+		axv[e] = md.axis[rr][e];
+	}
+	double comv[3] = {0, 0, 0}, inev[6] = {0, 0, 0, 0, 0, 0}, mass_r = 0.0;
+	if (roleA) {
+		UNR for (int e = 0; e < 3; e++) comv[e] = md.com[rr][e];
+		UNR for (int e = 0; e < 6; e++) inev[e] = md.inertia[rr][e];
+		mass_r = md.mass[rr];
+	}
 	const int ra = r < m ? r : 0;
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
 	if (roleA) {
-		jg_q = jt.goal[(size_t)ra * ld + b];
-		jg_dq = jt.goal[(size_t)(m + ra) * ld + b];
-		jg_ddq = jt.goal[(size_t)(2 * m + ra) * ld + b];
+		jg_q = saip_ldg(jt.goal, (size_t)ra * ld + b);
+		jg_dq = saip_ldg(jt.goal, (size_t)(m + ra) * ld + b);
+		jg_ddq = saip_ldg(jt.goal, (size_t)(2 * m + ra) * ld + b);
 	}
 	const bool track_mf = mf.has_ki || P.integ_always, track_jt = jt.has_ki || P.integ_always;
 	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;  // integrator state: requested with the inputs, committed from LDS / registers in the epilogue
-	if (roleB && track_mf && r < 6) mfi_pre = mf.integ[(size_t)r * ld + b];
-	if (roleA && track_jt) jti_pre = jt.integ[(size_t)ra * ld + b];
+	if (roleB && track_mf && r < 6) mfi_pre = saip_ldg(mf.integ, (size_t)r * ld + b);
+	if (roleA && track_jt) jti_pre = saip_ldg(jt.integ, (size_t)ra * ld + b);
 	const int gc = mf.goal_comps < 32 ? mf.goal_comps : 32;
 	double gl[4] = {0.0, 0.0, 0.0, 0.0};
 	if (roleB) {
-		UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? mf.goal[(size_t)(8 * c + r) * ld + b] : 0.0;
+		UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? saip_ldg(mf.goal, (size_t)(8 * c + r) * ld + b) : 0.0;
 	}
 
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
 	double Tw[12];
 	{
-		const double* R0 = md.R0[rr];
-		const double ax = md.axis[rr][0], ay = md.axis[rr][1], az = md.axis[rr][2];
-		if (md.jtype[rr] == 1) {
+		const double* R0 = R0v;
+		const double ax = axv[0], ay = axv[1], az = axv[2];
+		if (jtype_r == 1) {
 			double s, c;
 			sincos_joint(q_r, &s, &c);
 			if (md.all_axis_z) {  // (batch-uniform) rotation about the local z axis: R0 Rz(q) mixes the first two columns of R0 only
@@ -131,13 +147,13 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 				UNR for (int i = 0; i < 3; i++)
 					UNR for (int j = 0; j < 3; j++) Tw[3 * i + j] = R0[3 * i] * Rq[j] + R0[3 * i + 1] * Rq[3 + j] + R0[3 * i + 2] * Rq[6 + j];
 			}
-			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e];
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = p0v[e];
 		} else {
 			UNR for (int e = 0; e < 9; e++) Tw[e] = R0[e];
 			const double a[3] = {ax, ay, az};
 			double d[3];
 			oct_mat3_vec(R0, a, d);
-			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = md.p0[rr][e] + d[e] * q_r;
+			UNR for (int e = 0; e < 3; e++) Tw[9 + e] = p0v[e] + d[e] * q_r;
 		}
 	}
 	if (roleA) {
@@ -157,10 +173,10 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	OCT_FRAME_STEP(4, Tw, r)
 	double (*Xf)[12] = (ROLE == 2) ? bx[grp] : sm.X;  // the frames of this wavefront (B: its own block)
 	UNR for (int e = 0; e < 12; e++) Xf[r][e] = Tw[e];
-	const bool rev = md.jtype[rr] == 1;
+	const bool rev = jtype_r == 1;
 	double z[3], o[3];
 	{
-		const double a[3] = {md.axis[rr][0], md.axis[rr][1], md.axis[rr][2]};
+		const double a[3] = {axv[0], axv[1], axv[2]};
 		oct_mat3_vec(Tw, a, z);
 		UNR for (int e = 0; e < 3; e++) o[e] = Tw[9 + e];
 	}
@@ -178,17 +194,17 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	double Ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	if (roleA) {
 		double c[3], Bd[10];
-		const double cl[3] = {md.com[rr][0], md.com[rr][1], md.com[rr][2]};
+		const double cl[3] = {comv[0], comv[1], comv[2]};
 		oct_mat3_vec(Tw, cl, c);
 		UNR for (int e = 0; e < 3; e++) c[e] += o[e];
-		const double* I6 = md.inertia[rr];
+		const double* I6 = inev;
 		const double Il[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
 		double RI[9], Iw[9];
 		UNR for (int i = 0; i < 3; i++)
 			UNR for (int j = 0; j < 3; j++) RI[3 * i + j] = Tw[3 * i] * Il[j] + Tw[3 * i + 1] * Il[3 + j] + Tw[3 * i + 2] * Il[6 + j];
 		UNR for (int i = 0; i < 3; i++)
 			UNR for (int j = 0; j < 3; j++) Iw[3 * i + j] = RI[3 * i] * Tw[3 * j] + RI[3 * i + 1] * Tw[3 * j + 1] + RI[3 * i + 2] * Tw[3 * j + 2];
-		const double ms = md.mass[rr], cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+		const double ms = mass_r, cc2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
 		Bd[0] = ms;
 		Bd[1] = ms * c[0];
 		Bd[2] = ms * c[1];

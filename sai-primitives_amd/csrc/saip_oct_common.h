@@ -7,6 +7,14 @@ namespace saip {
 
 #define UNR _Pragma("unroll")
 
+// a load through a pointer that was itself read from memory (TaskDev::goal, ::integ): the compiler only knows it as a generic address and emits
+// flat_load, which may complete out of order with the global loads around it -- every wait behind it then becomes a wait for EVERYTHING in
+// flight (vmcnt(0)).  The arrays are in HBM: say so, and the waits stay counted.
+__device__ __forceinline__ double saip_ldg(const double* p, const size_t i) {
+	typedef const double __attribute__((address_space(1))) * gptr_t;
+	return ((gptr_t)(unsigned long long)p)[i];
+}
+
 // 1/x and 1/sqrt(x) from the hardware estimates plus two Newton steps: full double accuracy for the normal-range, positive arguments met
 // here (pivots of SPD factorisations), without the scaling / fix-up sequences of the IEEE division and the library rsqrt
 __device__ __forceinline__ double oct_rcp(const double x) {
