@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		if (tk.type != TASK_MOTION_FORCE) continue;
 		const bool track = tk.has_ki || P.integ_always;
 		const int k = tk.k, bd = tk.body;
-		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = tk.goal[(size_t)e * ld + b];
+		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = saip_ldg(tk.goal, (size_t)e * ld + b);
 		double Rb[9], ob[3], pw[3], Rcf[9];
 		UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bd][e];
 		UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bd][9 + e];
@@ -277,12 +277,12 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			double ip[3] = {0, 0, 0}, io[3] = {0, 0, 0}, ifm[6] = {0, 0, 0, 0, 0, 0};
 			if (track)
 				for (int i = 0; i < 3; i++) {
-					ip[i] = tk.integ[(size_t)i * ld + b];
-					io[i] = tk.integ[(size_t)(3 + i) * ld + b];
+					ip[i] = saip_ldg(tk.integ, (size_t)i * ld + b);
+					io[i] = saip_ldg(tk.integ, (size_t)(3 + i) * ld + b);
 				}
 			const bool closed = tk.cl_force || tk.cl_moment;
 			if (closed)
-				for (int i = 0; i < 6; i++) ifm[i] = tk.integ[(size_t)(6 + i) * ld + b];
+				for (int i = 0; i < 6; i++) ifm[i] = saip_ldg(tk.integ, (size_t)(6 + i) * ld + b);
 			bool ovf = false;
 			if (tk.general_law) {
 				// velocity saturation, force / moment spaces, open- or closed-loop force control
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		const bool track = tk.has_ki || P.integ_always;
 		WSTAMP(8 + 10 * t);
 		if (tk.type != TASK_MOTION_FORCE)
-			for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = tk.goal[(size_t)e * ld + b];
+			for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = saip_ldg(tk.goal, (size_t)e * ld + b);
 		if (tk.decoupling == DEC_BIE && tk.bie_threshold != P.bie_thr) {
 			flagged = true;
 			break;
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 						}
 					}
 					const double e = cur - sm.goal[j];
-					double ie = track ? tk.integ[(size_t)j * ld + b] : 0.0;
+					double ie = track ? saip_ldg(tk.integ, (size_t)j * ld + b) : 0.0;
 					ie += e * tk.dt;  // JointTask.cpp:323-324
 					if (track) tk.integ_new[(size_t)j * ld + b] = ie;
 					if (tk.vel_sat) {  // JointTask.cpp:327-341
@@ -1008,9 +1008,9 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			const TaskDev& tk = P.tasks[t];
 			const int rows = tk.type == TASK_MOTION_FORCE ? 6 : tk.m;
 			if ((commit_lo >> t) & 1u)
-				for (int i = lane; i < rows; i += 64) tk.integ[(size_t)i * ld + b] = tk.integ_new[(size_t)i * ld + b];
+				for (int i = lane; i < rows; i += 64) tk.integ[(size_t)i * ld + b] = saip_ldg(tk.integ_new, (size_t)i * ld + b);
 			if ((commit_hi >> t) & 1u)
-				for (int i = lane; i < 6; i += 64) tk.integ[(size_t)(6 + i) * ld + b] = tk.integ_new[(size_t)(6 + i) * ld + b];
+				for (int i = lane; i < 6; i += 64) tk.integ[(size_t)(6 + i) * ld + b] = saip_ldg(tk.integ_new, (size_t)(6 + i) * ld + b);
 		}
 	}
 }
