@@ -211,10 +211,29 @@ __device__ __forceinline__ void oct_sync() {
 // NN: dof of the chain.  7 everywhere except the general instantiation <true, 2, ...> (full joint task behind a motion-force task, rank
 // n - k by multi-pivot Gram-Schmidt), which also exists for 6 and 8 dof: with 8 no lane is padding, with 6 two are.
 template <bool FULL, int GJ, int ROLE, int NN = 7>
-__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB) {
+__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = NN;
+#if !defined(SAIP_OCT_NO_BROWS)
+	// Lean two-wavefront form: B does not wait where A takes the Jacobian from it -- A polls a flag in LDS instead of both meeting at a workgroup
+	// barrier (B was there 1.3 k clocks early) -- and B uses the time it gains to form the rows of A = T1 J^T from the T1 that A publishes
+	// (second flag), which takes the second half of the T1 / A phase off A's chain: 7.04 -> 6.91 us (same session; -DSAIP_OCT_NO_BROWS for the A/B).
+	// The flags live in LDS, are zeroed behind one early workgroup barrier, and every poll loop is bounded.
+	constexpr bool BROWS = DUO && !FULL && GJ == 0;
+	auto flag_wait = [&](const int k) {
+		int it = 0, v = 0;
+		while ((v = __hip_atomic_load(wgflags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++it < 200000) __builtin_amdgcn_s_sleep(1);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		return v;
+	};
+	auto flag_set = [&](const int k, const int v) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if ((threadIdx.x & 63) == 0) __hip_atomic_store(wgflags + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+#else
+	constexpr bool BROWS = false;
+#endif
 	static_assert(NN == 7 || (FULL && GJ == 2), "6- and 8-dof chains: the general instantiation only");
 	const int lane = threadIdx.x & 63;
 	const int r = octl_r(lane), grp = octl_grp(lane);
@@ -463,6 +482,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			fi_pre = -jkp_r * e - jkv_r * (dq_r - jg_dq) - jki_r * ie;  // :342-345
 		}
 	}
+#if !defined(SAIP_OCT_NO_BROWS)
+	if (BROWS) {
+		if (ROLE == 2) flag_set(0, 1);  // B: the Jacobian is in its block
+		oct_sync<DUO>();
+	} else
+#endif
 	if (DUO && !trunc_mode) __syncthreads();  // workgroup barrier: B's Jacobian is complete (A arrives ~1 k clocks after B)
 	else oct_sync<DUO>();                     // (reduced tasks: A waits further down, for the Jacobian B has reduced)
 	STAMP(3);
@@ -520,6 +545,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		__syncthreads();
 		keep_bits_b = (unsigned)smB.vec[6][7];
 	}
+#if !defined(SAIP_OCT_NO_BROWS)
+	if (BROWS && ROLE == 1) (void)flag_wait(0);
+#endif
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = (ROLE == 1 ? smB : sm).J[a][j];
 	double vw[6] = {0, 0, 0, 0, 0, 0};
@@ -736,6 +764,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			sm.T1[a][r] = t1c[a];
 			if (general_bie) sm.Lam[a][r] = tbc[a];
 		}
+#if !defined(SAIP_OCT_NO_BROWS)
+		const bool rows_by_b = BROWS && ROLE == 1 && !general_bie;
+		if (BROWS && ROLE == 1) flag_set(1, general_bie ? 2 : 1);
+#else
+		const bool rows_by_b = false;
+#endif
 		oct_sync<DUO>();
 		if (rank1_bie) {
 			double mee = 0.0;
@@ -750,6 +784,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			t1[j] = sm.T1[ra][j];
 			tb[j] = general_bie ? sm.Lam[ra][j] : 0.0;
 		}
+		if (!rows_by_b) {
 		UNR for (int c = 0; c < 6; c++) {
 			double s = 0.0, s2 = 0.0;
 			UNR for (int j = 0; j < N; j++) {
@@ -759,6 +794,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			const bool padrow = FULL && !keep_ra && c == ra;  // zero row of a partial / reduced task: keep the factorisation regular
 			sm.A[r][c] = padrow ? 1.0 : s;
 			if (general_bie) sm.Am[r][c] = padrow ? 1.0 : s2;
+		}
 		}
 		if (ROLE == 1) {  // what the blended block (run by B) wants from this wavefront besides A, T1, M and the columns of M^-1
 			if (general_bie) {
@@ -916,6 +952,19 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 			if (r == 6) sm.vec[6][6] = (singular ? 1.0 : 0.0) + (truncated ? 2.0 : 0.0);
 		}
+#if !defined(SAIP_OCT_NO_BROWS)
+		if (BROWS && ROLE == 2) {
+			if (flag_wait(1) == 1) {  // the rows of A = T1 J^T, into A's block
+				double t1[N];
+				UNR for (int j = 0; j < N; j++) t1[j] = smA.T1[ra][j];
+				UNR for (int c = 0; c < 6; c++) {
+					double s = 0.0;
+					UNR for (int j = 0; j < N; j++) s = fma(t1[j], Jf[c][j], s);
+					smA.A[r][c] = s;
+				}
+			}
+		}
+#endif
 		STAMP(29);
 		__syncthreads();
 		STAMP(30);
@@ -1975,9 +2024,16 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CyclePara
 	__shared__ OctInst smem[DUO ? 16 : 8];
 	static_assert(sizeof(OctInst) >= sizeof(OctDynInst), "the integration step reuses the cycle's LDS blocks");
 	const bool wave_b = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
+	__shared__ int wgflags[2];
+#if !defined(SAIP_OCT_NO_BROWS)
+	if (DUO && !FULL && GJ == 0) {
+		if (threadIdx.x == 0) wgflags[0] = wgflags[1] = 0;
+		__syncthreads();
+	}
+#endif
 	if (DUO) {
-		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8);
+		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8, wgflags);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags);
 	} else {
 		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem);
 	}
