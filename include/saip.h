@@ -344,7 +344,8 @@ saip_status saip_batch_set_state_device(saip_batch*, const double* q_dev, const 
 saip_status saip_batch_wait_for(saip_batch* waiter, saip_batch* producer);
 
 /* kernel selection: 0 = auto, 1 = general workgroup-per-instance kernel, 2 = lane-per-instance register kernel (dof <= 8),
- * 3 = eight-lanes-per-instance kernel (7-dof chain, full MotionForceTask + full JointTask; the auto choice for batches <= 8192),
+ * 3 = eight-lanes-per-instance kernel (7-dof chain, full MotionForceTask + full JointTask; the auto choice for batches <= 24576 of that stack, and at every batch size for its partial-task /
+ *     reduced-task / joint-first / 6- and 8-dof instantiations),
  * 4 = wavefront-per-instance kernel on the FP64 matrix cores (chains of 9..32 dof; the auto choice there) */
 saip_status saip_batch_set_kernel(saip_batch*, int which);
 const char* saip_batch_kernel_name(saip_batch*);

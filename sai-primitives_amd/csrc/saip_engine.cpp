@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1566,9 +1567,16 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 			P.flag_count_next = nxt;
 		}
 		// small batches of the headline stack: eight lanes per instance (the lane kernel would leave most of the chip idle)
+		// Up to which batch: 1024 wavefronts (8192 instances) are resident at once, larger launches run in rounds.  Measured against the lane
+		// kernel (tools/ab_cliff.sh, round 3): the lean instantiation (config 2's stack) stays ahead up to 24 576 instances (26.8 against
+		// 31.1 us) and is level at 32 768; every other instantiation -- partial tasks, reduced tasks, joint task first, 6 / 8 dof -- is ahead
+		// at every size (config 3: 109 against 195 us at 65 536, 384 against 627 at 262 144; config 6: 102 against 190 at 65 536), and
+		// stacks whose instances leave the non-singular branch are not a contest (the lane kernel hands those to the general kernel).
 		static const char* oct_env = getenv("SAIP_OCT_MAX_BATCH");
-		const int oct_max = oct_env ? atoi(oct_env) : 8192;  // four wavefronts per CU (35 KB of LDS each): beyond that the lane kernel wins (measured)
-		const bool oct = oct_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
+		const bool oct_ok = oct_eligible(b, P);
+		const bool oct_lean = oct_ok && P.oct_general_joint == 0 && !(P.jla || P.lane_general || P.oct_partial_mf);
+		const int oct_max = oct_env ? atoi(oct_env) : (oct_lean ? 24576 : INT_MAX);
+		const bool oct = oct_ok && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
 		const bool octjf = !oct && octjf_eligible(b, P) && (b->kernel_choice == 3 || (b->kernel_choice == 0 && b->B <= oct_max));
 		// the eight-lane kernel runs the blended singularity strategies of the headline stack itself (and passes a fully singular task
 		// through): with the handling enforced nothing is left for a slow path, and what it still refuses the general kernel would too

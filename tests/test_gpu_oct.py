@@ -201,9 +201,9 @@ def test_oct_uniform_postures_predicate_matches_oracle():
     assert W.torque_error(tau[ok], ref[ok]) < TOL
 
 
-@pytest.mark.parametrize("cfg,B,kernel", [(2, 4096, 2), (2, 16384, 0), (12, 768, 2), (14, 768, 2)])
+@pytest.mark.parametrize("cfg,B,kernel", [(2, 4096, 2), (2, 28672, 0), (12, 768, 2), (14, 768, 2)])
 def test_lane_kernel_on_the_same_stack(cfg, B, kernel):
-    """the lane-per-instance kernel stays the path of this stack for batches above 8192 (auto) and on request (selector 2)"""
+    """the lane-per-instance kernel stays the path of the lean stack for batches above 24576 (auto) and of every stack on request (selector 2)"""
     from oracle import Oracle
     d = W.make_inputs(cfg, B)
     ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)

@@ -51,7 +51,7 @@ def test_config6_golden():
 
 
 def test_config6_auto_choice_and_oracle():
-    """the automatic choice picks this kernel for batches up to 8192; 4096 instances of the seeded stream against the oracle"""
+    """the automatic choice picks this kernel at every batch size; 4096 instances of the seeded stream against the oracle"""
     from oracle import Oracle
     B = 4096
     d = W.make_inputs(6, B)

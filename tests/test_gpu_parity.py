@@ -92,7 +92,7 @@ def test_ragged_batches(B, kernel):
 
 def test_config4_shard_size_and_lean_variant():
     """BASELINE config 4 = 8 x 8192 instances of the config-2 stack: one per-GPU shard (rank 3 of the seeded stream) against the
-    oracle, and the large-batch (> 16384) instantiation of the lane kernel against the default one on the same inputs"""
+    oracle; then the same rows tiled to 20480 (eight-lane kernel in rounds) and 28672 instances (large-batch instantiation of the lane kernel)"""
     from oracle import Oracle
     d = W.make_inputs(4, 8192, shard=3)
     robot, ctrl, _ = _engine(d["model"].name, d["tasks"], 8192)
@@ -100,14 +100,17 @@ def test_config4_shard_size_and_lean_variant():
     ref, st = Oracle(d["model"], d["tasks"]).step(d["q"], d["dq"], d["goals"], nthreads=8)
     assert st.sum() == 0 and ctrl.status.sum() == 0
     assert W.torque_error(tau, ref) < TOL
-    B = 20480
-    reps = B // 4096
-    q, dq = np.tile(d["q"][:4096], (reps, 1)), np.tile(d["dq"][:4096], (reps, 1))
-    goals = [np.tile(g[:4096], (reps, 1)) for g in d["goals"]]
-    robot2, ctrl2, _ = _engine(d["model"].name, d["tasks"], B)
-    tau2 = _run(robot2, ctrl2, q, dq, goals)
-    assert ctrl2.status.sum() == 0
-    assert W.torque_error(tau2[:4096], ref[:4096]) < TOL and W.torque_error(tau2[-4096:], ref[:4096]) < TOL
+    # past 8192 instances the eight-lane kernel runs in rounds (automatic choice up to 24576 for this stack), beyond that the lane kernel's
+    # large-batch instantiation takes over: both against the same oracle rows
+    for B, kernel in ((20480, "saip_cycle_oct"), (28672, "saip_cycle_lane")):
+        reps = B // 4096
+        q, dq = np.tile(d["q"][:4096], (reps, 1)), np.tile(d["dq"][:4096], (reps, 1))
+        goals = [np.tile(g[:4096], (reps, 1)) for g in d["goals"]]
+        robot2, ctrl2, _ = _engine(d["model"].name, d["tasks"], B)
+        tau2 = _run(robot2, ctrl2, q, dq, goals)
+        assert ctrl2.kernelName() == kernel
+        assert ctrl2.status.sum() == 0
+        assert W.torque_error(tau2[:4096], ref[:4096]) < TOL and W.torque_error(tau2[-4096:], ref[:4096]) < TOL
 
 
 def test_general_kernel_explicitly_selected():
