@@ -47,3 +47,5 @@ if (sB[:, 29] > 0).all():
           f"  A waits at the barrier (stamp 9 -> 30): median {np.median(s[:, 30] - s[:, 9]):.0f};  B start - A start: median {np.median(sB[:, 0] - s[:, 0]):.0f}")
     if (s[:, 31] > 0).all():
         print(f"  second barrier: A arrives {np.median(s[:, 31] - s[:, 30]):.0f} after the first one, B {np.median(sB[:, 31] - s[:, 30]):.0f};  A: second barrier -> end of the tail {np.median(s[:, 14] - s[:, 31]):.0f}")
+if (s[:, 11] > 0).all():  # general joint task (GJ != 0): the tail split at stamp 11
+    print(f"general joint task: tau + column of N1 (10 -> 11) median {np.median(s[:, 11] - s[:, 10]):.0f}; joint task proper (11 -> 14) median {np.median(s[:, 14] - s[:, 11]):.0f}")
