@@ -234,6 +234,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #else
 	constexpr bool BROWS = false;
 #endif
+	bool lost = false;  // a bounded poll ran out (cannot happen while both wavefronts of the workgroup run; if it ever does, the instances end flagged, not silently wrong)
 	static_assert(NN == 7 || (FULL && GJ == 2), "6- and 8-dof chains: the general instantiation only");
 	const int lane = threadIdx.x & 63;
 	const int r = octl_r(lane), grp = octl_grp(lane);
@@ -546,7 +547,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		keep_bits_b = (unsigned)smB.vec[6][7];
 	}
 #if !defined(SAIP_OCT_NO_BROWS)
-	if (BROWS && ROLE == 1) (void)flag_wait(0);
+	if (BROWS && ROLE == 1) lost = flag_wait(0) == 0;
 #endif
 	UNR for (int a = 0; a < 6; a++)
 		UNR for (int j = 0; j < N; j++) Jf[a][j] = (ROLE == 1 ? smB : sm).J[a][j];
@@ -954,7 +955,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		}
 #if !defined(SAIP_OCT_NO_BROWS)
 		if (BROWS && ROLE == 2) {
-			if (flag_wait(1) == 1) {  // the rows of A = T1 J^T, into A's block
+			const int f1 = flag_wait(1);
+			lost = f1 == 0;
+			if (f1 == 1) {  // the rows of A = T1 J^T, into A's block
 				double t1[N];
 				UNR for (int j = 0; j < N; j++) t1[j] = smA.T1[ra][j];
 				UNR for (int c = 0; c < 6; c++) {
@@ -1551,7 +1554,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				sm.vec[7][r] = zr;
 				sm.vec[8][r] = v_own;
 				sm.vec[1][r] = tvo;
-				sm.vec[2][r] = (ovr ? 1.0 : 0.0) + (singular ? 2.0 : 0.0) + (truncated ? 4.0 : 0.0) + (blended_i ? 8.0 : 0.0);
+				sm.vec[2][r] = (ovr ? 1.0 : 0.0) + (singular ? 2.0 : 0.0) + (truncated ? 4.0 : 0.0) + (blended_i ? 8.0 : 0.0) + (lost ? 16.0 : 0.0);
 				if (r == 0) {
 					sm.vec[3][0] = zz;
 					sm.vec[3][1] = zv;
@@ -1572,6 +1575,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				singular = (fl & 2) != 0;
 				truncated = (fl & 4) != 0;
 				blended_i = (fl & 8) != 0;
+				lost = lost || (fl & 16) != 0;
 			}
 		}
 		if (ROLE == 1) {
@@ -1598,6 +1602,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		tv = fma(v_own * oct_rcp(zz), fma(rho, zf, za), tau_r);  // tau += Jh^T g
 		}
 		if (ovr) tv = tvo;  // the blended strategies / the pass-through of a fully singular task decided this instance's torque
+		if (BROWS && lost) singular = true;
 
 	} else {
 	{
