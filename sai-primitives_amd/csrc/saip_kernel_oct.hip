@@ -211,7 +211,7 @@ __device__ __forceinline__ void oct_sync() {
 // NN: dof of the chain.  7 everywhere except the general instantiation <true, 2, ...> (full joint task behind a motion-force task, rank
 // n - k by multi-pivot Gram-Schmidt), which also exists for 6 and 8 dof: with 8 no lane is padding, with 6 two are.
 template <bool FULL, int GJ, int ROLE, int NN = 7>
-__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr) {
+__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr, double* lawc = nullptr) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = NN;
@@ -281,6 +281,19 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		gl2 = saip_ldg(mf.goal, (size_t)(16 + r) * ld + b);
 	}
 	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(mf.goal, (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
+	// partial motion-force tasks: the control law multiplies by ninety batch-uniform constants (Bm, the projections, the sigma matrices, the
+	// gains: one contiguous run of the task block).  Read where the law runs -- behind a dozen wavefront fences -- they were 120 loads with
+	// their memory round trip in front of the law (3.0 k of B's 12.3 k clocks on config 3); requested here, two per lane, parked in LDS.
+	static_assert(offsetof(TaskDev, Ppos) == offsetof(TaskDev, Bm) + 36 * 8 && offsetof(TaskDev, Pori) == offsetof(TaskDev, Bm) + 45 * 8 &&
+					  offsetof(TaskDev, sig_p) == offsetof(TaskDev, Bm) + 54 * 8 && offsetof(TaskDev, sig_o) == offsetof(TaskDev, Bm) + 63 * 8 &&
+					  offsetof(TaskDev, kp_pos) == offsetof(TaskDev, Bm) + 72 * 8 && offsetof(TaskDev, ki_ori) == offsetof(TaskDev, Bm) + 87 * 8,
+				  "the law constants are one contiguous run");
+	double lc0 = 0.0, lc1 = 0.0;
+	if (FULL && roleB) {
+		const double* lsrc = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&mf) + offsetof(TaskDev, Bm));
+		lc0 = lsrc[lane];
+		lc1 = lsrc[lane < 26 ? 64 + lane : 89];
+	}
 	const int mj = GJ == 1 ? jt.m : N;                 // rows of the joint task (Gram path: <= 4)
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
@@ -346,6 +359,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	sm.vec[11][r] = gl1;
 	sm.vec[12][r] = gl2;
 	sm.vec[5][r] = gl3;
+	if (FULL && roleB) {
+		lawc[lane] = lc0;
+		if (lane < 26) lawc[64 + lane] = lc1;
+	}
 	OCT_REQUEST_STATE(_l)  // (dead code in the one-wavefront form)
 	if (ROLE == 1) {
 		UNR for (int e = 0; e < 3; e++) comv[e] = md.com[rr][e];
@@ -459,7 +476,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		if (FULL && !mf.bm_identity) {  // partial task: rows of the Jacobian in the basis of range(P), Jb = Bm^T Jw (columns >= k of Bm are zero)
 			UNR for (int a = 0; a < 6; a++) {
 				double sj = 0.0;
-				UNR for (int e = 0; e < 6; e++) sj = fma(mf.Bm[e * 6 + a], jw[e], sj);
+				UNR for (int e = 0; e < 6; e++) sj = fma(lawc[e * 6 + a], jw[e], sj);
 				sm.J[a][r] = sj;
 			}
 		} else {
@@ -881,13 +898,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			// F in the basis of range(P): fhat = Bm^T F_um
 			double v[3], w[3], e3[3], tmp[3], Fw[6];
 			UNR for (int i = 0; i < 3; i++) {
-				v[i] = mf.Ppos[3 * i] * vw[0] + mf.Ppos[3 * i + 1] * vw[1] + mf.Ppos[3 * i + 2] * vw[2];
-				w[i] = mf.Pori[3 * i] * vw[3] + mf.Pori[3 * i + 1] * vw[4] + mf.Pori[3 * i + 2] * vw[5];
+				v[i] = lawc[36 + 3 * i] * vw[0] + lawc[36 + 3 * i + 1] * vw[1] + lawc[36 + 3 * i + 2] * vw[2];
+				w[i] = lawc[45 + 3 * i] * vw[3] + lawc[45 + 3 * i + 1] * vw[4] + lawc[45 + 3 * i + 2] * vw[5];
 			}
 			UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G24[i];
-			UNR for (int i = 0; i < 3; i++) ip[i] += (mf.sig_p[3 * i] * e3[0] + mf.sig_p[3 * i + 1] * e3[1] + mf.sig_p[3 * i + 2] * e3[2]) * mf.dt;
-			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - mf.kp_pos[i] * e3[i] - mf.kv_pos[i] * (v[i] - G24[12 + i]) - mf.ki_pos[i] * ip[i];
-			UNR for (int i = 0; i < 3; i++) Fw[i] = mf.sig_p[3 * i] * tmp[0] + mf.sig_p[3 * i + 1] * tmp[1] + mf.sig_p[3 * i + 2] * tmp[2];
+			UNR for (int i = 0; i < 3; i++) ip[i] += (lawc[54 + 3 * i] * e3[0] + lawc[54 + 3 * i + 1] * e3[1] + lawc[54 + 3 * i + 2] * e3[2]) * mf.dt;
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[18 + i] - lawc[72 + i] * e3[i] - lawc[75 + i] * (v[i] - G24[12 + i]) - lawc[78 + i] * ip[i];
+			UNR for (int i = 0; i < 3; i++) Fw[i] = lawc[54 + 3 * i] * tmp[0] + lawc[54 + 3 * i + 1] * tmp[1] + lawc[54 + 3 * i + 2] * tmp[2];
 			double oe[3] = {0, 0, 0};
 			UNR for (int c = 0; c < 3; c++) {
 				const double a0 = Rc[c], a1 = Rc[3 + c], a2 = Rc[6 + c], b0 = G24[3 + c], b1 = G24[6 + c], b2 = G24[9 + c];
@@ -896,13 +913,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
 			}
 			double dphi[3];
-			UNR for (int i = 0; i < 3; i++) dphi[i] = mf.sig_o[3 * i] * oe[0] + mf.sig_o[3 * i + 1] * oe[1] + mf.sig_o[3 * i + 2] * oe[2];
+			UNR for (int i = 0; i < 3; i++) dphi[i] = lawc[63 + 3 * i] * oe[0] + lawc[63 + 3 * i + 1] * oe[1] + lawc[63 + 3 * i + 2] * oe[2];
 			UNR for (int i = 0; i < 3; i++) io[i] += dphi[i] * mf.dt;
-			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - mf.kp_ori[i] * dphi[i] - mf.kv_ori[i] * (w[i] - G24[15 + i]) - mf.ki_ori[i] * io[i];
-			UNR for (int i = 0; i < 3; i++) Fw[3 + i] = mf.sig_o[3 * i] * tmp[0] + mf.sig_o[3 * i + 1] * tmp[1] + mf.sig_o[3 * i + 2] * tmp[2];
+			UNR for (int i = 0; i < 3; i++) tmp[i] = G24[21 + i] - lawc[81 + i] * dphi[i] - lawc[84 + i] * (w[i] - G24[15 + i]) - lawc[87 + i] * io[i];
+			UNR for (int i = 0; i < 3; i++) Fw[3 + i] = lawc[63 + 3 * i] * tmp[0] + lawc[63 + 3 * i + 1] * tmp[1] + lawc[63 + 3 * i + 2] * tmp[2];
 			UNR for (int a = 0; a < 6; a++) {
 				double sf = 0.0;
-				UNR for (int e = 0; e < 6; e++) sf = fma(mf.Bm[e * 6 + a], Fw[e], sf);
+				UNR for (int e = 0; e < 6; e++) sf = fma(lawc[0 + e * 6 + a], Fw[e], sf);
 				Fum[a] = sf;
 			}
 		} else {
@@ -2030,6 +2047,7 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CyclePara
 	static_assert(sizeof(OctInst) >= sizeof(OctDynInst), "the integration step reuses the cycle's LDS blocks");
 	const bool wave_b = DUO && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
 	__shared__ int wgflags[2];
+	__shared__ double lawc[FULL ? 96 : 1];  // batch-uniform constants of the partial task's control law (the one wavefront of the workgroup that runs it)
 #if !defined(SAIP_OCT_NO_BROWS)
 	if (DUO && !FULL && GJ == 0) {
 		if (threadIdx.x == 0) wgflags[0] = wgflags[1] = 0;
@@ -2037,10 +2055,10 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CyclePara
 	}
 #endif
 	if (DUO) {
-		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8, wgflags);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags);
+		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8, wgflags, lawc);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags, lawc);
 	} else {
-		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem);
+		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem, nullptr, lawc);
 	}
 	if (SIM && !wave_b) {
 		SimParams S;
