@@ -251,6 +251,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	const TaskDev& mf = P.tasks[0];
 	const TaskDev& jt = P.tasks[1];
 	const int kmf = FULL ? mf.k : 6;  // rank of the motion-force task (partial tasks: rows >= k of its Jacobian are zero, diagonals padded with 1)
+	// the decoupling types decide branches in the tail of the cycle; read there (vector loads of a uniform word behind the fences) each cost a
+	// memory round trip on the critical path -- requested here, made scalar behind the local transform
+	const int mf_dec_v = mf.decoupling, jt_dec_v = jt.decoupling;
 	// disableSingularityHandling(): near-singular tasks are reduced in the kernel instead of being flagged (batch-uniform)
 	const bool trunc_mode = FULL && GJ == 2 && P.oct_truncate;
 
@@ -363,6 +366,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		lawc[lane] = lc0;
 		if (lane < 26) lawc[64 + lane] = lc1;
 	}
+	const int mf_dec = __builtin_amdgcn_readfirstlane(mf_dec_v), jt_dec = __builtin_amdgcn_readfirstlane(jt_dec_v);
 	OCT_REQUEST_STATE(_l)  // (dead code in the one-wavefront form)
 	if (ROLE == 1) {
 		UNR for (int e = 0; e < 3; e++) comv[e] = md.com[rr][e];
@@ -843,9 +847,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			UNR for (int j = 0; j <= i; j++) L[i][j] = sm.A[i][j];
 		oct_cholesky<6>(L, dinv);
 		oct_solve_unit<6>(L, dinv, ra, lam);
-		if (mf.decoupling == DEC_FULL) {
+		if (mf_dec == DEC_FULL) {
 			UNR for (int c = 0; c < 6; c++) lmod[c] = lam[c];
-		} else if (mf.decoupling == DEC_IMPEDANCE) {
+		} else if (mf_dec == DEC_IMPEDANCE) {
 			UNR for (int c = 0; c < 6; c++) lmod[c] = (c == ra) ? 1.0 : 0.0;
 		} else if (general_bie) {
 			UNR for (int i = 0; i < 6; i++)
@@ -1035,9 +1039,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		double wr = 0.0;
 		tau_r = 0.0;
 		if (roleA) {
-		if (mf.decoupling == DEC_IMPEDANCE) {
+		if (mf_dec == DEC_IMPEDANCE) {
 			UNR for (int a = 0; a < 6; a++) g[a] = Fum6[a] + Ff6[a];
-		} else if (mf.decoupling == DEC_BIE && general_bie) {
+		} else if (mf_dec == DEC_BIE && general_bie) {
 			double Lb[6][6], dinvb[6], y[6];
 			UNR for (int i = 0; i < 6; i++)
 				UNR for (int j = 0; j <= i; j++) Lb[i][j] = sm.Am[i][j];
@@ -1047,7 +1051,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		} else {
 			double y1[6];
 			oct_solve<6>(L6, dinv6, Fum6, y1);
-			if (mf.decoupling == DEC_BIE) {  // rank-one form (beta = 0 when nothing is clamped)
+			if (mf_dec == DEC_BIE) {  // rank-one form (beta = 0 when nothing is clamped)
 				double t[6], y2[6], ty1 = 0.0, ty2 = 0.0;
 				UNR for (int a = 0; a < 6; a++) {
 					double sacc = 0.0;
@@ -1127,9 +1131,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		const double za = octl_sum(zr * ai);
 		const double zf = octl_sum(zr * fi);
 		double rho = 1.0;
-		if (jt.decoupling == DEC_IMPEDANCE) {
+		if (jt_dec == DEC_IMPEDANCE) {
 			rho = zz * oct_rcp(zv);
-		} else if (jt.decoupling == DEC_BIE) {
+		} else if (jt_dec == DEC_BIE) {
 			if (general_bie) {
 				if (DUO) {
 					UNR for (int j = 0; j < N; j++) v[j] = smB.vec[4][j];
@@ -1240,8 +1244,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					const double aj = __shfl(af, src), fj = __shfl(ff, src);
 					const double mrj = (j <= rr) ? smA.M[rr][j] : smA.M[j][rr];
 					double mmod = mrj;
-					if (jt.decoupling == DEC_IMPEDANCE) mmod = (j == rr) ? 1.0 : 0.0;
-					else if (jt.decoupling == DEC_BIE) mmod = (j == rr) ? fmax(mrj, jt.bie_threshold) : mrj;
+					if (jt_dec == DEC_IMPEDANCE) mmod = (j == rr) ? 1.0 : 0.0;
+					else if (jt_dec == DEC_BIE) mmod = (j == rr) ? fmax(mrj, jt.bie_threshold) : mrj;
 					acc = fma(mrj, aj, fma(mmod, fj, acc));
 				}
 				if (singular && fully) {
@@ -1371,7 +1375,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 							Au[c][d] = acc;
 							Au[d][c] = acc;
 						}
-					if (mf.decoupling == DEC_BIE && general_bie) {
+					if (mf_dec == DEC_BIE && general_bie) {
 						UNR for (int i = 0; i < 6; i++)
 							UNR for (int j = 0; j <= i; j++) {
 								Af[i][j] = smA.Am[i][j];
@@ -1391,7 +1395,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 								Amu[d][c] = acc;
 							}
 					} else {
-						const double bb = (mf.decoupling == DEC_BIE) ? beta : 0.0;  // rank-one form: A_mod = A - beta t t^T (beta = 0: nothing clamped)
+						const double bb = (mf_dec == DEC_BIE) ? beta : 0.0;  // rank-one form: A_mod = A - beta t t^T (beta = 0: nothing clamped)
 						UNR for (int c = 0; c < 6; c++)
 							UNR for (int d = 0; d < 6; d++) Amu[c][d] = fma(-bb * tu[c], tu[d], Au[c][d]);
 					}
@@ -1420,7 +1424,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 					ffu[c] = bq;
 				}
 				UNR for (int i = 0; i < 6; i++) fn2 = fma(Fum6[i] + Ff6[i], Fum6[i] + Ff6[i], fn2);
-				if (mf.decoupling == DEC_IMPEDANCE) {
+				if (mf_dec == DEC_IMPEDANCE) {
 					UNR for (int c = 0; c < 6; c++) gu[c] = fu[c] + ffu[c];
 				} else {
 					oct_solve<6>(LM, dM, fu, gu);
@@ -1477,7 +1481,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 						Pm[c][e2] = both ? schm * isg : ((c == e2) ? 1.0 : 0.0);
 					}
 				}
-				if (mf.decoupling == DEC_FULL) {
+				if (mf_dec == DEC_FULL) {
 					UNR for (int c = 0; c < 6; c++)
 						UNR for (int e2 = 0; e2 <= c; e2++) Pm[c][e2] = Pj[c][e2];
 				}
@@ -1496,13 +1500,13 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				}
 				double tjs = 0.0, wsel[6];
 				UNR for (int c = 0; c < 6; c++) wsel[c] = type1 ? w1[c] : w2[c];  // (element-wise: never a run-time choice between two private arrays)
-				if (mf.decoupling == DEC_IMPEDANCE) {
+				if (mf_dec == DEC_IMPEDANCE) {
 					UNR for (int c = 0; c < 6; c++) lw[c] = wsel[c];
 				} else {
 					oct_solve<6>(Pm, dPm, wsel, lw);
 				}
 				UNR for (int c = 0; c < 6; c++) tjs = fma(jpp[c], type1 ? lw[c] : (w1[c] + lw[c]), tjs);
-				const double tmf = (mf.decoupling == DEC_IMPEDANCE) ? tns : (tns + alpha * ts + (1.0 - alpha) * tjs);  // :311-313, :367
+				const double tmf = (mf_dec == DEC_IMPEDANCE) ? tns : (tns + alpha * ts + (1.0 - alpha) * tjs);  // :311-313, :367
 				STAMP(27);
 				// ---- the joint task behind: N = N_js N_ns projects onto null(J) along M^-1 range(J^T), so N = z z^T M / (z^T M z) again;
 				// z from the Euclidean projector I - sum_c v_c v_c^T (pivot row: the lane with the largest diagonal entry)
@@ -1542,9 +1546,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				const double zzb = octl_sum(zb * zb), sb = octl_sum(act ? zb * mz : 0.0);
 				const double zab = octl_sum(zb * aib), zfb = octl_sum(zb * fi);
 				double rhob = 1.0;  // rho |z|^2 in the notation above: tau = (M z)_r / |z|^2 (z.a + rho' z.f), rho' = Lambda_mod / Lambda
-				if (jt.decoupling == DEC_IMPEDANCE) {
+				if (jt_dec == DEC_IMPEDANCE) {
 					rhob = zzb * oct_rcp(sb);
-				} else if (jt.decoupling == DEC_BIE) {
+				} else if (jt_dec == DEC_BIE) {
 					if (general_bie) {
 						double mbv = 0.0;
 						UNR for (int j = 0; j < N; j++) mbv = fma(mb[j], __shfl(mz, octl_src(lane, j)), mbv);
@@ -1600,9 +1604,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		const double za = octl_sum(zr * ai);
 		const double zf = octl_sum(zr * fi);
 		double rho = 1.0;
-		if (jt.decoupling == DEC_IMPEDANCE) {
+		if (jt_dec == DEC_IMPEDANCE) {
 			rho = zz * oct_rcp(zv);
-		} else if (jt.decoupling == DEC_BIE) {
+		} else if (jt_dec == DEC_BIE) {
 			if (general_bie) {
 				if (DUO) {
 					UNR for (int j = 0; j < N; j++) v[j] = smB.vec[4][j];
@@ -1741,10 +1745,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				A4[c][k] = (c == k && !keep[c]) ? 1.0 : gs;
 			}
 		oct_spd_inverse4(A4, Lam4);
-		if (jt.decoupling == DEC_FULL) {
+		if (jt_dec == DEC_FULL) {
 			UNR for (int c = 0; c < 4; c++)
 				UNR for (int k = 0; k < 4; k++) Lmod4[c][k] = Lam4[c][k];
-		} else if (jt.decoupling == DEC_IMPEDANCE) {
+		} else if (jt_dec == DEC_IMPEDANCE) {
 			UNR for (int c = 0; c < 4; c++)
 				UNR for (int k = 0; k < 4; k++) Lmod4[c][k] = (c == k) ? 1.0 : 0.0;
 		} else if (general_bie) {
@@ -1900,10 +1904,10 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				A5[c][k5] = (c == k5 && c >= rank) ? 1.0 : gs;
 			}
 		oct_spd_inverse_n<5>(A5, Lam5);
-		if (jt.decoupling == DEC_FULL) {
+		if (jt_dec == DEC_FULL) {
 			UNR for (int c = 0; c < 5; c++)
 				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = Lam5[c][k5];
-		} else if (jt.decoupling == DEC_IMPEDANCE) {
+		} else if (jt_dec == DEC_IMPEDANCE) {
 			UNR for (int c = 0; c < 5; c++)
 				UNR for (int k5 = 0; k5 < 5; k5++) Lmod5[c][k5] = (c == k5) ? 1.0 : 0.0;
 		} else if (general_bie) {
