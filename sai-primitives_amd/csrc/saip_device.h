@@ -144,6 +144,11 @@ struct CycleParams {
 	int* flag_count;
 	int* flag_list;
 	int* flag_count_next;
+	// eight-lane kernels: TaskDev::goal / ::integ of the stack's two tasks once more, as kernel arguments.  Read from the task block they are
+	// a pointer chase at the very start of every wavefront -- kernel arguments, then the pointer, then the data: one memory round trip more
+	// in front of the goals than in front of anything else the wavefront asks for.
+	const double* goal2[2];
+	double* integ2[2];
 };
 
 // forward dynamics + semi-implicit Euler step (saip_dynamics.hip)

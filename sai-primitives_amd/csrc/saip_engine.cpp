@@ -1351,6 +1351,10 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	}
 	P.model = b->model_dev;
 	P.tasks = b->tasks_dev;
+	for (int t = 0; t < 2; t++) {
+		P.goal2[t] = t < (int)b->tasks.size() ? (b->tasks[t].otg_enabled ? b->tasks[t].desired_dev : b->tasks[t].dev.goal) : nullptr;  // (as in the task block uploaded above)
+		P.integ2[t] = t < (int)b->tasks.size() ? b->tasks[t].dev.integ : nullptr;
+	}
 	// lane kernel: motion-force task slots, batch-uniform rank bounds, the shared BIE threshold
 	P.mf_task[0] = P.mf_task[1] = -1;
 	P.any_bie = 0;

@@ -279,11 +279,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	}
 	double gl0 = 0.0, gl1 = 0.0, gl2 = 0.0;  // 24 goal rows, 3 per lane
 	if (roleB) {
-		gl0 = saip_ldg(mf.goal, (size_t)r * ld + b);
-		gl1 = saip_ldg(mf.goal, (size_t)(8 + r) * ld + b);
-		gl2 = saip_ldg(mf.goal, (size_t)(16 + r) * ld + b);
+		gl0 = saip_ldg(P.goal2[0], (size_t)r * ld + b);
+		gl1 = saip_ldg(P.goal2[0], (size_t)(8 + r) * ld + b);
+		gl2 = saip_ldg(P.goal2[0], (size_t)(16 + r) * ld + b);
 	}
-	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(mf.goal, (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
+	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(P.goal2[0], (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
 	// partial motion-force tasks: the control law multiplies by ninety batch-uniform constants (Bm, the projections, the sigma matrices, the
 	// gains: one contiguous run of the task block).  Read where the law runs -- behind a dozen wavefront fences -- they were 120 loads with
 	// their memory round trip in front of the law (3.0 k of B's 12.3 k clocks on config 3); requested here, two per lane, parked in LDS.
@@ -301,9 +301,9 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
 	if (roleA) {
-		jg_q = saip_ldg(jt.goal, (size_t)rj * ld + b);
-		jg_dq = saip_ldg(jt.goal, (size_t)(mj + rj) * ld + b);
-		jg_ddq = saip_ldg(jt.goal, (size_t)(2 * mj + rj) * ld + b);
+		jg_q = saip_ldg(P.goal2[1], (size_t)rj * ld + b);
+		jg_dq = saip_ldg(P.goal2[1], (size_t)(mj + rj) * ld + b);
+		jg_ddq = saip_ldg(P.goal2[1], (size_t)(2 * mj + rj) * ld + b);
 	}
 
 	// integrator state and this lane's joint gains: requested early, committed from registers / LDS in the epilogue (the loads used to sit in front
@@ -314,8 +314,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 #define OCT_REQUEST_STATE(SFX)                                                                                          \
 	const bool track_mf##SFX = (mf.has_ki || P.integ_always), track_jt##SFX = (jt.has_ki || P.integ_always);            \
 	double mfi_pre##SFX = 0.0, jti_pre##SFX = 0.0;                                                                      \
-	if (roleB && track_mf##SFX && r < 6) mfi_pre##SFX = saip_ldg(mf.integ, (size_t)r * ld + b);                                   \
-	if (roleA && track_jt##SFX) jti_pre##SFX = saip_ldg(jt.integ, (size_t)(GJ == 1 ? rj : rr) * ld + b);                          \
+	if (roleB && track_mf##SFX && r < 6) mfi_pre##SFX = saip_ldg(P.integ2[0], (size_t)r * ld + b);                                   \
+	if (roleA && track_jt##SFX) jti_pre##SFX = saip_ldg(P.integ2[1], (size_t)(GJ == 1 ? rj : rr) * ld + b);                          \
 	double jkp_r##SFX = 0.0, jkv_r##SFX = 0.0, jki_r##SFX = 0.0; /* (per-lane gain loads: used by the control law behind M) */ \
 	if (roleA && GJ != 1) {                                                                                             \
 		jkp_r##SFX = jt.kp[rr];                                                                                         \
@@ -1167,12 +1167,12 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 				const bool r1b = P.any_bie && !general_bie;
 				UNR for (int j = 0; j < N; j++) mcol[j] = r1b ? smA.vec[3][j] : 0.0;
 				UNR for (int j = 0; j < N; j++) mb[j] = general_bie ? smA.Lam[r][j] : mi[j];
-				jg_q = saip_ldg(jt.goal, (size_t)rr * ld + b);
-				jg_dq = saip_ldg(jt.goal, (size_t)(N + rr) * ld + b);
-				jg_ddq = saip_ldg(jt.goal, (size_t)(2 * N + rr) * ld + b);
+				jg_q = saip_ldg(P.goal2[1], (size_t)rr * ld + b);
+				jg_dq = saip_ldg(P.goal2[1], (size_t)(N + rr) * ld + b);
+				jg_ddq = saip_ldg(P.goal2[1], (size_t)(2 * N + rr) * ld + b);
 				const double e = q_r - jg_q;
 				double ie = 0.0;
-				if (jt.has_ki || P.integ_always) ie = saip_ldg(jt.integ, (size_t)rr * ld + b);
+				if (jt.has_ki || P.integ_always) ie = saip_ldg(P.integ2[1], (size_t)rr * ld + b);
 				ie += e * jt.dt;
 				if (jt.vel_sat) {
 					double vdes = -jt.kp[rr] * jt.kvinv[rr] * e - jt.ki[rr] * jt.kvinv[rr] * ie;
@@ -2035,8 +2035,8 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 	// launched behind recomputes it from the untouched state, or it stays invalid).  Motion-force rows from the LDS block of the wavefront
 	// that ran the law (B's block outlives B), joint rows from the lane that owns them.
 	if (live && !singular) {
-		if (track_mf && r < 6) mf.integ[(size_t)r * ld + b] = (ROLE == 1 ? smB : sm).ist[r];
-		if (track_jt && (GJ == 1 ? r < mj : act)) jt.integ[(size_t)r * ld + b] = jt_ie_new;
+		if (track_mf && r < 6) P.integ2[0][(size_t)r * ld + b] = (ROLE == 1 ? smB : sm).ist[r];
+		if (track_jt && (GJ == 1 ? r < mj : act)) P.integ2[1][(size_t)r * ld + b] = jt_ie_new;
 	}
 	STAMP(15);
 }

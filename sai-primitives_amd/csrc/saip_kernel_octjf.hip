@@ -111,18 +111,18 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	const int ra = r < m ? r : 0;
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
 	if (roleA) {
-		jg_q = saip_ldg(jt.goal, (size_t)ra * ld + b);
-		jg_dq = saip_ldg(jt.goal, (size_t)(m + ra) * ld + b);
-		jg_ddq = saip_ldg(jt.goal, (size_t)(2 * m + ra) * ld + b);
+		jg_q = saip_ldg(P.goal2[0], (size_t)ra * ld + b);
+		jg_dq = saip_ldg(P.goal2[0], (size_t)(m + ra) * ld + b);
+		jg_ddq = saip_ldg(P.goal2[0], (size_t)(2 * m + ra) * ld + b);
 	}
 	const bool track_mf = mf.has_ki || P.integ_always, track_jt = jt.has_ki || P.integ_always;
 	double mfi_pre = 0.0, jti_pre = 0.0, jt_ie_new = 0.0;  // integrator state: requested with the inputs, committed from LDS / registers in the epilogue
-	if (roleB && track_mf && r < 6) mfi_pre = saip_ldg(mf.integ, (size_t)r * ld + b);
-	if (roleA && track_jt) jti_pre = saip_ldg(jt.integ, (size_t)ra * ld + b);
+	if (roleB && track_mf && r < 6) mfi_pre = saip_ldg(P.integ2[1], (size_t)r * ld + b);
+	if (roleA && track_jt) jti_pre = saip_ldg(P.integ2[0], (size_t)ra * ld + b);
 	const int gc = mf.goal_comps < 32 ? mf.goal_comps : 32;
 	double gl[4] = {0.0, 0.0, 0.0, 0.0};
 	if (roleB) {
-		UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? saip_ldg(mf.goal, (size_t)(8 * c + r) * ld + b) : 0.0;
+		UNR for (int c = 0; c < 4; c++) gl[c] = (8 * c + r < gc) ? saip_ldg(P.goal2[1], (size_t)(8 * c + r) * ld + b) : 0.0;
 	}
 
 	// ---------------------------------------------------------------- updateModel(): kinematics (log-step prefix product over the chain)
@@ -595,8 +595,8 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	if (P.flag_list && blockIdx.x == 0 && lane == 0) *P.flag_count_next = 0;  // the other list: its last readers finished a cycle ago
 	// integrators: commit what the control laws advanced them to unless the instance ended flagged
 	if (live && !singular) {
-		if (track_mf && r < 6) mf.integ[(size_t)r * ld + b] = sm.ist[r];
-		if (track_jt && r < m) jt.integ[(size_t)r * ld + b] = jt_ie_new;
+		if (track_mf && r < 6) P.integ2[1][(size_t)r * ld + b] = sm.ist[r];
+		if (track_jt && r < m) P.integ2[0][(size_t)r * ld + b] = jt_ie_new;
 	}
 }
 
