@@ -47,7 +47,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # 33.6 vs 40.0 us).
     sched = {"csrc/saip_kernel_lane.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "csrc/saip_kernel_wg.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-             "csrc/saip_kernel_oct.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-kernarg-preload-count=14"],  # (leading scalar arguments in SGPRs at wavefront start: OctHot)
+             "csrc/saip_kernel_oct.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
              "csrc/saip_kernel_octjf.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
     objs = []
     procs = []

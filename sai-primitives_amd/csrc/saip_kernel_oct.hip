@@ -210,22 +210,8 @@ __device__ __forceinline__ void oct_sync() {
 // other's registers: as run-time branches of one body the merged live ranges spilled)
 // NN: dof of the chain.  7 everywhere except the general instantiation <true, 2, ...> (full joint task behind a motion-force task, rank
 // n - k by multi-pivot Gram-Schmidt), which also exists for 6 and 8 dof: with 8 no lane is padding, with 6 two are.
-// What every wavefront needs before it can ask for anything: batch size and stride, state, model and task blocks, the two goal arrays.  The
-// kernel takes them as leading scalar arguments (copies of the CycleParams fields), and the translation unit is built with
-// -amdgpu-kernarg-preload-count=14: on hardware that preloads kernel arguments they are in SGPRs when the wavefront starts, so its first memory
-// requests do not wait for a round trip to the argument segment first (the prologue the compiler emits loads them on firmware that does not).
-struct OctHot {
-	int B, ld;
-	const double* q;
-	const double* dq;
-	const ModelDev* model;
-	const TaskDev* tasks;
-	const double* goal0;
-	const double* goal1;
-};
-
 template <bool FULL, int GJ, int ROLE, int NN = 7>
-__device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr, double* lawc = nullptr) {
+__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr, double* lawc = nullptr) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = NN;
@@ -258,12 +244,12 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 	OctInst& smA = smemA[grp];  // wavefront A's block (B reads A = J M^-1 J^T, T1 and M^-1 from it after the first barrier)
 	OctInst& smB = smemB[grp];  // where wavefront B leaves its results
 	const int b_raw = blockIdx.x * 8 + grp;
-	const bool live = b_raw < H.B;
-	const int b = live ? b_raw : H.B - 1;
-	const size_t ld = H.ld;
-	const ModelDev& md = *H.model;
-	const TaskDev& mf = H.tasks[0];
-	const TaskDev& jt = H.tasks[1];
+	const bool live = b_raw < P.B;
+	const int b = live ? b_raw : P.B - 1;
+	const size_t ld = P.ld;
+	const ModelDev& md = *P.model;
+	const TaskDev& mf = P.tasks[0];
+	const TaskDev& jt = P.tasks[1];
 	const int kmf = FULL ? mf.k : 6;  // rank of the motion-force task (partial tasks: rows >= k of its Jacobian are zero, diagonals padded with 1)
 	// the decoupling types decide branches in the tail of the cycle; read there (vector loads of a uniform word behind the fences) each cost a
 	// memory round trip on the critical path -- requested here, made scalar behind the local transform
@@ -273,8 +259,8 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 
 	STAMP(0);
 	// ---------------------------------------------------------------- inputs (requested up front; consumed much later)
-	const double q_r = H.q[(size_t)rr * ld + b];
-	const double dq_r = H.dq[(size_t)rr * ld + b];
+	const double q_r = P.q[(size_t)rr * ld + b];
+	const double dq_r = P.dq[(size_t)rr * ld + b];
 	// this joint's constants, requested together with the state.  (Left where they are used, the loads of R0 / p0 / axis sat INSIDE the branch on the
 	// joint type -- a second memory round trip behind the one that fetched the type -- and those of the body's inertia behind the frames: two
 	// exposed round trips at the start of every wavefront.)
@@ -293,11 +279,11 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 	}
 	double gl0 = 0.0, gl1 = 0.0, gl2 = 0.0;  // 24 goal rows, 3 per lane
 	if (roleB) {
-		gl0 = saip_ldg(H.goal0, (size_t)r * ld + b);
-		gl1 = saip_ldg(H.goal0, (size_t)(8 + r) * ld + b);
-		gl2 = saip_ldg(H.goal0, (size_t)(16 + r) * ld + b);
+		gl0 = saip_ldg(P.goal2[0], (size_t)r * ld + b);
+		gl1 = saip_ldg(P.goal2[0], (size_t)(8 + r) * ld + b);
+		gl2 = saip_ldg(P.goal2[0], (size_t)(16 + r) * ld + b);
 	}
-	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(H.goal0, (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
+	const double gl3 = (roleB && FULL && mf.general_law && r < 6) ? saip_ldg(P.goal2[0], (size_t)(24 + r) * ld + b) : 0.0;  // goal force / moment of the general laws
 	// partial motion-force tasks: the control law multiplies by ninety batch-uniform constants (Bm, the projections, the sigma matrices, the
 	// gains: one contiguous run of the task block).  Read where the law runs -- behind a dozen wavefront fences -- they were 120 loads with
 	// their memory round trip in front of the law (3.0 k of B's 12.3 k clocks on config 3); requested here, two per lane, parked in LDS.
@@ -315,9 +301,9 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 	const int rj = GJ == 1 ? (r < mj ? r : 0) : rr;    // the task row whose goal this lane fetches
 	double jg_q = 0.0, jg_dq = 0.0, jg_ddq = 0.0;
 	if (roleA) {
-		jg_q = saip_ldg(H.goal1, (size_t)rj * ld + b);
-		jg_dq = saip_ldg(H.goal1, (size_t)(mj + rj) * ld + b);
-		jg_ddq = saip_ldg(H.goal1, (size_t)(2 * mj + rj) * ld + b);
+		jg_q = saip_ldg(P.goal2[1], (size_t)rj * ld + b);
+		jg_dq = saip_ldg(P.goal2[1], (size_t)(mj + rj) * ld + b);
+		jg_ddq = saip_ldg(P.goal2[1], (size_t)(2 * mj + rj) * ld + b);
 	}
 
 	// integrator state and this lane's joint gains: requested early, committed from registers / LDS in the epilogue (the loads used to sit in front
@@ -1181,9 +1167,9 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 				const bool r1b = P.any_bie && !general_bie;
 				UNR for (int j = 0; j < N; j++) mcol[j] = r1b ? smA.vec[3][j] : 0.0;
 				UNR for (int j = 0; j < N; j++) mb[j] = general_bie ? smA.Lam[r][j] : mi[j];
-				jg_q = saip_ldg(H.goal1, (size_t)rr * ld + b);
-				jg_dq = saip_ldg(H.goal1, (size_t)(N + rr) * ld + b);
-				jg_ddq = saip_ldg(H.goal1, (size_t)(2 * N + rr) * ld + b);
+				jg_q = saip_ldg(P.goal2[1], (size_t)rr * ld + b);
+				jg_dq = saip_ldg(P.goal2[1], (size_t)(N + rr) * ld + b);
+				jg_ddq = saip_ldg(P.goal2[1], (size_t)(2 * N + rr) * ld + b);
 				const double e = q_r - jg_q;
 				double ie = 0.0;
 				if (jt.has_ki || P.integ_always) ie = saip_ldg(P.integ2[1], (size_t)rr * ld + b);
@@ -2059,9 +2045,7 @@ __device__ __forceinline__ void oct_cycle_body(const OctHot& H, const CycleParam
 // instances goes on to integrate them (saip_dynamics_oct_body.h) -- same lane layout, the torques it has just written, the LDS block
 // the cycle no longer needs: one launch per closed-loop period.  A separate instantiation, so that the benchmarked kernel does not carry it.
 template <bool FULL, int GJ, bool DUO = false, bool SIM = false, int NN = 7>
-__global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const int hB, const int hld, const double* hq, const double* hdq, const ModelDev* hmodel, const TaskDev* htasks,
-																	  const double* hgoal0, const double* hgoal1, const CycleParams P) {
-	const OctHot H{hB, hld, hq, hdq, hmodel, htasks, hgoal0, hgoal1};
+__global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CycleParams P) {
 	static_assert(!SIM || NN == 7, "the fused integration step is the 7-dof one");
 	__shared__ OctInst smem[DUO ? 16 : 8];
 	static_assert(sizeof(OctInst) >= sizeof(OctDynInst), "the integration step reuses the cycle's LDS blocks");
@@ -2075,10 +2059,10 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const int hB, c
 	}
 #endif
 	if (DUO) {
-		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(H, P, smem + 8, smem, smem + 8, wgflags, lawc);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(H, P, smem, smem, smem + 8, wgflags, lawc);
+		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8, wgflags, lawc);
+		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags, lawc);
 	} else {
-		oct_cycle_body<FULL, GJ, 0, NN>(H, P, smem, smem, smem, nullptr, lawc);
+		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem, nullptr, lawc);
 	}
 	if (SIM && !wave_b) {
 		SimParams S;
@@ -2115,34 +2099,33 @@ static bool oct_duo_enabled(const int workgroups) {
 	return on && workgroups <= 2 * cus;
 }
 
-#define OCT_ARGS P.B, P.ld, P.q, P.dq, P.model, P.tasks, P.goal2[0], P.goal2[1], P
 hipError_t launch_cycle_oct(const CycleParams& P, hipStream_t stream) {
 	const dim3 grid((P.B + 7) / 8), block(64);
 	const bool duo = oct_duo_enabled((int)grid.x);
 	if (P.oct_general_joint == 2 && P.n == 8) {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 8>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 8>), grid, block, 0, stream, OCT_ARGS);
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 8>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 8>), grid, block, 0, stream, P);
 	} else if (P.oct_general_joint == 2 && P.n == 6) {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 6>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 6>), grid, block, 0, stream, OCT_ARGS);
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true, false, 6>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2, false, false, 6>), grid, block, 0, stream, P);
 	} else if (P.oct_general_joint == 2) {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, OCT_ARGS);
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 2, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 2>), grid, block, 0, stream, P);
 	} else if (P.oct_general_joint == 1) {
-		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, OCT_ARGS);
+		if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 1, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 1>), grid, block, 0, stream, P);
 	} else if (P.jla || P.lane_general || P.oct_partial_mf) {
 		if (P.sim_substeps > 0) {
-			if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-			else hipLaunchKernelGGL((saip_cycle_oct<true, 0, false, true>), grid, block, 0, stream, OCT_ARGS);
-		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, OCT_ARGS);
+			if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true, true>), grid, dim3(128), 0, stream, P);
+			else hipLaunchKernelGGL((saip_cycle_oct<true, 0, false, true>), grid, block, 0, stream, P);
+		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<true, 0, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<true, 0>), grid, block, 0, stream, P);
 	} else {
 		if (P.sim_substeps > 0) {
-			if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-			else hipLaunchKernelGGL((saip_cycle_oct<false, 0, false, true>), grid, block, 0, stream, OCT_ARGS);
-		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, OCT_ARGS);
-		else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, OCT_ARGS);
+			if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true, true>), grid, dim3(128), 0, stream, P);
+			else hipLaunchKernelGGL((saip_cycle_oct<false, 0, false, true>), grid, block, 0, stream, P);
+		} else if (duo) hipLaunchKernelGGL((saip_cycle_oct<false, 0, true>), grid, dim3(128), 0, stream, P);
+		else hipLaunchKernelGGL((saip_cycle_oct<false, 0>), grid, block, 0, stream, P);
 	}
 	return hipGetLastError();
 }

@@ -10,7 +10,6 @@ K=${SAIP_VARIANT_KERNEL:-oct}
 SRC=${SAIP_VARIANT_SRC:-csrc/saip_kernel_$K.hip}
 SCHED=${SAIP_VARIANT_SCHED:-max-ilp}
 if [ "$SCHED" = "default" ]; then SFLAGS=""; else SFLAGS="-mllvm -amdgpu-sched-strategy=$SCHED"; fi
-if [ "$K" = "oct" ]; then SFLAGS="$SFLAGS -mllvm -amdgpu-kernarg-preload-count=14"; fi  # (as in capi.py: the kernel's leading scalar arguments arrive in SGPRs)
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -x hip -c $SFLAGS "$@" -o build/saip_kernel_${K}_var_$NAME.o $SRC
 OBJS=$(ls build/*.hip.o build/*.cpp.o | grep -v saip_kernel_$K.hip.o)
 hipcc --offload-arch=gfx950 -fPIC -shared -o libsaip_var_$NAME.so $OBJS build/saip_kernel_${K}_var_$NAME.o
