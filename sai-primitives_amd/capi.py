@@ -8,7 +8,7 @@ import subprocess
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "libsaip.so")
 SOURCES = ["csrc/saip_engine.cpp", "csrc/saip_comm.cpp", "csrc/saip_kernel_wg.hip", "csrc/saip_kernel_lane.hip", "csrc/saip_kernel_lane_lean.hip", "csrc/saip_kernel_oct.hip", "csrc/saip_kernel_octjf.hip", "csrc/saip_kernel_wave.hip", "csrc/saip_otg.hip", "csrc/saip_dynamics.hip", "csrc/saip_dynamics_oct.hip"]
-HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "csrc/saip_fk.h", "csrc/saip_oct_common.h", "csrc/saip_wave_prims.h", "csrc/saip_dynamics_oct_body.h", "../include/saip.h"]
+HEADERS = ["csrc/saip_device.h", "csrc/saip_law.h", "csrc/saip_wg_linalg.h", "csrc/saip_wg_cycle.h", "csrc/saip_fk.h", "csrc/saip_oct_common.h", "csrc/saip_wave_prims.h", "csrc/saip_dynamics_oct_body.h", "../include/saip.h"]
 
 SAIP_OK, SAIP_ERR_INVALID_ARGUMENT, SAIP_ERR_UNSUPPORTED, SAIP_ERR_NO_DEVICE, SAIP_ERR_DEVICE, SAIP_ERR_ORDER = range(6)
 NAME_LEN = 48

@@ -144,6 +144,9 @@ struct CycleParams {
 	int* flag_count;
 	int* flag_list;
 	int* flag_count_next;
+	// eight-lane kernels: the wavefront that could not finish an instance recomputes it itself, right behind its epilogue, with the general
+	// kernel's body on its own (by then dead) LDS block -- no list, no second launch (round 4; 0: flagged instances go to the list / stay flagged)
+	int slow_tail;
 	// eight-lane kernels: TaskDev::goal / ::integ of the stack's two tasks once more, as kernel arguments.  Read from the task block they are
 	// a pointer chase at the very start of every wavefront -- kernel arguments, then the pointer, then the data: one memory round trip more
 	// in front of the goals than in front of anything else the wavefront asks for.

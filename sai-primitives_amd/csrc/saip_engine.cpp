@@ -1390,6 +1390,7 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.flag_count = nullptr;  // set by launch_cycle when a device-side slow path follows the lane / eight-lane kernel
 	P.flag_count_next = nullptr;
 	P.flag_list = nullptr;
+	P.slow_tail = 0;
 	P.lane_general = 0;
 	P.oct_general_joint = 0;
 	P.oct_partial_mf = 0;
@@ -1586,6 +1587,15 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		// through): with the handling enforced nothing is left for a slow path, and what it still refuses the general kernel would too
 		if (oct && P.oct_general_joint == 0 && b->tasks[0].dev.sing_handling) {
 			slow = false;
+			P.flag_count = P.flag_count_next = P.flag_list = nullptr;
+		}
+		// every other eight-lane stack: the wavefront that flags an instance recomputes it itself behind its epilogue (the general kernel's body on
+		// its own LDS block) -- no list and no second launch behind the kernel (round 4; SAIP_NO_SLOW_TAIL=1 restores the list launch for A/B runs)
+		static const bool tail_on = getenv("SAIP_NO_SLOW_TAIL") == nullptr;
+		P.slow_tail = 0;
+		if (slow && tail_on && ((oct && P.oct_general_joint != 0) || octjf)) {
+			slow = false;
+			P.slow_tail = 1;
 			P.flag_count = P.flag_count_next = P.flag_list = nullptr;
 		}
 		b->sim_done = false;

@@ -30,6 +30,15 @@
 #include "saip_fk.h"
 #include "saip_law.h"
 #include "saip_oct_common.h"
+// the general kernel's body as this kernel's slow tail: one wavefront plays the 64-thread workgroup, so its synchronisation points are
+// wavefront-local (the other wavefront of a two-wavefront workgroup has left by then)
+#define SAIP_WG_SYNC()                                          \
+	do {                                                        \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+		__builtin_amdgcn_wave_barrier();                        \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+	} while (0)
+#include "saip_wg_cycle.h"
 
 namespace saip {
 
@@ -211,7 +220,7 @@ __device__ __forceinline__ void oct_sync() {
 // NN: dof of the chain.  7 everywhere except the general instantiation <true, 2, ...> (full joint task behind a motion-force task, rank
 // n - k by multi-pivot Gram-Schmidt), which also exists for 6 and 8 dof: with 8 no lane is padding, with 6 two are.
 template <bool FULL, int GJ, int ROLE, int NN = 7>
-__device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr, double* lawc = nullptr) {
+__device__ __forceinline__ bool oct_cycle_body(const CycleParams& P, OctInst* smem, OctInst* smemA, OctInst* smemB, int* wgflags = nullptr, double* lawc = nullptr) {
 	constexpr bool DUO = ROLE != 0;
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = NN;
@@ -992,7 +1001,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		STAMP(29);
 		__syncthreads();
 		STAMP(30);
-		if (ROLE == 2 && GJ != 0) return;
+		if (ROLE == 2 && GJ != 0) return false;
 		if (ROLE == 1) {
 			UNR for (int a = 0; a < 6; a++) {
 				Fum6[a] = smB.vec[6][a];
@@ -1584,7 +1593,7 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 			}
 			STAMP(31);
 			__syncthreads();
-			if (ROLE == 2) return;
+			if (ROLE == 2) return false;
 			zr = smB.vec[7][r];
 			v_own = smB.vec[8][r];
 			zz = smB.vec[3][0];
@@ -2023,9 +2032,11 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		tv += rev ? tgr : tgp;
 	}
 	// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
+	// (with the slow tail on, the tail decides torques and status of a flagged instance: nothing is written for it here)
+	const bool to_tail = GJ != 0 && P.slow_tail && singular;
 	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
-	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
-	if (live && r == 0) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (blended_i ? 8 : 0));
+	if (live && act && singular && P.flag_nan && !to_tail) P.tau[(size_t)r * ld + b] = __builtin_nan("");
+	if (live && r == 0 && !to_tail) P.status[b] = singular ? 1 : ((truncated ? 2 : 0) | (blended_i ? 8 : 0));
 	if (live && r == 0 && singular && P.flag_list) {
 		const int slot = atomicAdd(P.flag_count, 1);
 		if (slot < P.B) P.flag_list[slot] = b;
@@ -2039,6 +2050,27 @@ __device__ __forceinline__ void oct_cycle_body(const CycleParams& P, OctInst* sm
 		if (track_jt && (GJ == 1 ? r < mj : act)) P.integ2[1][(size_t)r * ld + b] = jt_ie_new;
 	}
 	STAMP(15);
+	return live && to_tail;
+}
+
+// Slow tail (round 4): the instances of this wavefront that ended flagged -- outside SingularityHandler's non-singular branch with the blended
+// strategies on (SingularityHandler.cpp:100-121, 146-158, 310-367), a reduced task with fewer than two directions left, an ambiguous rank
+// gap -- are recomputed here, one after the other, by the general kernel's body (saip_wg_cycle.h: Jacobi eigen-pairs of the Gram matrix,
+// U_ns / U_s split, blended type-1 / type-2 strategies with their per-instance state) on this wavefront's own LDS block, which the cycle no
+// longer needs.  The instance's inputs are untouched (nothing was written for it, no integrator advanced), so the result is what the list
+// launch behind the kernel used to produce -- without the launch, which cost 4.5 us per cycle whether or not anything was on the list.
+// Everything the tail needs is in HBM or batch-uniform: no register of the ordinary path lives across it.
+__device__ __forceinline__ void oct_slow_tail(const CycleParams& P, const bool flagged, void* lds) {
+	const unsigned long long votes = __ballot(flagged);
+	if (__builtin_expect(votes == 0ull, 1)) return;  // wave-uniform: the usual case
+	static_assert(sizeof(WgSmem<8>) <= 8 * sizeof(OctInst), "the general kernel's block fits the eight instance blocks of a wavefront");
+	WgSmem<8>& wsm = *reinterpret_cast<WgSmem<8>*>(lds);
+	for (int g = 0; g < 8; g++) {
+		const int l0 = OCT_ILV ? (((g >> 1) << 4) | (g & 1)) : (g << 3);  // the lane of joint 0 of instance g (octl_grp / octl_r)
+		if (((votes >> l0) & 1ull) == 0ull) continue;                     // wave-uniform
+		SAIP_WG_SYNC();  // the block's previous user (the cycle, or the instance before) is done with it
+		wg_cycle<8, 64>(P, (int)blockIdx.x * 8 + g, wsm);
+	}
 }
 
 // SIM (rollouts of stacks without internal OTGs and without a slow path behind): the wavefront that finished the cycle of its eight
@@ -2058,12 +2090,16 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_oct(const CyclePara
 		__syncthreads();
 	}
 #endif
+	bool flagged = false;
 	if (DUO) {
 		if (wave_b) oct_cycle_body<FULL, GJ, DUO ? 2 : 0, NN>(P, smem + 8, smem, smem + 8, wgflags, lawc);
-		else oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags, lawc);
+		else flagged = oct_cycle_body<FULL, GJ, DUO ? 1 : 0, NN>(P, smem, smem, smem + 8, wgflags, lawc);
 	} else {
-		oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem, nullptr, lawc);
+		flagged = oct_cycle_body<FULL, GJ, 0, NN>(P, smem, smem, smem, nullptr, lawc);
 	}
+	// (the stacks whose blended branch lives in the kernel itself, GJ == 0, have nothing left for a tail; in the two-wavefront form wavefront A runs it:
+	// B returned behind the first workgroup barrier)
+	if (GJ != 0 && !SIM && !wave_b) oct_slow_tail(P, flagged, smem);
 	if (SIM && !wave_b) {
 		SimParams S;
 		S.B = P.B;

@@ -27,6 +27,14 @@
 #include "saip_fk.h"
 #include "saip_law.h"
 #include "saip_oct_common.h"
+// the general kernel's body as this kernel's slow tail (see saip_kernel_oct.hip: oct_slow_tail): one wavefront plays the 64-thread workgroup
+#define SAIP_WG_SYNC()                                          \
+	do {                                                        \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+		__builtin_amdgcn_wave_barrier();                        \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+	} while (0)
+#include "saip_wg_cycle.h"
 
 namespace saip {
 
@@ -67,7 +75,7 @@ __device__ __forceinline__ void jf_sync() {  // one wavefront per workgroup: its
 // A's LDS block at the ONE workgroup barrier of the kernel, which A reaches only when it needs the force (behind the factor of Lambda_mod^-1).
 // B keeps its frames in its own small block `bx`; every other synchronisation point is wavefront-local.
 template <int ROLE>
-__device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, double (*bx)[8][12]) {
+__device__ __forceinline__ bool jf_body(const CycleParams& P, JfInst* smem, double (*bx)[8][12]) {
 	constexpr bool roleA = ROLE != 2, roleB = ROLE != 1;
 	constexpr int N = 8;
 	const int lane = threadIdx.x & 63;
@@ -325,7 +333,7 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	}
 	if (ROLE == 2) {  // B is done: (F_um, F_f) are in A's block (and the advanced integrators in HBM) behind this barrier
 		__syncthreads();
-		return;
+		return false;
 	}
 	// ---------------------------------------------------------------- M^-1 (and M_BIE^-1): Cholesky factor in every lane, own column of the inverse
 	// M_BIE = M with the diagonal clamped from below (SingularityHandler.cpp:176-182, JointTask.cpp:253-259); factored a second time only
@@ -585,9 +593,11 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 	if (!(tv == tv)) singular = true;  // non-finite inputs: refuse rather than write NaN as a valid torque
 	singular = octl_votes(__builtin_amdgcn_ballot_w64(singular && act), lane) != 0u;  // (one verdict per instance)
 	// a flagged instance holds its last valid torques (or gets them from the slow path launched behind) unless NaN was asked for
+	// (with the slow tail on, the tail decides torques and status of a flagged instance: nothing is written for it here)
+	const bool to_tail = P.slow_tail && singular;
 	if (live && act && !singular) P.tau[(size_t)r * ld + b] = tv;
-	if (live && act && singular && P.flag_nan) P.tau[(size_t)r * ld + b] = __builtin_nan("");
-	if (live && r == 0) P.status[b] = singular ? 1 : 0;
+	if (live && act && singular && P.flag_nan && !to_tail) P.tau[(size_t)r * ld + b] = __builtin_nan("");
+	if (live && r == 0 && !to_tail) P.status[b] = singular ? 1 : 0;
 	if (live && r == 0 && singular && P.flag_list) {
 		const int slot = atomicAdd(P.flag_count, 1);
 		if (slot < P.B) P.flag_list[slot] = b;
@@ -598,6 +608,22 @@ __device__ __forceinline__ void jf_body(const CycleParams& P, JfInst* smem, doub
 		if (track_mf && r < 6) P.integ2[1][(size_t)r * ld + b] = sm.ist[r];
 		if (track_jt && r < m) P.integ2[0][(size_t)r * ld + b] = jt_ie_new;
 	}
+	return live && to_tail;
+}
+
+// Slow tail (round 4; the same as saip_kernel_oct.hip's): the instances of this wavefront whose motion-force task left the non-singular branch
+// are recomputed here by the general kernel's body on this wavefront's own LDS block -- no list, no second launch behind the kernel.
+__device__ __forceinline__ void jf_slow_tail(const CycleParams& P, const bool flagged, void* lds) {
+	const unsigned long long votes = __ballot(flagged);
+	if (__builtin_expect(votes == 0ull, 1)) return;  // wave-uniform: the usual case
+	static_assert(sizeof(WgSmem<8>) <= 8 * sizeof(JfInst), "the general kernel's block fits the eight instance blocks of a wavefront");
+	WgSmem<8>& wsm = *reinterpret_cast<WgSmem<8>*>(lds);
+	for (int g = 0; g < 8; g++) {
+		const int l0 = ((g >> 1) << 4) | (g & 1);  // the lane of joint 0 of instance g (interleaved layout)
+		if (((votes >> l0) & 1ull) == 0ull) continue;
+		SAIP_WG_SYNC();
+		wg_cycle<8, 64>(P, (int)blockIdx.x * 8 + g, wsm);
+	}
 }
 
 template <bool DUO>
@@ -607,9 +633,9 @@ __global__ void __launch_bounds__(DUO ? 128 : 64) saip_cycle_octjf(const CyclePa
 	if (DUO) {
 		const bool wave_b = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
 		if (wave_b) jf_body<2>(P, smem, bx);
-		else jf_body<1>(P, smem, bx);
+		else jf_slow_tail(P, jf_body<1>(P, smem, bx), smem);
 	} else {
-		jf_body<0>(P, smem, bx);
+		jf_slow_tail(P, jf_body<0>(P, smem, bx), smem);
 	}
 }
 

@@ -6,7 +6,14 @@
 
 namespace saip {
 
+// the synchronisation point between two steps of a routine: a workgroup barrier -- or, where the "workgroup" is ONE wavefront inside a larger
+// kernel (the slow tail of the eight-lane kernels: T = 64, the other wavefront of the workgroup has left), whatever the includer defines:
+// LDS operations of one wavefront execute in order, a wavefront-scope fence is enough there
+#if defined(SAIP_WG_SYNC)
+#define SYNC() SAIP_WG_SYNC()
+#else
 #define SYNC() __syncthreads()
+#endif
 
 enum { GEMM_SET = 0, GEMM_I_MINUS = 1, GEMM_ADD = 2, GEMM_SUB = 3 };
 
