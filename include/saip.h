@@ -370,6 +370,12 @@ int saip_comm_world(const saip_comm* comm); /* the number of ranks RCCL counts i
 int saip_comm_rank(const saip_comm* comm);
 /* every rank's batch must have the same dof and leading dimension (saip_batch_set_leading_dimension for uneven shards) */
 saip_status saip_batch_all_gather_torques(saip_batch* batch, saip_comm* comm, double* gathered_dev);
+/* HIP-event timing of `steps` cycles WITH the torque gather in the timed region: gather_mode 0 = one all-gather behind the last cycle (north_star:
+ * "RCCL ... only for the final torque gather"), 1 = one behind EVERY cycle (what a consumer that takes the torques each control period sees,
+ * /root/reference/examples/05-using_robot_controller/05-using_robot_controller.cpp:193-196, 225-231).  elapsed_ms = events around the whole region,
+ * gather_ms = the sum over the gathers of the event time of each (so gather_ms / number of gathers is the cost of one).  comm == NULL (one
+ * rank): no collective is issued and gather_ms = 0. */
+saip_status saip_batch_time_steps_gather(saip_batch* batch, saip_comm* comm, double* gathered_dev, int steps, int gather_mode, double* elapsed_ms, double* gather_ms);
 /* (b) one process, n devices: one batch + stream + communicator per device.  saip_multi_create makes the (unfinalized) batches -- add the same
  *     tasks to every saip_multi_batch(m, i) -- saip_multi_finalize finalizes them, runs ncclCommInitAll and allocates the gather buffers;
  *     saip_multi_step_async = saip_batch_step_async on every device, saip_multi_all_gather_torques = one grouped ncclAllGather, after which
@@ -382,6 +388,9 @@ saip_status saip_multi_finalize(saip_multi* m);
 saip_status saip_multi_step_async(saip_multi* m);
 saip_status saip_multi_all_gather_torques(saip_multi* m);
 saip_status saip_multi_synchronize(saip_multi* m);
+/* the same timing for the one-process form: every device runs `steps` cycles (+ the grouped all-gather, gather_mode as above); elapsed_ms / gather_ms =
+ * the maximum over the devices of each device's event times */
+saip_status saip_multi_time_steps(saip_multi* m, int steps, int gather_mode, double* elapsed_ms, double* gather_ms);
 double* saip_multi_gathered_device(saip_multi* m, int i);
 saip_status saip_multi_get_gathered_host(saip_multi* m, int i, double* out /*[n_devices][dof][B]*/);
 void saip_multi_destroy(saip_multi* m);

@@ -76,6 +76,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs)
     exact_objs = [oct_exact_obj if os.path.basename(o) == "saip_kernel_oct.hip.o" else (jf_exact_obj if os.path.basename(o) == "saip_kernel_octjf.hip.o" else o) for o in objs]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", exact_lib] + exact_objs)
+    # objects of one-off experiments (tools/oct_variant.sh and friends leave build/*_var_*.o behind) are not part of the product: they would
+    # travel to the GPU box with every gpurun snapshot
+    keep = {os.path.basename(o) for o in objs + [oct_exact_obj, jf_exact_obj]}
+    for f in os.listdir(os.path.join(_DIR, "build")):
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(_DIR, "build", f))
     return LIB_PATH
 
 
@@ -192,6 +198,8 @@ def lib():
         "saip_comm_world": (C.c_int, [vp]),
         "saip_comm_rank": (C.c_int, [vp]),
         "saip_batch_all_gather_torques": (C.c_int, [vp, vp, vp]),
+        "saip_batch_time_steps_gather": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, dp, dp]),
+        "saip_multi_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp, dp]),
         "saip_multi_create": (C.c_int, [vp, C.c_int, ip, C.c_int, C.POINTER(vp)]),
         "saip_multi_size": (C.c_int, [vp]),
         "saip_multi_batch": (vp, [vp, C.c_int]),

@@ -58,6 +58,14 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _check_otg_limits(who, **limits):
+    """what the reference's OTG wrappers check before they touch any member (OTG_joints.cpp:41-86, OTG_6dof_cartesian.cpp:59-117): every
+    limit strictly positive.  Checked here so that a task outside any batch rejects the call as well, before anything is logged."""
+    for what, v in limits.items():
+        if not np.all(np.asarray(v) > 0):
+            raise ValueError(f"max {what} cannot be 0 or negative in any directions in {who}::setMax{what.capitalize()}")
+
+
 def _soa(a, B, comps, what):
     """(B, comps) user array -> contiguous [comps][B] host staging array"""
     a = np.asarray(a, dtype=np.float64)
@@ -156,7 +164,7 @@ class _Task:
         self._ctrl = None
         self._id = -1
         self._log = []  # every configuration call, replayed into the batch the task joins (its RobotController's or its private one)
-        self._keepalive = []
+        self._keepalive = {}  # (setter, field) -> the arrays its logged arguments point into: replaced, hence released, with the log entry
         self._manual = False  # model last updated through updateTaskModel(N_prec) rather than updateControllerTaskModels()
 
     # -- TemplateTask accessors
@@ -172,17 +180,25 @@ class _Task:
     def getTaskName(self):
         return self._name
 
-    def _log_call(self, fn_name, args, key=None):
+    def _log_call(self, fn_name, args, key=None, keep=None):
         """the configuration log replayed into the batch the task joins holds the LAST call per setter (per field for setters that address
-        several): a caller that sets gains every cycle neither grows it nor replays duplicates"""
+        several): a caller that sets gains every cycle neither grows it nor replays duplicates.  `keep`: the arrays the logged pointer arguments
+        point into; they live exactly as long as the entry."""
         k = (fn_name, key)
         self._log = [e for e in self._log if e[2] != k]
         self._log.append((fn_name, args, k))
+        if keep is not None:
+            self._keepalive[k] = keep
+        else:
+            self._keepalive.pop(k, None)
 
-    def _cfg(self, fn_name, *args):
-        self._log_call(fn_name, args)
+    def _cfg(self, fn_name, *args, keep=None):
+        """one configuration call: into the engine first when the task sits in a batch -- a call the engine rejects raises and leaves the log (and
+        whatever the caller commits behind this call) as it was, like the reference leaves its members untouched when a setter throws
+        (JointTask.cpp:400-409) -- then into the replay log"""
         if self._ctrl is not None:
             self._ctrl._call(fn_name, self._id, *args)
+        self._log_call(fn_name, args, keep=keep)
 
     def reInitializeTask(self):
         """TemplateTask::reInitializeTask of this task alone: goal := current pose, integrators := 0, OTG re-initialised"""
@@ -248,8 +264,7 @@ class _Task:
             if x.ndim != 1 or x.shape[0] not in (1, size):
                 raise ValueError("kp, kv and ki must be scalars or vectors of the same size")
         k = [np.ascontiguousarray(np.broadcast_to(x, (size,))) for x in (kp, kv, ki)]
-        self._keepalive.append(k)
-        self._cfg(fn, _dptr(k[0]), _dptr(k[1]), _dptr(k[2]), size)
+        self._cfg(fn, _dptr(k[0]), _dptr(k[1]), _dptr(k[2]), size, keep=k)
 
     def setDynamicDecouplingType(self, t):
         self._cfg("saip_batch_set_dynamic_decoupling_type", int(t))
@@ -287,8 +302,7 @@ class _Task:
         if values:
             v = np.ascontiguousarray(np.concatenate([np.atleast_1d(np.asarray(x, float)) for x in values]))
             self._sat_vel = tuple(v.tolist())
-            self._keepalive.append(v)
-            self._cfg("saip_batch_set_saturation_velocities", _dptr(v), int(v.shape[0]))
+            self._cfg("saip_batch_set_saturation_velocities", _dptr(v), int(v.shape[0]), keep=v)
         self._cfg("saip_batch_set_velocity_saturation", 1)
 
     def disableVelocitySaturation(self):
@@ -422,12 +436,12 @@ class MotionForceTask(_Task):
 
     def _space(self, fn, dim, axis):
         a = np.ascontiguousarray(np.asarray(axis if axis is not None else (0.0, 0.0, 0.0), float).reshape(3))
-        self._keepalive.append(a)
-        self._log_call(fn, (int(dim), _dptr(a), None))
         if self._ctrl is None:
+            self._log_call(fn, (int(dim), _dptr(a), None), keep=a)
             return None
         ch = C.c_int(0)
         self._ctrl._call(fn, self._id, int(dim), _dptr(a), C.byref(ch))
+        self._log_call(fn, (int(dim), _dptr(a), None), keep=a)
         return bool(ch.value)
 
     def parametrizeForceMotionSpaces(self, force_space_dimension, force_or_motion_single_axis=None):  # MotionForceTask.h:560-580
@@ -475,8 +489,7 @@ class MotionForceTask(_Task):
     def setControlToSensorTransform(self, R, p):
         """_T_control_to_sensor of setForceSensorFrame (MotionForceTask.cpp:802): rotation (3,3) and translation (3,)"""
         R, p = np.ascontiguousarray(np.asarray(R, float).reshape(9)), np.ascontiguousarray(np.asarray(p, float).reshape(3))
-        self._keepalive.append((R, p))
-        self._cfg("saip_batch_set_control_to_sensor_transform", _dptr(R), _dptr(p))
+        self._cfg("saip_batch_set_control_to_sensor_transform", _dptr(R), _dptr(p), keep=(R, p))
 
     # remaining MotionForceTask.h surface: aliases, host-side getters of what was configured, integrator resets
     def setPosControlGainsUnsafe(self, kp, kv, ki=0.0):  # MotionForceTask.h: same as the checked setter (the engine validates itself)
@@ -619,9 +632,9 @@ class MotionForceTask(_Task):
                                              max_angular_velocity=np.pi / 3, max_angular_acceleration=2 * np.pi):
         v = np.ascontiguousarray([float(max_linear_velocity), float(max_angular_velocity)])
         a = np.ascontiguousarray([float(max_linear_acceleration), float(max_angular_acceleration)])
-        self._keepalive.append((v, a))
+        _check_otg_limits("OTG_6dof_cartesian", velocity=v, acceleration=a)
+        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), 2, keep=(v, a))
         self._otg_enabled = True
-        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), 2)
 
     def enableInternalOtgJerkLimited(self, max_linear_velocity=0.3, max_linear_acceleration=2.0, max_linear_jerk=10.0,
                                      max_angular_velocity=np.pi / 3, max_angular_acceleration=2 * np.pi, max_angular_jerk=10 * np.pi):
@@ -629,9 +642,9 @@ class MotionForceTask(_Task):
         v = np.ascontiguousarray([float(max_linear_velocity), float(max_angular_velocity)])
         a = np.ascontiguousarray([float(max_linear_acceleration), float(max_angular_acceleration)])
         j = np.ascontiguousarray([float(max_linear_jerk), float(max_angular_jerk)])
-        self._keepalive.append((v, a, j))
+        _check_otg_limits("OTG_6dof_cartesian", velocity=v, acceleration=a, jerk=j)
+        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), 2, keep=(v, a, j))
         self._otg_enabled = True
-        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), 2)
 
     # desired state = OTG output when enabled, else the goal (MotionForceTask.h getDesired*)
     def getDesiredPosition(self):
@@ -794,9 +807,9 @@ class JointTask(_Task):
         if v.shape != a.shape or v.ndim != 1 or v.shape[0] not in (1, m):  # JointTask.cpp:367-373
             raise ValueError("max velocity or max acceleration vector size not consistent with task dof in JointTask::enableInternalOtgAccelerationLimited")
         v, a = np.ascontiguousarray(v), np.ascontiguousarray(a)
-        self._keepalive.append((v, a))
+        _check_otg_limits("OTG_joints", velocity=v, acceleration=a)
+        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), int(v.shape[0]), keep=(v, a))
         self._otg_enabled = True
-        self._cfg("saip_batch_set_otg_acceleration_limited", _dptr(v), _dptr(a), int(v.shape[0]))
 
     def enableInternalOtgJerkLimited(self, max_velocity, max_acceleration, max_jerk):
         """JointTask.h:298-316 / JointTask.cpp:383-410: third-order (jerk-limited) Ruckig profiles; scalars or one value per task dof.  The OTG
@@ -804,9 +817,9 @@ class JointTask(_Task):
         v, a, j = (np.ascontiguousarray(np.atleast_1d(np.asarray(x, float))) for x in (max_velocity, max_acceleration, max_jerk))
         if not (v.shape == a.shape == j.shape) or v.shape[0] not in (1, self.getTaskDof()):
             raise ValueError("max velocity, max acceleration or max jerk vector size not consistent with task dof in JointTask::enableInternalOtgJerkLimited")
-        self._keepalive.append((v, a, j))
+        _check_otg_limits("OTG_joints", velocity=v, acceleration=a, jerk=j)
+        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), int(v.shape[0]), keep=(v, a, j))
         self._otg_enabled = True
-        self._cfg("saip_batch_set_otg_jerk_limited", _dptr(v), _dptr(a), _dptr(j), int(v.shape[0]))
 
     def getDesiredPosition(self):  # JointTask.h:185-200: the OTG output when enabled, else the goal
         return self._desired_block()[:, :self.getTaskDof()]
@@ -823,9 +836,11 @@ class JointTask(_Task):
 class RobotController:
     """RobotController.h:47-90 for B robots at once."""
 
-    def __init__(self, robot: SaiModel, tasks, _private=False, leading_dimension=None):
+    def __init__(self, robot: SaiModel, tasks, _private=False, leading_dimension=None, _adopt=None):
         """leading_dimension (engine extra): the leading dimension of the device arrays when it must be larger than the batch rounded up
-        to 32 -- the shards of a sharded run all take the largest shard's, so that the final all-gather moves slabs of one shape"""
+        to 32 -- the shards of a sharded run all take the largest shard's, so that the final all-gather moves slabs of one shape.
+        _adopt: an unfinalized batch handle owned by somebody else (saip_multi_batch of sharding.MultiController): tasks are added here, the
+        owner finalizes all its batches together and then calls _after_finalize(); the handle is not destroyed by this object."""
         L = capi.lib()
         if len(tasks) == 0:  # RobotController.cpp:11-14
             raise ValueError("RobotController must have at least one task")
@@ -835,27 +850,40 @@ class RobotController:
         for t in tasks:
             if t._ctrl is not None and not t._ctrl._private:
                 raise ValueError(f"task [{t.getTaskName()}] already belongs to a RobotController")
-        h = C.c_void_p()
-        capi.check(L.saip_batch_create(robot._h, robot.batch_size, robot.device, C.byref(h)))
+        self._owns = _adopt is None
+        if self._owns:
+            h = C.c_void_p()
+            capi.check(L.saip_batch_create(robot._h, robot.batch_size, robot.device, C.byref(h)))
+        else:
+            h = C.c_void_p(_adopt)
         if leading_dimension is not None:
             try:
                 capi.check(L.saip_batch_set_leading_dimension(h, int(leading_dimension)))
             except Exception:
-                L.saip_batch_destroy(h)
+                if self._owns:
+                    L.saip_batch_destroy(h)
                 raise
         self._h = h
         self._robot = robot
         self.batch_size = robot.batch_size
         self._tasks = list(tasks)
+        self._private = bool(_private)  # the one-task batch of a task driven by hand (TemplateTask.h:43-60), not a user-visible controller
         try:
             for t in tasks:
                 t._id = t._add(L, h)
-            capi.check(L.saip_batch_finalize(h))  # remaining constructor checks, :32-58
+            if self._owns:
+                capi.check(L.saip_batch_finalize(h))  # remaining constructor checks, :32-58
         except Exception:
-            L.saip_batch_destroy(h)
+            if self._owns:
+                L.saip_batch_destroy(h)
             self._h = None
             raise
-        self._private = bool(_private)  # the one-task batch of a task driven by hand (TemplateTask.h:43-60), not a user-visible controller
+        if self._owns:
+            self._after_finalize()
+
+    def _after_finalize(self):
+        """the part of the constructor behind saip_batch_finalize: the tasks' logged configuration is replayed into the batch"""
+        L, h, robot, tasks, _private = capi.lib(), self._h, self._robot, self._tasks, self._private
         for t in tasks:
             goal = None
             if t._ctrl is not None:  # the task was driven by hand before: it moves here (configuration replayed, goal kept; integrators start afresh)
@@ -879,7 +907,8 @@ class RobotController:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            capi.lib().saip_batch_destroy(self._h)
+            if getattr(self, "_owns", True):
+                capi.lib().saip_batch_destroy(self._h)
             self._h = None
 
     def _release(self):
@@ -1022,6 +1051,14 @@ class RobotController:
         ms = C.c_double(0)
         capi.check(capi.lib().saip_batch_time_steps(self._h, steps, warmup, C.byref(ms)))
         return ms.value
+
+    def timeStepsGather(self, steps: int, comm=None, gathered_ptr=None, every_step: bool = False):
+        """(elapsed_ms, gather_ms) of `steps` cycles with the torque all-gather inside the timed region (saip_batch_time_steps_gather): one gather
+        behind the last cycle, or one behind every cycle; comm None (one rank) issues no collective"""
+        e, g = C.c_double(0), C.c_double(0)
+        capi.check(capi.lib().saip_batch_time_steps_gather(self._h, comm, C.c_void_p(gathered_ptr) if gathered_ptr else None, int(steps),
+                                                           1 if every_step else 0, C.byref(e), C.byref(g)))
+        return e.value, g.value
 
     def devicePointers(self):
         L = capi.lib()

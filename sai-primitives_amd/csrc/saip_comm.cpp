@@ -153,6 +153,57 @@ extern "C" saip_status saip_batch_all_gather_torques(saip_batch* b, saip_comm* c
 	return SAIP_OK;
 }
 
+// `steps` cycles with the gather inside the timed region (see saip.h): events around the region and around every gather, all created before it
+namespace {
+struct EventPool {
+	std::vector<hipEvent_t> ev;
+	~EventPool() {
+		for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+	}
+	bool grow(size_t n) {
+		while (ev.size() < n) {
+			hipEvent_t e = nullptr;
+			if (hipEventCreate(&e) != hipSuccess) return false;
+			ev.push_back(e);
+		}
+		return true;
+	}
+};
+}  // namespace
+extern "C" saip_status saip_batch_time_steps_gather(saip_batch* b, saip_comm* c, double* gathered_dev, int steps, int gather_mode, double* elapsed_ms, double* gather_ms) {
+	if (!b || steps <= 0 || !elapsed_ms || !gather_ms || (gather_mode != 0 && gather_mode != 1) || (c && !gathered_dev))
+		return fail_external(SAIP_ERR_INVALID_ARGUMENT, "saip_batch_time_steps_gather: bad arguments");
+	hipStream_t stream = (hipStream_t)saip_batch_stream(b);
+	if (!stream) return fail_external(SAIP_ERR_ORDER, "saip_batch_time_steps_gather: the batch is not finalized on a device");
+	const int ngather = c ? (gather_mode == 1 ? steps : 1) : 0;
+	EventPool pool;
+	if (!pool.grow(2 + 2 * (size_t)ngather)) return fail_external(SAIP_ERR_DEVICE, "hipEventCreate failed");
+	HIP_TRY2(hipEventRecord(pool.ev[0], stream));
+	int g = 0;
+	for (int i = 0; i < steps; i++) {
+		saip_status st = saip_batch_step_async(b);
+		if (st) return st;
+		if (c && (gather_mode == 1 || i == steps - 1)) {
+			HIP_TRY2(hipEventRecord(pool.ev[2 + 2 * g], stream));
+			if ((st = saip_batch_all_gather_torques(b, c, gathered_dev))) return st;
+			HIP_TRY2(hipEventRecord(pool.ev[3 + 2 * g], stream));
+			g++;
+		}
+	}
+	HIP_TRY2(hipEventRecord(pool.ev[1], stream));
+	HIP_TRY2(hipStreamSynchronize(stream));
+	float ms = 0;
+	HIP_TRY2(hipEventElapsedTime(&ms, pool.ev[0], pool.ev[1]));
+	*elapsed_ms = ms;
+	double gsum = 0.0;
+	for (int i = 0; i < g; i++) {
+		HIP_TRY2(hipEventElapsedTime(&ms, pool.ev[2 + 2 * i], pool.ev[3 + 2 * i]));
+		gsum += ms;
+	}
+	*gather_ms = gsum;
+	return SAIP_OK;
+}
+
 // ------------------------------------------------------------------ one process, n devices
 struct saip_multi {
 	std::vector<int> devices;
@@ -230,6 +281,58 @@ extern "C" saip_status saip_multi_synchronize(saip_multi* m) {
 		saip_status st = saip_batch_synchronize(b);
 		if (st) return st;
 	}
+	return SAIP_OK;
+}
+extern "C" saip_status saip_multi_time_steps(saip_multi* m, int steps, int gather_mode, double* elapsed_ms, double* gather_ms) {
+	if (!m || !m->finalized) return fail_external(SAIP_ERR_ORDER, "saip_multi_time_steps: call saip_multi_finalize first");
+	if (steps <= 0 || !elapsed_ms || !gather_ms || (gather_mode != 0 && gather_mode != 1)) return fail_external(SAIP_ERR_INVALID_ARGUMENT, "saip_multi_time_steps: bad arguments");
+	const size_t nd = m->batches.size();
+	const bool coll = nd > 1;  // one device: there is nothing to gather, no collective is issued
+	const int ngather = coll ? (gather_mode == 1 ? steps : 1) : 0;
+	const size_t per = 2 + 2 * (size_t)ngather;
+	std::vector<EventPool> pools(nd);
+	for (size_t d = 0; d < nd; d++) {
+		HIP_TRY2(hipSetDevice(m->devices[d]));
+		if (!pools[d].grow(per)) return fail_external(SAIP_ERR_DEVICE, "hipEventCreate failed");
+	}
+	auto record = [&](size_t slot) -> hipError_t {
+		for (size_t d = 0; d < nd; d++) {
+			hipError_t e = hipSetDevice(m->devices[d]);
+			if (e == hipSuccess) e = hipEventRecord(pools[d].ev[slot], (hipStream_t)saip_batch_stream(m->batches[d]));
+			if (e != hipSuccess) return e;
+		}
+		return hipSuccess;
+	};
+	HIP_TRY2(record(0));
+	int g = 0;
+	for (int i = 0; i < steps; i++) {
+		saip_status st = saip_multi_step_async(m);
+		if (st) return st;
+		if (coll && (gather_mode == 1 || i == steps - 1)) {
+			HIP_TRY2(record(2 + 2 * (size_t)g));
+			if ((st = saip_multi_all_gather_torques(m))) return st;
+			HIP_TRY2(record(3 + 2 * (size_t)g));
+			g++;
+		}
+	}
+	HIP_TRY2(record(1));
+	saip_status st = saip_multi_synchronize(m);
+	if (st) return st;
+	double emax = 0.0, gmax = 0.0;
+	for (size_t d = 0; d < nd; d++) {
+		HIP_TRY2(hipSetDevice(m->devices[d]));
+		float ms = 0;
+		HIP_TRY2(hipEventElapsedTime(&ms, pools[d].ev[0], pools[d].ev[1]));
+		emax = ms > emax ? ms : emax;
+		double gsum = 0.0;
+		for (int i = 0; i < g; i++) {
+			HIP_TRY2(hipEventElapsedTime(&ms, pools[d].ev[2 + 2 * (size_t)i], pools[d].ev[3 + 2 * (size_t)i]));
+			gsum += ms;
+		}
+		gmax = gsum > gmax ? gsum : gmax;
+	}
+	*elapsed_ms = emax;
+	*gather_ms = gmax;
 	return SAIP_OK;
 }
 extern "C" double* saip_multi_gathered_device(saip_multi* m, int i) { return (m && m->finalized && i >= 0 && i < (int)m->gathered.size()) ? m->gathered[i] : nullptr; }

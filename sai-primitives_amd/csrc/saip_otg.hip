@@ -1,3 +1,23 @@
+// ---------------------------------------------------------------------------------------------------------------------------------
+// THIRD-PARTY NOTICE.  The closed-form profile expressions, root solvers and case structure in this file are derived from Ruckig 0.10.1
+// (https://github.com/pantor/ruckig, vendored by the reference under ruckig/), which is distributed under the MIT License:
+//
+//   MIT License -- Copyright (c) 2021 Lars Berscheid
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation files
+//   (the "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy, modify, merge,
+//   publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is furnished to do
+//   so, subject to the following conditions:
+//
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of the Software.
+//
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+//   MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE
+//   FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN
+//   CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// See THIRD_PARTY.md at the repository root.
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Batched online trajectory generation (internal OTG of JointTask, acceleration-limited mode -- the reference default).
 //
 // Reference call stack, one control cycle of one robot (JointTask.cpp:313-319):

@@ -112,6 +112,10 @@ class NativeGather:
         capi.check(self._L.saip_batch_all_gather_torques(self._ctrl._h, self._comm, out.data_ptr()))
         return out
 
+    def time_steps(self, steps: int, out, every_step: bool):
+        """(elapsed_ms, gather_ms): `steps` cycles + the all-gather (behind the last cycle, or behind every cycle) event-timed on the engine stream"""
+        return self._ctrl.timeStepsGather(steps, self._comm, out.data_ptr(), every_step)
+
     def close(self):
         if self._comm:
             self._L.saip_comm_destroy(self._comm)
@@ -125,3 +129,75 @@ def max_over_ranks(value: float, device) -> float:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class MultiController:
+    """ONE process driving n GPUs through the engine's own C++ multi-device layer (saip_multi_*, csrc/saip_comm.cpp: one batch + stream +
+    communicator per device, ncclCommInitAll, grouped ncclAllGather) -- no torch, no torch.distributed, no launcher.  Every device gets the
+    same task stack (built from workloads.py-style specs) and a contiguous shard of the instances."""
+
+    def __init__(self, description, task_specs, batch_per_device: int, devices, leading_dimension=None):
+        import ctypes as C
+        from . import capi
+        from .controller import SaiModel, RobotController, tasks_from_specs
+        L = capi.lib()
+        self._L, self._m = L, C.c_void_p()
+        self.devices = [int(d) for d in devices]
+        self.robots = [SaiModel(description, batch_per_device, d) for d in self.devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        capi.check(L.saip_multi_create(self.robots[0]._h, int(batch_per_device), arr, len(self.devices), C.byref(self._m)))
+        self.controllers, self.tasks = [], []
+        try:
+            for i, robot in enumerate(self.robots):
+                objs = tasks_from_specs(robot, task_specs)
+                self.controllers.append(RobotController(robot, objs, leading_dimension=leading_dimension, _adopt=L.saip_multi_batch(self._m, i)))
+                self.tasks.append(objs)
+            capi.check(L.saip_multi_finalize(self._m))   # finalizes every batch, then ncclCommInitAll and the gather buffers
+            for c in self.controllers:
+                c._after_finalize()
+        except Exception:
+            self.close()
+            raise
+
+    def world(self) -> int:
+        return int(self._L.saip_multi_size(self._m))
+
+    def step_async(self):
+        from . import capi
+        capi.check(self._L.saip_multi_step_async(self._m))
+
+    def all_gather(self):
+        from . import capi
+        capi.check(self._L.saip_multi_all_gather_torques(self._m))
+
+    def synchronize(self):
+        from . import capi
+        capi.check(self._L.saip_multi_synchronize(self._m))
+
+    def time_steps(self, steps: int, every_step_gather: bool):
+        """(elapsed_ms, gather_ms): HIP events on every device's stream, maximum over the devices (saip_multi_time_steps)"""
+        import ctypes as C
+        from . import capi
+        e, g = C.c_double(0.0), C.c_double(0.0)
+        capi.check(self._L.saip_multi_time_steps(self._m, int(steps), 1 if every_step_gather else 0, C.byref(e), C.byref(g)))
+        return e.value, g.value
+
+    def gathered(self, i: int):
+        """[n_devices][B][dof] host copy of the gathered torques as device i holds them"""
+        import numpy as np
+        import ctypes as C
+        from . import capi
+        n, dof, B = self.world(), self.robots[0].dof(), self.robots[0].batch_size
+        out = np.empty((n, dof, B))
+        capi.check(self._L.saip_multi_get_gathered_host(self._m, int(i), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.transpose(0, 2, 1)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            for c in self.controllers:
+                c._h = None           # the batches belong to the multi object
+            self._L.saip_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        self.close()

@@ -164,3 +164,28 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "saip_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_rejected_setter_leaves_the_replay_log_untouched(sp):
+    """a configuration call the engine (or, for a task outside any batch, the Python side) rejects changes nothing: the log replayed into the
+    batch the task joins keeps the last VALID call, getInternalOtgEnabled() keeps its value (the reference leaves its members untouched when a
+    setter throws, JointTask.cpp:400-409), and buffers of replaced log entries are released"""
+    robot = _cfg_only(sp)
+    jt = sp.JointTask(robot, task_name="posture")
+    jt.disableInternalOtg()
+    jt.enableInternalOtgJerkLimited(1.0, 2.0, 3.0)
+    good = [e for e in jt._log if e[0] == "saip_batch_set_otg_jerk_limited"]
+    assert len(good) == 1 and jt.getInternalOtgEnabled()
+    jt.disableInternalOtg()
+    with pytest.raises(ValueError, match="jerk"):   # task outside any batch: rejected before anything is logged
+        jt.enableInternalOtgJerkLimited(1.0, 2.0, 0.0)
+    assert [e for e in jt._log if e[0] == "saip_batch_set_otg_jerk_limited"] == good and not jt.getInternalOtgEnabled()
+    ctrl = sp.RobotController(robot, [jt])           # joins a (configuration-only) batch: the log replays without error
+    with pytest.raises(ValueError):                  # task inside a batch: the engine rejects, the log still holds the valid call
+        jt.enableInternalOtgJerkLimited(1.0, -2.0, 3.0)
+    assert [e for e in jt._log if e[0] == "saip_batch_set_otg_jerk_limited"] == good and not jt.getInternalOtgEnabled()
+    n0 = len(jt._keepalive)
+    for i in range(50):                              # a caller that sets gains every cycle grows neither the log nor the keep-alive table
+        jt.setGains(100.0 + i, 20.0, 0.0)
+    assert len(jt._keepalive) <= n0 + 1 and len([e for e in jt._log if "gains" in e[0]]) == 1
+    del ctrl

@@ -129,3 +129,78 @@ def test_uneven_shards_share_one_leading_dimension():
         controller_from_specs("panda_arm", tasks, 513, device=-1, leading_dimension=512)   # smaller than the batch
     with pytest.raises(ValueError):
         controller_from_specs("panda_arm", tasks, 513, device=-1, leading_dimension=550)   # not a multiple of 32
+
+
+class _StubLib:
+    """saip_comm_* of the C-ABI replaced by recorders (there is no RCCL and no device here): what is under test is NativeGather's collective
+    agree-or-fall-back logic around them -- the probe answers and slab shapes are reduced over the process group BEFORE anybody would enter
+    ncclCommInitRank, and rank 0's unique id reaches every rank"""
+
+    def __init__(self, real, rank, fail_probe_on=None):
+        self._real, self._rank, self._fail = real, rank, fail_probe_on
+        self.created_with = None
+
+    def __getattr__(self, name):   # everything else (saip_batch_dof, saip_batch_ld, ...) is the real library
+        return getattr(self._real, name)
+
+    def saip_comm_probe(self, device):
+        return 3 if self._rank == self._fail else 0      # SAIP_ERR_NO_DEVICE
+
+    def saip_comm_unique_id(self, buf):
+        for i in range(128):
+            buf[i] = (37 * i + 11) % 256
+        return 0
+
+    def saip_comm_create(self, device, world, rank, buf, out):
+        self.created_with = (device, world, rank, bytes(buf))
+        return 0
+
+    def saip_comm_world(self, comm):
+        return self.created_with[1]
+
+    def saip_comm_destroy(self, comm):
+        pass
+
+
+def _worker_native(rank, world, port, fail_on, ld_rank1, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import workloads as W
+    from sai_primitives_amd import sharding, capi
+    from sai_primitives_amd.controller import controller_from_specs
+    dist = sharding.init_process_group("gloo")
+    ld = ld_rank1 if rank == 1 else 64
+    _, ctrl, _ = controller_from_specs("panda_arm", W.config_tasks(2), 40, device=-1, leading_dimension=ld)
+    stub = _StubLib(capi.lib(), rank, fail_probe_on=fail_on)
+    capi.lib = lambda: stub                               # (this process only: mp.spawn children are fresh interpreters)
+    outcome = "ok"
+    try:
+        ng = sharding.NativeGather(ctrl, world, rank, rank, torch.device("cpu"))
+        assert ng.world() == world
+        assert stub.created_with[:3] == (rank, world, rank)
+        assert stub.created_with[3] == bytes((37 * i + 11) % 256 for i in range(128))   # rank 0's id, on every rank
+    except RuntimeError as e:
+        outcome = "fallback: " + str(e)[:60]
+        assert stub.created_with is None                  # nobody entered the communicator creation
+        # ... and the fallback bench.py takes still works on the same process group
+        slab = torch.full((7, 64), float(rank), dtype=torch.float64)
+        got = sharding.gather_torques(slab, world)
+        assert all(bool((got[r] == r).all()) for r in range(world))
+    with open(os.path.join(out_dir, f"native_{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on,ld_rank1,expect", [(None, 64, "ok"), (1, 64, "fallback"), (None, 96, "fallback")])
+def test_native_gather_agrees_or_falls_back_on_all_ranks(tmp_path, fail_on, ld_rank1, expect):
+    """all ranks create the native communicator, or none does: a probe that fails on ONE rank, or slabs of different shapes, make EVERY rank
+    raise before saip_comm_create (which would otherwise block the healthy ranks inside ncclCommInitRank)"""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker_native, args=(world, _free_port(), fail_on, ld_rank1, str(tmp_path)), nprocs=world, join=True)
+    outcomes = [open(tmp_path / f"native_{r}.txt").read() for r in range(world)]
+    assert all(o.startswith(expect) for o in outcomes), outcomes

@@ -4,7 +4,7 @@
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --config C --steps S`         -> kernel average durations
 #   2. (pmc = 1) separate rocprofv3 --pmc passes, one counter per run (gpurun refuses PMC together with other tracing)
 #   3. the bench line itself
-# Everything lands under gpurun_out/prof_cfg<C>_<tag>; tools/summarise_cfg.py turns it into the committed profiles/r03_* files.
+# Everything lands under gpurun_out/prof_cfg<C>_<tag>; tools/summarise_cfg.py turns it into the committed profiles/r04_* files.
 set -e
 CFG=${1:-2}; TAG=${2:-v1}; STEPS=${3:-200}; PMC=${4:-1}
 # counters of the PMC passes (one rocprofv3 run each); override with SAIP_PMC_COUNTERS="A B C"
