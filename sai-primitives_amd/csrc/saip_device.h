@@ -125,6 +125,7 @@ struct CycleParams {
 	int any_bie;
 	int oct_partial_mf;           // eight-lane kernel: the motion-force task is partial (k < 6)
 	int oct_truncate;             // eight-lane kernel: singularity handling disabled -> near-singular instances are reduced in the kernel
+	int wave_general_joint;       // wavefront kernel: some joint task needs a range basis (anything but one full joint task closing the hierarchy)
 	double bie_thr;
 	// per-task entry points of the general kernel (TemplateTask::updateTaskModel(N_prec) / computeTorques() / computeTorques(tau_prec),
 	// TemplateTask.h:43-60): evaluate ONE task with a caller-supplied N_prec instead of walking the hierarchy

@@ -1397,6 +1397,11 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 	P.oct_truncate = 0;
 	for (auto& T : b->tasks)
 		if (T.dev.general_law) P.lane_general = 1;
+	P.wave_general_joint = 0;
+	for (size_t t = 0; t < b->tasks.size(); t++) {
+		const TaskDev& T = b->tasks[t].dev;
+		if (T.type == saip::TASK_JOINT && !(T.s_identity && T.m == P.n && t + 1 == b->tasks.size())) P.wave_general_joint = 1;
+	}
 	P.lane_prefetch_ok = (b->tasks.size() == 2 && b->tasks[0].dev.type == saip::TASK_MOTION_FORCE && b->tasks[1].dev.type == saip::TASK_JOINT &&
 						  b->tasks[1].dev.m == P.n && !b->tasks[0].dev.general_law) ? 1 : 0;
 	{

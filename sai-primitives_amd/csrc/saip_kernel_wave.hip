@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "saip_device.h"
 #include "saip_fk.h"
 #include "saip_law.h"
@@ -81,7 +83,13 @@ __device__ __forceinline__ double wv_dot6(const double* S, const double* F) {  /
 #endif
 // JLA: RobotController::enableJointLimitAvoidance.  A separate instantiation because the wrap needs M^-1 once more AFTER the task loop: without it
 // the stored M^-1 (32 registers) is dead as soon as the last task has used it.
-template <bool JLA>
+// GENLAW: some motion-force task runs the general control law (velocity saturation, force / moment spaces, closed-loop force control);
+// GENJT: some joint task needs a range basis (anything but ONE full joint task closing the hierarchy).  Both are batch-uniform properties of the
+// stack, decided on the host (launch_cycle_wave).  They are template parameters because the register allocator sees every path of the task loop
+// at once: with the general law (~100 live values on one lane) and the Gram-Schmidt path (six 32 x 32 forms live) compiled in, the stack of
+// BASELINE config 5 -- which runs neither -- spilled its per-joint state at every turn of the law loop and M^-1 / N_prec at the head of the task
+// loop (656 B of scratch per lane, 343 reloads per wavefront: 42 % of its cycles waiting for memory; round 4).
+template <bool JLA, bool GENLAW, bool GENJT>
 __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const CycleParams P) {
 	__shared__ WaveSmem sm;
 	const int b = blockIdx.x;
@@ -284,7 +292,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			if (closed)
 				for (int i = 0; i < 6; i++) ifm[i] = saip_ldg(tk.integ, (size_t)(6 + i) * ld + b);
 			bool ovf = false;
-			if (tk.general_law) {
+			if (GENLAW && tk.general_law) {
 				// velocity saturation, force / moment spaces, open- or closed-loop force control
 				law_motion_force_general<true>(&tk, sm.vw, sm.xp, sm.Rc, sm.goal, ip, io, ifm, sm.Fum, sm.Ff, tk.popc ? tk.popc + b : nullptr, ld, &ovf);
 			} else {
@@ -372,9 +380,10 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 	wv_sync();
 	WSTAMP(4);
 	// ---------------------------------------------------------------- bounded inertia estimates: clamped entries, K^-1
-	double Kinv[2][1];
+	double Kinv[2][1], Kmat[2][1];  // K^-1 and K itself (the posture task's Woodbury step wants K)
 	int nclamp = 0, myidx = -1;  // column lo of the index matrix E (n x c) selects joint idx[lo]
 	Kinv[0][0] = Kinv[1][0] = 0.0;
+	Kmat[0][0] = Kmat[1][0] = 0.0;
 	if (P.any_bie && !flagged) {
 		const double thr = P.bie_thr;
 		const bool cl = lane < 32 && jv && sm.diagM[j] < thr;
@@ -398,6 +407,8 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 					else if (i < 8) K4[ks][0] = 1.0;
 				}
 			}
+			Kmat[0][0] = K4[0][0];
+			Kmat[1][0] = K4[1][0];
 			const double mp = wv_sweep<1>(K4, 2, lo, hi);
 			if (!(mp > 0.0)) flagged = true;
 			Kinv[0][0] = -K4[0][0];
@@ -406,11 +417,54 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 	}
 	WSTAMP(5);
 	// ---------------------------------------------------------------- task hierarchy
+	// N_prec.  Stacks without a range-basis joint task (!GENJT) have no other use for the LDS image (it serves the Gram-Schmidt path): there N_prec
+	// LIVES in the image between its uses -- read in stored form where a product wants it, in transposed form by the posture task, written back by
+	// the rank-k update -- and its 32 registers are free in between (they used to spend the whole task loop in scratch memory: the register
+	// allocator parked N_prec there at the loop head).  With the general joint task compiled in, N_prec stays in registers as before.
+	constexpr bool NPL = !GENJT;
 	double Np[8][2];
-	UNR for (int ks = 0; ks < 8; ks++)
-		UNR for (int t = 0; t < 2; t++) Np[ks][t] = (4 * ks + hi == 16 * t + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
+	auto np_load = [&]() {
+		UNR for (int ks = 0; ks < 8; ks++)
+			UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = sm.img[(4 * ks + hi) * LDI + 16 * tt + lo];
+	};
+	auto np_store = [&]() {
+		UNR for (int ks = 0; ks < 8; ks++)
+			UNR for (int tt = 0; tt < 2; tt++) sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] = Np[ks][tt];
+	};
+	if (!NPL) {
+		UNR for (int ks = 0; ks < 8; ks++)
+			UNR for (int t = 0; t < 2; t++) Np[ks][t] = (4 * ks + hi == 16 * t + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
+	}
+	bool np_ident = true;  // N_prec is still the identity (wave-uniform): the first task's products with it are skipped ("first task skips the product with N_prec = I")
 	bool all_full = true;  // every task so far acts with its full rank (motion-force tasks: certified, else flagged; joint tasks: r == m)
-	for (int t = 0; t < P.nt && !flagged; t++) {
+	// stored Jb = Bm^T Jw (k x n) of a motion-force task: lane (lo, hi) owns task directions 4 ks + hi of joints 16 tt + lo
+	auto jacobian_rows = [&](const TaskDev& tu, double (&Jb)[2][2]) {
+		const int ku = tu.k, bu = tu.body;
+		double Rb[9], ob[3], pw[3];
+		UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bu][e];
+		UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bu][9 + e];
+		oct_mat3_vec(Rb, tu.pos, pw);
+		UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
+		double bm[2][6];
+		UNR for (int ks = 0; ks < 2; ks++)
+			UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi < ku) ? tu.Bm[i * 6 + (4 * ks + hi < 6 ? 4 * ks + hi : 0)] : 0.0;
+		UNR for (int tt = 0; tt < 2; tt++) {
+			const int jj = 16 * tt + lo;
+			const double* S = sm.jd[jj];
+			const bool on = jj <= bu;
+			const double w0 = on ? S[0] : 0.0, w1 = on ? S[1] : 0.0, w2 = on ? S[2] : 0.0;
+			const double c0 = on ? (w1 * pw[2] - w2 * pw[1] + S[3]) : 0.0, c1 = on ? (w2 * pw[0] - w0 * pw[2] + S[4]) : 0.0,
+						 c2 = on ? (w0 * pw[1] - w1 * pw[0] + S[5]) : 0.0;
+			UNR for (int ks = 0; ks < 2; ks++)
+				Jb[ks][tt] = fma(w2, bm[ks][5], fma(w1, bm[ks][4], fma(w0, bm[ks][3], fma(c2, bm[ks][2], fma(c1, bm[ks][1], c0 * bm[ks][0])))));
+		}
+	};
+	// One task of the hierarchy.  MODE 0: either kind (the loop of the GENJT instantiations); 1: motion-force tasks only; 2: the joint task only.  The
+	// stacks without a range-basis joint task (!GENJT) are "motion-force tasks, then at most ONE full joint task": they run a loop over MODE 1 and
+	// then MODE 2 once, so that no turn of a loop carries the register needs of both kinds (the allocator spills what lives across a loop at its
+	// head: with both kinds in one body that was M^-1 or N_prec).
+	auto run_task = [&](const int t, auto mode_tag) __attribute__((always_inline)) {
+		constexpr int MODE = decltype(mode_tag)::value;
 		const TaskDev& tk = P.tasks[t];
 		const bool need_N = t + 1 < P.nt;
 		const bool track = tk.has_ki || P.integ_always;
@@ -419,9 +473,9 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = saip_ldg(tk.goal, (size_t)e * ld + b);
 		if (tk.decoupling == DEC_BIE && tk.bie_threshold != P.bie_thr) {
 			flagged = true;
-			break;
+			return;
 		}
-		if (tk.type == TASK_MOTION_FORCE) {
+		if (MODE != 2 && tk.type == TASK_MOTION_FORCE) {
 			const int k = tk.k, bd = tk.body;
 			// control point of the task (uniform LDS address: a broadcast read)
 			double Rb[9], ob[3], pw[3];
@@ -446,8 +500,14 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			__builtin_amdgcn_sched_barrier(0);
 			WSTAMP(9 + 10 * t);
 			double Jh[2][2], Jht[8][1];
-			wv_mm<false, false>(Jbt, Np, Jh);   // Jh = Jb N_prec (k x n)
-			wv_mm<false, false>(Np, Jbt, Jht);  // Jh^T (n x k)
+			if (np_ident) {  // N_prec = I: Jh = Jb, both forms straight from the joint data (32 MFMAs less)
+				jacobian_rows(tk, Jh);
+				UNR for (int ks = 0; ks < 8; ks++) Jht[ks][0] = Jbt[ks][0];
+			} else {
+				if (NPL) np_load();
+				wv_mm<false, false>(Jbt, Np, Jh);   // Jh = Jb N_prec (k x n)
+				wv_mm<false, false>(Np, Jbt, Jht);  // Jh^T (n x k)
+			}
 			WSTAMP(10 + 10 * t);
 			// singular values of the projected Jacobian (SingularityHandler.cpp:78-121): certificate on G = Jh Jh^T instead of an SVD
 			bool certified;
@@ -479,7 +539,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			}
 			if (!certified) {  // outside the non-singular branch, or too close to call: the general kernel decides (exact eigen-solve)
 				flagged = true;
-				break;
+				return;
 			}
 			WSTAMP(11 + 10 * t);
 			double T1[2][2], T1t[8][1], A2[2][1], Lam[4][1], Lmod[4][1];
@@ -499,7 +559,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			};
 			if (!pad_sweep(A2, Lam)) {
 				flagged = true;
-				break;
+				return;
 			}
 			WSTAMP(12 + 10 * t);
 			if (tk.decoupling == DEC_FULL) {
@@ -518,7 +578,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				wv_mm<true, true>(Ytt, Zk, AB);       // A - (T1 E) K^-1 (T1 E)^T
 				if (!pad_sweep(AB, Lmod)) {
 					flagged = true;
-					break;
+					return;
 				}
 			}
 			WSTAMP(13 + 10 * t);
@@ -545,12 +605,22 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			if (need_N) {  // N_prec <- N N_prec = N_prec - Jbar (Jh N_prec) with Jbar^T = Lambda T1: a rank-k update in place (24 MFMAs, no n x n temporaries)
 				double Lm2[2][1] = {{Lam[0][0]}, {Lam[1][0]}}, Jbart[2][2], JhN[2][2];
 				wv_mm<false, false>(Lm2, T1, Jbart);
-				wv_mm<false, false>(Jht, Np, JhN);
+				if (np_ident) {  // Jh N_prec = Jh, N_prec = I
+					UNR for (int ks = 0; ks < 2; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) JhN[ks][tt] = Jh[ks][tt];
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) Np[ks][tt] = (4 * ks + hi == 16 * tt + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
+				} else {
+					if (NPL) np_load();
+					wv_mm<false, false>(Jht, Np, JhN);
+				}
 				wv_mm<true, true>(Jbart, JhN, Np);
+				if (NPL) np_store();
+				np_ident = false;
 			}
 			wv_sync();
 			WSTAMP(15 + 10 * t);
-		} else {
+		} else if (MODE != 1) {
 			// ------------------------------------------------------------ JointTask
 			const int m = tk.m;
 			wv_sync();
@@ -609,112 +679,130 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				// Gram-Schmidt (n - sum k sequential steps) and the two reduced inverses.  matrixRangeBasis' rank decision (sigma_i / sigma_0 >= 1e-3,
 				// JointTask.cpp:233) is certified instead of computed: N_prec is a projector, so its non-zero singular values are >= 1 and
 				// sigma_0 <= ||N_prec||_F; ||N_prec||_F <= 100 keeps every one of them a factor 10 inside the tolerance (else: general kernel).
-				double fs = 0.0;
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) fs = fma(Np[ks][tt], Np[ks][tt], fs);
-				const double fro2 = wv_uniform(wv_wavesum(fs));
-				if (!(fro2 <= 1.0e4)) {
+				const bool same = tk.decoupling == DEC_FULL || (tk.decoupling == DEC_BIE && nclamp == 0), ident = tk.decoupling == DEC_IMPEDANCE;
+				if (ident) {  // Lambda_mod = I acts in range coordinates (U U^T f): impedance-type posture tasks keep the Gram-Schmidt path of the general kernel
 					flagged = true;
-					break;
+					return;
 				}
-				double CtC[8][2];
+				double Xm[8][2], Zst[8][1];
+				{
+					double NpT[8][2], Rm[8][2];  // stored N_prec^T through the LDS image, then M^-1 N_prec^T
+					if (!NPL) {
+						np_store();
+						wv_sync();
+					} else if (np_ident) {  // (a full joint task alone: nothing has written the image yet)
+						UNR for (int ks = 0; ks < 8; ks++)
+							UNR for (int tt = 0; tt < 2; tt++) sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] = (4 * ks + hi == 16 * tt + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
+						wv_sync();
+					}
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) NpT[ks][tt] = sm.img[(16 * tt + lo) * LDI + 4 * ks + hi];
+					double fs = 0.0;
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) fs = fma(NpT[ks][tt], NpT[ks][tt], fs);
+					const double fro2 = wv_uniform(wv_wavesum(fs));  // ||N_prec||_F^2: the rank certificate above
+					if (!(fro2 <= 1.0e4)) {
+						flagged = true;
+						return;
+					}
+					wv_mm<false, false>(Minv, NpT, Rm);
+					wv_mm<false, false>(NpT, Rm, Xm);  // X = N_prec M^-1 N_prec^T
+					if (!same) {
+						double Em[8][1];
+						UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
+						wv_mm<false, false>(Rm, Em, Zst);  // Z = N_prec M^-1 E (n x c)
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				// Y = X + gamma C^T C, C = the raw Jacobians of the tasks above, gamma = trace X / trace C^T C (any positive value would do: it only
+				// balances the two parts).  C^T C is never formed: trace(Jb^T Jb) = |Jb|_F^2 gives gamma first, then every task adds its
+				// (sqrt(gamma) Jb)^T (sqrt(gamma) Jb) straight into X on the matrix cores.
+				double dx = 0.0, dc = 0.0;
 				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) CtC[ks][tt] = 0.0;
+					UNR for (int tt = 0; tt < 2; tt++)
+						if (4 * ks + hi == 16 * tt + lo) dx += Xm[ks][tt];
 				for (int u = 0; u < t; u++) {
 					const TaskDev& tu = P.tasks[u];
 					if (tu.type == TASK_MOTION_FORCE) {
-						const int ku = tu.k, bu = tu.body;
-						double Rb[9], ob[3], pw[3], Jb[2][2];  // stored Jb = Bm^T Jw (k x n)
-						UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bu][e];
-						UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bu][9 + e];
-						oct_mat3_vec(Rb, tu.pos, pw);
-						UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
-						double bm[2][6];
+						double Jb[2][2];
+						jacobian_rows(tu, Jb);
 						UNR for (int ks = 0; ks < 2; ks++)
-							UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi < ku) ? tu.Bm[i * 6 + (4 * ks + hi < 6 ? 4 * ks + hi : 0)] : 0.0;
-						UNR for (int tt = 0; tt < 2; tt++) {
-							const int jj = 16 * tt + lo;
-							const double* S = sm.jd[jj];
-							const bool on = jj <= bu;
-							const double w0 = on ? S[0] : 0.0, w1 = on ? S[1] : 0.0, w2 = on ? S[2] : 0.0;
-							const double c0 = on ? (w1 * pw[2] - w2 * pw[1] + S[3]) : 0.0, c1 = on ? (w2 * pw[0] - w0 * pw[2] + S[4]) : 0.0,
-										 c2 = on ? (w0 * pw[1] - w1 * pw[0] + S[5]) : 0.0;
-							UNR for (int ks = 0; ks < 2; ks++)
-								Jb[ks][tt] = fma(w2, bm[ks][5], fma(w1, bm[ks][4], fma(w0, bm[ks][3], fma(c2, bm[ks][2], fma(c1, bm[ks][1], c0 * bm[ks][0])))));
-						}
-						wv_mm<true, false>(Jb, Jb, CtC);  // += Jb^T Jb
+							UNR for (int tt = 0; tt < 2; tt++) dc = fma(Jb[ks][tt], Jb[ks][tt], dc);
+					} else {
+						UNR for (int ks = 0; ks < 8; ks++)
+							UNR for (int tt = 0; tt < 2; tt++) {
+								const double sv = (4 * ks + hi < tu.m && 16 * tt + lo < n) ? tu.S[(4 * ks + hi) * n + 16 * tt + lo] : 0.0;
+								dc = fma(sv, sv, dc);
+							}
+					}
+				}
+				const double trX = wv_uniform(wv_wavesum(dx)), trC = wv_uniform(wv_wavesum(dc));
+				const double gam = trC > 0.0 ? trX / trC : 0.0, sg = sqrt(gam);
+				for (int u = 0; u < t; u++) {
+					const TaskDev& tu = P.tasks[u];
+					if (tu.type == TASK_MOTION_FORCE) {
+						double Jb[2][2];
+						jacobian_rows(tu, Jb);
+						UNR for (int ks = 0; ks < 2; ks++)
+							UNR for (int tt = 0; tt < 2; tt++) Jb[ks][tt] *= sg;
+						wv_mm<true, false>(Jb, Jb, Xm);  // += gamma Jb^T Jb
 					} else {
 						double Ss[8][2];  // stored S (m x n), full row rank under its N_prec (all_full)
 						UNR for (int ks = 0; ks < 8; ks++)
 							UNR for (int tt = 0; tt < 2; tt++)
-								Ss[ks][tt] = (4 * ks + hi < tu.m && 16 * tt + lo < n) ? tu.S[(4 * ks + hi) * n + 16 * tt + lo] : 0.0;
-						wv_mm<true, false>(Ss, Ss, CtC);  // += S^T S
+								Ss[ks][tt] = (4 * ks + hi < tu.m && 16 * tt + lo < n) ? sg * tu.S[(4 * ks + hi) * n + 16 * tt + lo] : 0.0;
+						wv_mm<true, false>(Ss, Ss, Xm);  // += gamma S^T S
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
-				const bool same = tk.decoupling == DEC_FULL || (tk.decoupling == DEC_BIE && nclamp == 0), ident = tk.decoupling == DEC_IMPEDANCE;
-				double Xm[8][2], Ztt[2][2];
-				{
-					double NpT[8][2], Rm[8][2];  // stored N_prec^T through the LDS image, then M^-1 N_prec^T
-					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] = Np[ks][tt];
-					wv_sync();
-					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) NpT[ks][tt] = sm.img[(16 * tt + lo) * LDI + 4 * ks + hi];
-					wv_mm<false, false>(Minv, NpT, Rm);
-					wv_mm<false, false>(NpT, Rm, Xm);  // X = N_prec M^-1 N_prec^T
-					if (!same && !ident) {
-						double Em[8][1];
-						UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
-						wv_mm<false, false>(Em, Rm, Ztt);  // (N_prec M^-1 E)^T (c x n)
-					}
-				}
-				__builtin_amdgcn_sched_barrier(0);
-				double dx = 0.0, dc = 0.0;
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++)
-						if (4 * ks + hi == 16 * tt + lo) {
-							dx += Xm[ks][tt];
-							dc += CtC[ks][tt];
-						}
-				const double trX = wv_uniform(wv_wavesum(dx)), trC = wv_uniform(wv_wavesum(dc));
-				const double gam = trC > 0.0 ? trX / trC : 0.0;
 				const int nbn = (n + 3) >> 2;
 				double zr[8], y2[2], zsum[2] = {0.0, 0.0};
-				if (ident) {  // Lambda_mod = I on the range: U U^T f = X^+ X f restricted... the identity acts in range coordinates: U U^T f
-					// U U^T = X X^+: (X + gamma C^T C)^-1 X f  (the C part annihilates X's range complement)
-					flagged = true;  // (impedance-type posture tasks keep the Gram-Schmidt path of the general kernel)
-					break;
-				}
-				if (!same) {  // X_B = X - Z K^-1 Z^T (bounded inertia estimates), then (X_B + gamma C^T C)^-1 f
-					double XB[8][2], Zk[2][2];
-					UNR for (int ks = 0; ks < 8; ks++)
-						UNR for (int tt = 0; tt < 2; tt++) XB[ks][tt] = fma(gam, CtC[ks][tt], Xm[ks][tt]);
-					wv_mm<false, false>(Kinv, Ztt, Zk);
-					wv_mm<true, true>(Ztt, Zk, XB);
-					wv_pad_identity(XB, n, 4 * nbn, lo, hi);
-					const double mp = wv_sweep<2>(XB, nbn, lo, hi);
-					if (!(mp > 0.0)) flagged = true;
-					wv_load_rows(sm.vb, hi, zr);
-					wv_matvec(XB, zr, y2);
-					zsum[0] -= y2[0];
-					zsum[1] -= y2[1];
-				}
-				__builtin_amdgcn_sched_barrier(0);
-				UNR for (int ks = 0; ks < 8; ks++)
-					UNR for (int tt = 0; tt < 2; tt++) Xm[ks][tt] = fma(gam, CtC[ks][tt], Xm[ks][tt]);
 				wv_pad_identity(Xm, n, 4 * nbn, lo, hi);
 				{
-					const double mp = wv_sweep<2>(Xm, nbn, lo, hi);
+					const double mp = wv_sweep<2>(Xm, nbn, lo, hi);  // Xm = -Y^-1
 					if (!(mp > 0.0)) flagged = true;
 				}
-				if (flagged) break;
-				wv_load_rows(sm.vc, hi, zr);
-				if (same) {
+				if (flagged) return;
+				// z = Y^-1 a + (X_B + gamma C^T C)^-1 f with X_B = X - Z K^-1 Z^T (bounded inertia estimates on the clamped joints).  The second inverse is
+				// a Woodbury step on the first (round 4: it used to be a second 32 x 32 sweep -- 48 MFMAs, eight pivot blocks and 32 more live registers):
+				//     (Y - Z K^-1 Z^T)^-1 = Y^-1 + Y^-1 Z (K - Z^T Y^-1 Z)^-1 Z^T Y^-1      =>      z = Y^-1 (a + f + Z w),   w = (K - Z^T Y^-1 Z)^-1 Z^T Y^-1 f,
+				// one c x c sweep (c <= 8 clamped joints); K - Z^T Y^-1 Z is the Schur complement of [Y Z; Z^T K], positive definite exactly when X_B + gamma C^T C is.
+				wv_load_rows(sm.vc, hi, zr);  // a
+				{
 					double fr8[8];
-					wv_load_rows(sm.vb, hi, fr8);
+					wv_load_rows(sm.vb, hi, fr8);  // f
+					if (!same) {
+						double Wst[8][1], ZtW[2][1], Sm4[4][1], yu[2], ur[8], zu[1], zur[2], wc[1];
+						wv_mm<false, true>(Xm, Zst, Wst);    // Y^-1 Z (n x c): Xm = -Y^-1
+						wv_mm<false, false>(Zst, Wst, ZtW);  // Z^T Y^-1 Z (c x c)
+						UNR for (int ks = 0; ks < 4; ks++) {
+							const int i = 4 * ks + hi;
+							double val = ks < 2 ? Kmat[ks < 2 ? ks : 0][0] - ZtW[ks < 2 ? ks : 0][0] : 0.0;
+							if ((i >= nclamp || lo >= nclamp) && i < 8 && lo < 8) val = (i == lo) ? 1.0 : 0.0;
+							Sm4[ks][0] = val;
+						}
+						const double mp = wv_sweep<1>(Sm4, 2, lo, hi);  // -> -(K - Z^T Y^-1 Z)^-1
+						if (!(mp > 0.0)) flagged = true;
+						wv_matvec(Xm, fr8, yu);  // -Y^-1 f, column distribution
+						wv_sync();
+						if (hi == 0) {
+							sm.vd[lo] = -yu[0];
+							sm.vd[16 + lo] = -yu[1];
+						}
+						wv_sync();
+						wv_load_rows(sm.vd, hi, ur);
+						wv_matvec(Zst, ur, zu);  // Z^T Y^-1 f (c entries)
+						if (lane < 16) sm.g8[lane] = zu[0];
+						wv_sync();
+						wv_load_rows(sm.g8, hi, zur);
+						double Sm2[2][1] = {{Sm4[0][0]}, {Sm4[1][0]}};
+						wv_matvec(Sm2, zur, wc);  // -w, column distribution: entry lo in every row of lanes
+						// Z w in ROW distribution straight from the stored form: (Z w)[4 ks + hi] = sum over lo of Z[4 ks + hi][lo] w[lo]
+						UNR for (int ks = 0; ks < 8; ks++) fr8[ks] -= wv_rowsum(Zst[ks][0] * wc[0]);
+					}
 					UNR for (int ks = 0; ks < 8; ks++) zr[ks] += fr8[ks];
 				}
+				if (flagged) return;
 				wv_matvec(Xm, zr, y2);  // (the sweep leaves -inverse)
 				zsum[0] -= y2[0];
 				zsum[1] -= y2[1];
@@ -725,14 +813,25 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				}
 				wv_sync();
 				wv_load_rows(sm.vd, hi, zr);
-				wv_matvec(Np, zr, y2);  // tau += N_prec^T z
+				{
+					// N_prec once more from its LDS image (written above for the transpose, untouched since): its 32 registers are free for the two
+					// sweeps in between instead of living in scratch memory
+					double NpL[8][2];
+					UNR for (int ks = 0; ks < 8; ks++)
+						UNR for (int tt = 0; tt < 2; tt++) NpL[ks][tt] = sm.img[(4 * ks + hi) * LDI + 16 * tt + lo];
+					wv_matvec(NpL, zr, y2);  // tau += N_prec^T z
+				}
 				if (hi == 0) {
 					sm.tau[lo] += y2[0];
 					sm.tau[16 + lo] += y2[1];
 				}
 				wv_sync();
 				WSTAMP(13 + 10 * t);
-				break;  // (!need_N: this was the last task -- leaving the loop here tells the register allocator that M^-1 and N_prec are dead)
+				return;  // (!need_N: this was the last task -- leaving the loop here tells the register allocator that M^-1 and N_prec are dead)
+			}
+			if (!GENJT) {  // (not reached: the host gives stacks with such a joint task the GENJT instantiation)
+				flagged = true;
+				return;
 			}
 			// Jp = S N_prec (JointTask.cpp:231)
 			double Wc[8][2];
@@ -825,7 +924,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			}
 			if (need_exact) {  // ambiguous rank gap: the general kernel decides with the reference's tolerances (eigen-solve of the Gram matrix)
 				flagged = true;
-				break;
+				return;
 			}
 			const int r = rank;
 			if (r != m) all_full = false;
@@ -885,7 +984,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 					wv_negate(A);  // Lambda
 					if (same) wv_matvec(A, b1r, ymod);
 				}
-				if (flagged) break;
+				if (flagged) return;
 				WSTAMP(12 + 10 * t);
 				{
 					double a1r[8], y[2];
@@ -934,11 +1033,19 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 					load_Jht(Jht);
 					wv_mm<false, false>(Jht, Np, JhN);
 					wv_mm<true, true>(Jbart, JhN, Np);
+					np_ident = false;
 				}
 			}
 			// r == 0: no controllable direction left, N = I (JointTask.cpp:234-239)
 			wv_sync();
 		}
+	};
+	if (GENJT) {
+		for (int t = 0; t < P.nt && !flagged; t++) run_task(t, std::integral_constant<int, 0>());
+	} else {
+		int t = 0;
+		for (; t < P.nt && !flagged && P.tasks[t].type == TASK_MOTION_FORCE; t++) run_task(t, std::integral_constant<int, 1>());
+		if (t < P.nt && !flagged) run_task(t, std::integral_constant<int, 2>());  // (the host gives this instantiation only to stacks whose one joint task is the last task)
 	}
 	wv_sync();
 	WSTAMP(60);
@@ -1020,9 +1127,21 @@ extern "C" int saip_debug_stamps_wave(unsigned long long* out) {
 	return hipMemcpyFromSymbol(out, HIP_SYMBOL(saip_stamps_wave), sizeof(unsigned long long) * 256 * 64) == hipSuccess ? 0 : -1;
 }
 #endif
+template <bool JLA, bool GENLAW>
+static void launch_wave_jt(const bool genjt, const CycleParams& P, hipStream_t stream) {
+	if (genjt) hipLaunchKernelGGL((saip_cycle_wave<JLA, GENLAW, true>), dim3(P.B), dim3(64), 0, stream, P);
+	else hipLaunchKernelGGL((saip_cycle_wave<JLA, GENLAW, false>), dim3(P.B), dim3(64), 0, stream, P);
+}
 hipError_t launch_cycle_wave(const CycleParams& P, hipStream_t stream) {
-	if (P.jla) hipLaunchKernelGGL(saip_cycle_wave<true>, dim3(P.B), dim3(64), 0, stream, P);
-	else hipLaunchKernelGGL(saip_cycle_wave<false>, dim3(P.B), dim3(64), 0, stream, P);
+	// P.lane_general: some task runs a general control law; P.wave_general_joint: some joint task needs a range basis (saip_engine.cpp)
+	const bool genlaw = P.lane_general != 0, genjt = P.wave_general_joint != 0;
+	if (P.jla) {
+		if (genlaw) launch_wave_jt<true, true>(genjt, P, stream);
+		else launch_wave_jt<true, false>(genjt, P, stream);
+	} else {
+		if (genlaw) launch_wave_jt<false, true>(genjt, P, stream);
+		else launch_wave_jt<false, false>(genjt, P, stream);
+	}
 	return hipGetLastError();
 }
 

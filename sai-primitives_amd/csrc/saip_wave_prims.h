@@ -142,9 +142,9 @@ __device__ __forceinline__ void wv_load_rows(const double* x, const int hi, doub
 // In place: stored symmetric positive definite X (16 T x 16 T) -> stored -X^-1 on the leading 4 nb rows / columns (nb wave-uniform;
 // what lies beyond must be the identity -- it is left alone).  Returns the smallest LDL^T pivot met: X is positive definite iff it is
 // positive (the singular-value certificates test it against their tolerance; a caller that gets a non-positive one discards the
-// result).  Block step kb (pivot rows 4 kb .. 4 kb + 3, living in column tile t0 = kb / 4 at lanes lo = rho .. rho + 3, rho = 4 (kb % 4)):
+// result; a non-positive 2 x 2 determinant shows as a non-positive pivot).  Block step kb (pivot rows 4 kb .. 4 kb + 3, living in column tile t0 = kb / 4 at lanes lo = rho .. rho + 3, rho = 4 (kb % 4)):
 //   P_t = v[kb][t]                       the pivot's block row = (by symmetry) its block column, already an MFMA operand
-//   D   = the 4 x 4 diagonal block       16 lanes of P_t0; every lane rebuilds it from v_readlane broadcasts and inverts it (Cholesky)
+//   D   = the 4 x 4 diagonal block       16 lanes of P_t0; rebuilt from v_readlane broadcasts (scalar registers) and inverted by 2 x 2 blocks in closed form
 //   W_t = P_t D^-1                       one MFMA per tile: A operand = D^-1 on rows rho .., B operand = P_t; lands in register kb % 4
 //   X  -= W P'^T                         T x T MFMAs; P' = P with -I on the pivot's own columns and those columns of X zeroed first, so
 //                                        that the block column comes out as +W exactly (sweep operator: a_ik <- a_ik / a_kk)
@@ -157,24 +157,50 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 			const int t0 = kb >> 2, rho = 4 * (kb & 3);
 			double P[T];
 			UNR for (int t = 0; t < T; t++) P[t] = v[kb][t];
-			// D[b][a] sits in lane (rho + a) + 16 b of P[t0]; lower triangle by broadcast
-			double L[4][4], dinv[4];
+			// D[b][a] sits in lane (rho + a) + 16 b of P[t0]; lower triangle by broadcast (wave-uniform values: scalar registers)
+			double D[4][4];
 			UNR for (int i = 0; i < 4; i++)
-				UNR for (int j2 = 0; j2 <= i; j2++) L[i][j2] = wv_readlane(P[t0], (rho + j2) + 16 * i);
-			UNR for (int k = 0; k < 4; k++) {
-				minpiv = (L[k][k] < minpiv || L[k][k] != L[k][k]) ? L[k][k] : minpiv;  // (a NaN pivot sticks: every later comparison with it is false)
-				const double rs = oct_rsqrt(L[k][k]);
-				dinv[k] = rs;
-				UNR for (int i = k + 1; i < 4; i++) L[i][k] *= rs;
-				UNR for (int j2 = k + 1; j2 < 4; j2++)
-					UNR for (int i = j2; i < 4; i++) L[i][j2] = fma(-L[i][k], L[j2][k], L[i][j2]);
+				UNR for (int j2 = 0; j2 <= i; j2++) D[i][j2] = wv_readlane(P[t0], (rho + j2) + 16 * i);
+			// D^-1 by 2 x 2 blocks in closed form, D = [A B^T; B C]:  A^-1 = adj(A) / det A,  E = B A^-1,  S = C - E B^T,  S^-1 = adj(S) / det S,
+			//   D^-1 = [A^-1 + E^T S^-1 E, -(S^-1 E)^T; -S^-1 E, S^-1].
+			// Two reciprocals in sequence where the 4 x 4 Cholesky factor + substitution this replaces had four reciprocal square roots and two
+			// triangular solves (round 4: the dependent chain of a pivot block ~650 -> ~250 clocks; 38 pivot blocks per config-5 instance).  The LDL^T
+			// pivots the certificates look at are d00, det A / d00, s00, det S / s00 (their reciprocals are off the chain: hardware estimate).
+			double Di[4][4];  // lower triangle of D^-1
+			{
+				const double a00 = D[0][0], a10 = D[1][0], a11 = D[1][1];
+				const double b00 = D[2][0], b01 = D[2][1], b10 = D[3][0], b11 = D[3][1];
+				const double c00 = D[2][2], c10 = D[3][2], c11 = D[3][3];
+				const double detA = fma(a00, a11, -a10 * a10);
+				const double iA = oct_rcp(detA);
+				const double ai00 = a11 * iA, ai10 = -a10 * iA, ai11 = a00 * iA;
+				const double e00 = fma(b00, ai00, b01 * ai10), e01 = fma(b00, ai10, b01 * ai11);
+				const double e10 = fma(b10, ai00, b11 * ai10), e11 = fma(b10, ai10, b11 * ai11);
+				const double s00 = c00 - fma(e00, b00, e01 * b01), s10 = c10 - fma(e10, b00, e11 * b01), s11 = c11 - fma(e10, b10, e11 * b11);
+				const double detS = fma(s00, s11, -s10 * s10);
+				const double iS = oct_rcp(detS);
+				const double si00 = s11 * iS, si10 = -s10 * iS, si11 = s00 * iS;
+				const double f00 = fma(si00, e00, si10 * e10), f01 = fma(si00, e01, si10 * e11);
+				const double f10 = fma(si10, e00, si11 * e10), f11 = fma(si10, e01, si11 * e11);
+				Di[0][0] = fma(e00, f00, fma(e10, f10, ai00));
+				Di[1][0] = fma(e01, f00, fma(e11, f10, ai10));
+				Di[1][1] = fma(e01, f01, fma(e11, f11, ai11));
+				Di[2][0] = -f00;
+				Di[2][1] = -f01;
+				Di[3][0] = -f10;
+				Di[3][1] = -f11;
+				Di[2][2] = si00;
+				Di[3][2] = si10;
+				Di[3][3] = si11;
+				const double piv[4] = {a00, detA * __builtin_amdgcn_rcp(a00), s00, detS * __builtin_amdgcn_rcp(s00)};
+				UNR for (int k = 0; k < 4; k++) minpiv = (piv[k] < minpiv || piv[k] != piv[k]) ? piv[k] : minpiv;  // (a NaN pivot sticks: every later comparison with it is false)
 			}
-			double x[4];
-			oct_solve_unit<4>(L, dinv, hi, x);  // column hi of D^-1
 			const int a = lo - rho;
 			const bool inblk = a >= 0 && a < 4;
-			const double xa = (a == 0) ? x[0] : (a == 1) ? x[1] : (a == 2) ? x[2] : x[3];
-			const double dl = inblk ? xa : 0.0;  // D^-1[a][hi] on the pivot's lanes, 0 elsewhere
+			// D^-1[a][hi] on the pivot's lanes, 0 elsewhere (symmetric: entry (max, min) of the lower triangle)
+			double dl = 0.0;
+			UNR for (int i = 0; i < 4; i++)
+				UNR for (int j2 = 0; j2 <= i; j2++) dl = ((a == i && hi == j2) || (a == j2 && hi == i)) ? Di[i][j2] : dl;
 			double W[T];
 			UNR for (int t = 0; t < T; t++) {
 				wv_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
