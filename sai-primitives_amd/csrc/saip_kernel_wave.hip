@@ -251,6 +251,8 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		if (tk.type != TASK_MOTION_FORCE) continue;
 		const bool track = tk.has_ki || P.integ_always;
 		const int k = tk.k, bd = tk.body;
+		// (requesting every task's goal rows at the start of the kernel, so that they travel while the kinematics run, was measured and lost: 180.5 against
+		// 172.7 us per launch, round 4 -- the eight extra live values cost more in the phases in between than the round trip here)
 		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = saip_ldg(tk.goal, (size_t)e * ld + b);
 		double Rb[9], ob[3], pw[3], Rcf[9];
 		UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bd][e];
@@ -435,7 +437,10 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		UNR for (int ks = 0; ks < 8; ks++)
 			UNR for (int t = 0; t < 2; t++) Np[ks][t] = (4 * ks + hi == 16 * t + lo && 4 * ks + hi < n) ? 1.0 : 0.0;
 	}
-	bool np_ident = true;  // N_prec is still the identity (wave-uniform): the first task's products with it are skipped ("first task skips the product with N_prec = I")
+	// N_prec is still the identity (wave-uniform): the first task's products with it are skipped ("first task skips the product with
+	// N_prec = I").  Not in the GENJT instantiations: their one loop body would carry both versions of every product (measured in registers: 912
+	// against 656 B of scratch per lane).
+	bool np_ident = NPL;
 	bool all_full = true;  // every task so far acts with its full rank (motion-force tasks: certified, else flagged; joint tasks: r == m)
 	// stored Jb = Bm^T Jw (k x n) of a motion-force task: lane (lo, hi) owns task directions 4 ks + hi of joints 16 tt + lo
 	auto jacobian_rows = [&](const TaskDev& tu, double (&Jb)[2][2]) {
@@ -537,10 +542,8 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				const double mp = wv_sweep<1>(Gc, 2, lo, hi);
 				certified = wv_uniform((mp > 1e-13) && ok_s0 && (tr > 0.0) && !nonfinite);
 			}
-			if (!certified) {  // outside the non-singular branch, or too close to call: the general kernel decides (exact eigen-solve)
-				flagged = true;
-				return;
-			}
+			// (no branch on the certificate yet: its chain -- three dependent products, a sweep -- and the Lambda chain below are independent; in one
+			// basic block the scheduler interleaves their MFMAs instead of waiting out each one's result latency)
 			WSTAMP(11 + 10 * t);
 			double T1[2][2], T1t[8][1], A2[2][1], Lam[4][1], Lmod[4][1];
 			wv_mm<false, false>(Jht, Minv, T1);   // Jh M^-1 (k x n)
@@ -557,7 +560,8 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				wv_negate(Out);
 				return mp > 0.0;
 			};
-			if (!pad_sweep(A2, Lam)) {
+			const bool lam_ok = pad_sweep(A2, Lam);
+			if (!certified || !lam_ok) {  // outside the non-singular branch, or too close to call: the general kernel decides (exact eigen-solve)
 				flagged = true;
 				return;
 			}

@@ -152,6 +152,11 @@ __device__ __forceinline__ void wv_load_rows(const double* x, const int hi, doub
 template <int T>
 __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, const int lo, const int hi) {
 	double minpiv = 1.0e300;
+	bool nanpiv = false;
+	// which entry of the (symmetric) 4 x 4 inverse a lane of a pivot block takes: D^-1[a][hi] with a = lo & 3 -- the same in every block step of the
+	// sweep, so the ten selection masks are formed once here (they used to be rebuilt from a = lo - rho in each of the 4 T steps)
+	const int sa = lo & 3, smax = sa > hi ? sa : hi, smin = sa > hi ? hi : sa;
+	const int scode = smax * 4 + smin;
 	UNR for (int kb = 0; kb < 4 * T; kb++) {
 		if (kb < nb) {  // wave-uniform
 			const int t0 = kb >> 2, rho = 4 * (kb & 3);
@@ -192,22 +197,27 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 				Di[2][2] = si00;
 				Di[3][2] = si10;
 				Di[3][3] = si11;
-				const double piv[4] = {a00, detA * __builtin_amdgcn_rcp(a00), s00, detS * __builtin_amdgcn_rcp(s00)};
-				UNR for (int k = 0; k < 4; k++) minpiv = (piv[k] < minpiv || piv[k] != piv[k]) ? piv[k] : minpiv;  // (a NaN pivot sticks: every later comparison with it is false)
+				// smallest pivot so far (v_min ignores a NaN operand, so NaNs are tracked on the side: a NaN anywhere in the block shows in the sum)
+				const double p1 = detA * __builtin_amdgcn_rcp(a00), p3 = detS * __builtin_amdgcn_rcp(s00);
+				minpiv = fmin(fmin(minpiv, a00), fmin(p1, fmin(s00, p3)));
+				const double psum = (a00 + p1) + (s00 + p3);
+				nanpiv = nanpiv || (psum != psum);
 			}
 			const int a = lo - rho;
-			const bool inblk = a >= 0 && a < 4;
+			const bool inblk = (lo >> 2) == (kb & 3);
 			// D^-1[a][hi] on the pivot's lanes, 0 elsewhere (symmetric: entry (max, min) of the lower triangle)
-			double dl = 0.0;
-			UNR for (int i = 0; i < 4; i++)
-				UNR for (int j2 = 0; j2 <= i; j2++) dl = ((a == i && hi == j2) || (a == j2 && hi == i)) ? Di[i][j2] : dl;
+			double dl = Di[0][0];
+			UNR for (int i = 1; i < 4; i++)
+				UNR for (int j2 = 0; j2 <= i; j2++) dl = (scode == 4 * i + j2) ? Di[i][j2] : dl;
+			dl = inblk ? dl : 0.0;
 			double W[T];
 			UNR for (int t = 0; t < T; t++) {
 				wv_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dl, P[t], acc, 0, 0, 0);
 				W[t] = acc[kb & 3];  // W[16 t + lo][hi]
 			}
-			UNR for (int ks = 0; ks < 4 * T; ks++) v[ks][t0] = inblk ? 0.0 : v[ks][t0];
+			const double keep = inblk ? 0.0 : 1.0;
+			UNR for (int ks = 0; ks < 4 * T; ks++) v[ks][t0] *= keep;  // (one multiplication per entry where a select costs two moves; a NaN or infinity here is a failed sweep anyway)
 			double Pm[T];
 			UNR for (int t = 0; t < T; t++) Pm[t] = P[t];
 			Pm[t0] = inblk ? ((hi == a) ? -1.0 : 0.0) : Pm[t0];
@@ -222,7 +232,8 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 			v[kb][t0] = inblk ? -dl : v[kb][t0];
 		}
 	}
-	return wv_uniform(minpiv);
+	const double mp = wv_uniform(minpiv);
+	return wv_uniform(nanpiv) ? __builtin_nan("") : mp;  // (a NaN pivot fails every "> tolerance" test of the callers)
 }
 
 template <int KS, int T>
