@@ -252,7 +252,7 @@ __device__ __forceinline__ bool oct_cycle_body(const CycleParams& P, OctInst* sm
 	OctInst& sm = smem[grp];
 	OctInst& smA = smemA[grp];  // wavefront A's block (B reads A = J M^-1 J^T, T1 and M^-1 from it after the first barrier)
 	OctInst& smB = smemB[grp];  // where wavefront B leaves its results
-	const int b_raw = blockIdx.x * 8 + grp;
+	const int b_raw = (int)blockIdx.x * 8 + grp;
 	const bool live = b_raw < P.B;
 	const int b = live ? b_raw : P.B - 1;
 	const size_t ld = P.ld;

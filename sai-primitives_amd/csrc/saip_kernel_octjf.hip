@@ -84,7 +84,7 @@ __device__ __forceinline__ bool jf_body(const CycleParams& P, JfInst* smem, doub
 	const int rr = r < n ? r : n - 1;  // (7 dof) the padding lane mirrors joint 6
 	const bool act = r < n;
 	JfInst& sm = smem[grp];
-	const int b_raw = blockIdx.x * 8 + grp;
+	const int b_raw = (int)blockIdx.x * 8 + grp;
 	const bool live = b_raw < P.B;
 	const int b = live ? b_raw : P.B - 1;
 	const size_t ld = P.ld;

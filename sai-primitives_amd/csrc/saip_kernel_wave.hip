@@ -92,7 +92,7 @@ __device__ __forceinline__ double wv_dot6(const double* S, const double* F) {  /
 template <bool JLA, bool GENLAW, bool GENJT>
 __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const CycleParams P) {
 	__shared__ WaveSmem sm;
-	const int b = blockIdx.x;
+	const int b = saip_xcd_block(blockIdx.x, gridDim.x);  // (one instance per workgroup: the instances of an XCD are contiguous, see saip_oct_common.h)
 	if (b >= P.B) return;
 	const int lane = threadIdx.x, lo = lane & 15, hi = lane >> 4;
 	const int j = lane & 31;  // joint owned in the per-joint phases (both halves of the wavefront do the same work)

@@ -55,6 +55,26 @@ __device__ __forceinline__ double oct_group_max(double x) {
 	return fmax(x, oct_dpp<DPP_HALF_MIRROR>(x));
 }
 
+// Which block of instances a workgroup takes.  The dispatcher is observed to deal workgroups round-robin over the 8 XCDs (workgroups w and w + 8
+// share one; MI355X_MICROARCH.md "Workgroup dispatch, XCD placement"), each with a private L2.  With block = blockIdx, neighbouring blocks -- which
+// share cache lines of every [row][ld] input array (8 instances x 8 B = half a 128-B line per row for the eight-lane kernels, ONE double per row for
+// the wavefront-per-instance kernel) -- sit on different XCDs, and every line is fetched from HBM once per XCD that touches it (measured, round 3 / 4:
+// 2.15 x the algorithmic bytes on config 2, 8 x on config 5).  This bijective remap gives the workgroups of one XCD a contiguous range of blocks.
+// A speed choice only: any other placement reads the same values.  (SAIP_NO_XCD_REMAP: identity, for A/B builds.)
+// Used by the wavefront-per-instance kernel only (config 5, same session: 172.7 -> 170.2 us per launch, HBM traffic 65 -> 11 MB against 7.5 MB
+// algorithmic).  The eight-lane kernels were measured with it as well and run on plain blockIdx: their traffic fell as expected (config 2: 4.6 ->
+// 2.7 MB per launch against 2.2 algorithmic) but every launch got SLOWER (config 2 6.67 -> 6.92 us, config 3 13.53 -> 13.85, config 4's shard 9.61 ->
+// 10.02; tools/ab_remap.sh) -- at 4 % of the HBM peak the bytes are not what these kernels wait for, and neighbouring workgroups that miss on the
+// same line at the same moment queue behind one another in one L2 instead of missing in parallel in two.
+__device__ __forceinline__ int saip_xcd_block(const unsigned orig, const unsigned nwg) {
+#if defined(SAIP_NO_XCD_REMAP)
+	return (int)orig;
+#else
+	const unsigned q = nwg >> 3, r = nwg & 7u, x = orig & 7u;
+	return (int)((x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (orig >> 3));
+#endif
+}
+
 // ---------------------------------------------------------------- lane layout
 // Eight lanes per instance, eight instances per wavefront, two instances per 16-lane DPP row.  INTERLEAVED (default): the two instances of a
 // row take its even and its odd lanes (joint r of instance 2 row + parity sits in lane 16 row + 2 r + parity).  Every boundary of a scan along
