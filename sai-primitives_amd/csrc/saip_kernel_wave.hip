@@ -139,24 +139,33 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			UNR for (int e = 0; e < 12; e++) X[e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
 		}
 	}
-	// log-step prefix product over the chain: T_j <- T_{j-d} o T_j, (Ra, oa) o (Rb, ob) = (Ra Rb, oa + Ra ob)
-	UNR for (int d = 1; d < 32; d <<= 1) {
-		if (d < n) {
-			if (lane < 32) {
-				UNR for (int e = 0; e < 12; e++) sm.img[12 * j + e] = X[e];
-			}
-			wv_sync();
-			if (j >= d) {
-				double Xa[12], Xn[12];
-				UNR for (int e = 0; e < 12; e++) Xa[e] = sm.img[12 * (j - d) + e];
-				UNR for (int r = 0; r < 3; r++) {
-					UNR for (int cc = 0; cc < 3; cc++) Xn[3 * r + cc] = Xa[3 * r] * X[cc] + Xa[3 * r + 1] * X[3 + cc] + Xa[3 * r + 2] * X[6 + cc];
-					Xn[9 + r] = Xa[9 + r] + Xa[3 * r] * X[9] + Xa[3 * r + 1] * X[10] + Xa[3 * r + 2] * X[11];
-				}
-				UNR for (int e = 0; e < 12; e++) X[e] = Xn[e];
-			}
-			wv_sync();
+	// log-step prefix product over the chain: T_j <- T_{j-d} o T_j, (Ra, oa) o (Rb, ob) = (Ra Rb, oa + Ra ob).  Joint j sits in lane j (and j + 32):
+	// joints 0..15 and 16..31 are two 16-lane DPP rows, so the steps d = 1, 2, 4, 8 are row shifts (a VALU move per dword; lanes without a left
+	// neighbour receive the identity) and only the last step crosses rows: joint 15's frame, read through the scalar unit, in front of every
+	// joint of the second row.  (Round 4; the five steps used to be LDS round trips with two wavefront fences each.)
+#define WV_FRAME_STEP(D)                                                                                                                  \
+	if (D < n) {                                                                                                                          \
+		double Xa[12], Xn[12];                                                                                                            \
+		UNR for (int e = 0; e < 12; e++) Xa[e] = (e == 0 || e == 4 || e == 8) ? wv_shr<D, true>(X[e]) : wv_shr<D, false>(X[e]);           \
+		UNR for (int r = 0; r < 3; r++) {                                                                                                 \
+			UNR for (int cc = 0; cc < 3; cc++) Xn[3 * r + cc] = Xa[3 * r] * X[cc] + Xa[3 * r + 1] * X[3 + cc] + Xa[3 * r + 2] * X[6 + cc]; \
+			Xn[9 + r] = Xa[9 + r] + Xa[3 * r] * X[9] + Xa[3 * r + 1] * X[10] + Xa[3 * r + 2] * X[11];                                     \
+		}                                                                                                                                 \
+		UNR for (int e = 0; e < 12; e++) X[e] = Xn[e];                                                                                    \
+	}
+	WV_FRAME_STEP(1)
+	WV_FRAME_STEP(2)
+	WV_FRAME_STEP(4)
+	WV_FRAME_STEP(8)
+#undef WV_FRAME_STEP
+	if (n > 16) {
+		double Xa[12], Xn[12];
+		UNR for (int e = 0; e < 12; e++) Xa[e] = wv_readlane(X[e], 15);
+		UNR for (int r = 0; r < 3; r++) {
+			UNR for (int cc = 0; cc < 3; cc++) Xn[3 * r + cc] = Xa[3 * r] * X[cc] + Xa[3 * r + 1] * X[3 + cc] + Xa[3 * r + 2] * X[6 + cc];
+			Xn[9 + r] = Xa[9 + r] + Xa[3 * r] * X[9] + Xa[3 * r + 1] * X[10] + Xa[3 * r + 2] * X[11];
 		}
+		UNR for (int e = 0; e < 12; e++) X[e] = (lane & 16) ? Xn[e] : X[e];
 	}
 	WSTAMP(1);
 	// world axis, spatial inertia of body j about the world origin (m, h = m c, Io: xx yy zz xy xz yz)
@@ -189,17 +198,16 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			UNR for (int e = 0; e < 10; e++) Bd[e] = 0.0;
 		}
 	}
-	// composite inertias: log-step suffix sums (plain sums: everything is expressed about the world origin)
-	UNR for (int d = 1; d < 32; d <<= 1) {
-		if (d < n) {
-			if (lane < 32) {
-				UNR for (int e = 0; e < 10; e++) sm.img[10 * j + e] = Bd[e];
-			}
-			wv_sync();
-			if (j + d < 32) {
-				UNR for (int e = 0; e < 10; e++) Bd[e] += sm.img[10 * (j + d) + e];
-			}
-			wv_sync();
+	// composite inertias: log-step suffix sums (plain sums: everything is expressed about the world origin), the same way: row shifts, then the
+	// second row's total (lane 16) on top of the first row
+	UNR for (int e = 0; e < 10; e++) Bd[e] += wv_shl<1>(Bd[e]);
+	UNR for (int e = 0; e < 10; e++) Bd[e] += wv_shl<2>(Bd[e]);
+	UNR for (int e = 0; e < 10; e++) Bd[e] += wv_shl<4>(Bd[e]);
+	UNR for (int e = 0; e < 10; e++) Bd[e] += wv_shl<8>(Bd[e]);
+	if (n > 16) {
+		UNR for (int e = 0; e < 10; e++) {
+			const double up = wv_readlane(Bd[e], 16);
+			Bd[e] += (lane & 16) ? 0.0 : up;
 		}
 	}
 	// motion axis S_j = (w, v) and F_j = Ic_j S_j about the world origin
@@ -246,14 +254,26 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 	// that needs registers: a law depends on the kinematics only (control frame, vw = Jw dq, goals), runs on one lane and carries a
 	// large set of temporaries (sigma projectors, ...) -- here nothing else is live yet.  F_um, F_f wait in LDS as range(P) coordinates.
 	unsigned commit_lo = 0, commit_hi = 0;
+	// goal rows of a motion-force task: 36, one per lane.  The NEXT task's are requested while this task's law runs (one live value); requesting every
+	// task's rows at the start of the kernel was measured and lost (180.5 against 172.7 us per launch: eight live values across the kinematics).
+	double gnext = 0.0;
+	{
+		int u = 0;
+		while (u < P.nt && P.tasks[u].type != TASK_MOTION_FORCE) u++;
+		if (u < P.nt && lane < P.tasks[u].goal_comps) gnext = saip_ldg(P.tasks[u].goal, (size_t)lane * ld + b);
+	}
 	for (int t = 0; t < P.nt; t++) {
 		const TaskDev& tk = P.tasks[t];
 		if (tk.type != TASK_MOTION_FORCE) continue;
 		const bool track = tk.has_ki || P.integ_always;
 		const int k = tk.k, bd = tk.body;
-		// (requesting every task's goal rows at the start of the kernel, so that they travel while the kinematics run, was measured and lost: 180.5 against
-		// 172.7 us per launch, round 4 -- the eight extra live values cost more in the phases in between than the round trip here)
-		for (int e = lane; e < tk.goal_comps; e += 64) sm.goal[e] = saip_ldg(tk.goal, (size_t)e * ld + b);
+		{
+			const double gcur = gnext;
+			int u = t + 1;
+			while (u < P.nt && P.tasks[u].type != TASK_MOTION_FORCE) u++;
+			gnext = (u < P.nt && lane < P.tasks[u].goal_comps) ? saip_ldg(P.tasks[u].goal, (size_t)lane * ld + b) : 0.0;
+			if (lane < tk.goal_comps) sm.goal[lane] = gcur;
+		}
 		double Rb[9], ob[3], pw[3], Rcf[9];
 		UNR for (int e = 0; e < 9; e++) Rb[e] = sm.fr[bd][e];
 		UNR for (int e = 0; e < 3; e++) ob[e] = sm.fr[bd][9 + e];

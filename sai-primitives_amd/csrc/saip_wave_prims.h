@@ -63,6 +63,21 @@ template <int N>
 __device__ __forceinline__ int wv_ror_i(const int x) {
 	return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xF, 0xF, false);
 }
+// value of the lane D places to the left (shr) / right (shl) inside the 16-lane row; lanes without such a neighbour get 0 -- or, with ONE, 1.0 (the
+// diagonal of an identity frame): the high dword keeps its `old` operand 0x3FF00000 where DPP finds no source lane
+template <int D, bool ONE>
+__device__ __forceinline__ double wv_shr(const double x) {
+	const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x110 + D, 0xF, 0xF, true);
+	const int h = ONE ? __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(x), 0x110 + D, 0xF, 0xF, false)
+					  : __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x110 + D, 0xF, 0xF, true);
+	return __hiloint2double(h, l);
+}
+template <int D>
+__device__ __forceinline__ double wv_shl(const double x) {
+	const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x100 + D, 0xF, 0xF, true);
+	const int h = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x100 + D, 0xF, 0xF, true);
+	return __hiloint2double(h, l);
+}
 // sum over the 16 lanes of a row; the pairing is commutative at every step, so all lanes end with bitwise the same value
 __device__ __forceinline__ double wv_rowsum(double x) {
 	x += wv_ror<8>(x);
