@@ -352,6 +352,11 @@ const char* saip_batch_kernel_name(saip_batch*);
 /* HIP-event timing of `steps` back-to-back cycles on the engine stream (after `warmup` untimed ones):
  * total elapsed ms over the timed region.  Used by bench.py for the live roofline figure. */
 saip_status saip_batch_time_steps(saip_batch*, int steps, int warmup, double* elapsed_ms);
+/* the same without a wait inside: _begin records the first event, enqueues `steps` cycles, records the second event and returns; the caller waits
+ * for the device in whatever way it waits anyway (bench.py: the torch.cuda.synchronize() its timing contract prescribes) and then asks _end for the
+ * event time.  One wait instead of two: every runtime wait is its own marker round trip (4 - 15 us), which a 20-step timed region notices. */
+saip_status saip_batch_time_steps_begin(saip_batch*, int steps);
+saip_status saip_batch_time_steps_end(saip_batch*, double* elapsed_ms);
 
 /* ---- multi-GPU (the reference is single-robot / single-thread, /root/reference/src/RobotController.cpp:68-118 has nothing to
  * shard): instances shard embarrassingly across the GPUs of a node, one batch per device, NO data-path collective; the only exchange is the

@@ -198,6 +198,8 @@ def lib():
         "saip_comm_world": (C.c_int, [vp]),
         "saip_comm_rank": (C.c_int, [vp]),
         "saip_batch_all_gather_torques": (C.c_int, [vp, vp, vp]),
+        "saip_batch_time_steps_begin": (C.c_int, [vp, C.c_int]),
+        "saip_batch_time_steps_end": (C.c_int, [vp, dp]),
         "saip_batch_time_steps_gather": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, dp, dp]),
         "saip_multi_time_steps": (C.c_int, [vp, C.c_int, C.c_int, dp, dp]),
         "saip_multi_create": (C.c_int, [vp, C.c_int, ip, C.c_int, C.POINTER(vp)]),

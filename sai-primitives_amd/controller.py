@@ -1052,6 +1052,16 @@ class RobotController:
         capi.check(capi.lib().saip_batch_time_steps(self._h, steps, warmup, C.byref(ms)))
         return ms.value
 
+    def timeStepsBegin(self, steps: int):
+        """enqueue `steps` cycles between two HIP events on the engine stream and return without waiting (saip_batch_time_steps_begin)"""
+        capi.check(capi.lib().saip_batch_time_steps_begin(self._h, int(steps)))
+
+    def timeStepsEnd(self) -> float:
+        """event time (ms) of the cycles timeStepsBegin enqueued; call it behind the caller's own wait for the device"""
+        ms = C.c_double(0)
+        capi.check(capi.lib().saip_batch_time_steps_end(self._h, C.byref(ms)))
+        return ms.value
+
     def timeStepsGather(self, steps: int, comm=None, gathered_ptr=None, every_step: bool = False):
         """(elapsed_ms, gather_ms) of `steps` cycles with the torque all-gather inside the timed region (saip_batch_time_steps_gather): one gather
         behind the last cycle, or one behind every cycle; comm None (one rank) issues no collective"""

@@ -2101,5 +2101,30 @@ extern "C" saip_status saip_batch_time_steps(saip_batch* b, int steps, int warmu
 	return SAIP_OK;
 }
 
+extern "C" saip_status saip_batch_time_steps_begin(saip_batch* b, int steps) {
+	saip_status st = need_ready(b, "saip_batch_time_steps_begin");
+	if (st) return st;
+	if (steps <= 0) return fail(SAIP_ERR_INVALID_ARGUMENT, "bad timing arguments");
+	if (!b->time_ev[0]) {
+		HIP_TRY(hipEventCreate(&b->time_ev[0]));
+		HIP_TRY(hipEventCreate(&b->time_ev[1]));
+	}
+	HIP_TRY(hipEventRecord(b->time_ev[0], b->stream));
+	for (int i = 0; i < steps; i++)
+		if ((st = launch_cycle(b, false))) return st;
+	HIP_TRY(hipEventRecord(b->time_ev[1], b->stream));
+	return SAIP_OK;
+}
+extern "C" saip_status saip_batch_time_steps_end(saip_batch* b, double* elapsed_ms) {
+	saip_status st = need_ready(b, "saip_batch_time_steps_end");
+	if (st) return st;
+	if (!elapsed_ms || !b->time_ev[0]) return fail(SAIP_ERR_ORDER, "saip_batch_time_steps_end: call saip_batch_time_steps_begin first");
+	HIP_TRY(hipEventSynchronize(b->time_ev[1]));  // (returns at once when the caller has waited for the device, as it should have)
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, b->time_ev[0], b->time_ev[1]));
+	*elapsed_ms = ms;
+	return SAIP_OK;
+}
+
 extern "C" const char* saip_last_error(void) { return g_err.c_str(); }
 extern "C" const char* saip_version(void) { return "saip 0.1 (gfx950)"; }

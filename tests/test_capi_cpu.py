@@ -189,3 +189,22 @@ def test_rejected_setter_leaves_the_replay_log_untouched(sp):
         jt.setGains(100.0 + i, 20.0, 0.0)
     assert len(jt._keepalive) <= n0 + 1 and len([e for e in jt._log if "gains" in e[0]]) == 1
     del ctrl
+
+
+def test_xcd_block_remap_is_a_bijection():
+    """csrc/saip_oct_common.h::saip_xcd_block (the wavefront-per-instance kernel takes instance saip_xcd_block(blockIdx, gridDim)): whatever the
+    grid size, every instance is taken exactly once, and the workgroups that share an XCD (equal blockIdx % 8) take one contiguous range.
+    The formula is restated here from the header's text; the -m gpu size tests (B = 1, 3, 65, 4096) exercise the device side."""
+    src = open(os.path.join(ROOT, "sai-primitives_amd", "csrc", "saip_oct_common.h")).read()
+    assert "(x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (orig >> 3)" in src   # the expression below is the header's
+
+    def remap(orig, nwg):
+        q, r, x = nwg >> 3, nwg & 7, orig & 7
+        return (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + (orig >> 3)
+
+    for nwg in (1, 3, 7, 8, 9, 65, 511, 512, 4096, 4099):
+        got = [remap(w, nwg) for w in range(nwg)]
+        assert sorted(got) == list(range(nwg)), nwg
+        for x in range(min(8, nwg)):
+            mine = sorted(remap(w, nwg) for w in range(x, nwg, 8))
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (nwg, x)
