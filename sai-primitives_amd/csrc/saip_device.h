@@ -79,7 +79,10 @@ struct TaskDev {
 	double kp[SAIP_MAXN], kv[SAIP_MAXN], ki[SAIP_MAXN];
 	// velocity saturation, force / moment spaces (open-loop force control): MotionForceTask.cpp:306-383, 416-430, 449-462, 892-971; JointTask.cpp:327-341
 	int general_law;   // 0: defaults (no velocity saturation, force and moment space dimension 0) -> short control-law path
-	int vel_sat, force_dim, moment_dim, param_in_compliant_frame, pad1_[3];
+	int vel_sat, force_dim, moment_dim, param_in_compliant_frame;
+	int law_identity;  // motion force: Bm, Ppos, Pori, sigmaPosition, sigmaOrientation are all EXACTLY the identity and the short control law applies (the
+	                   // full 6-dof task without force / moment space: the reference default) -- set at upload; the wavefront kernel skips the products
+	int pad1_[2];
 	double lin_sat, ang_sat, kv_force, kv_moment;
 	double force_axis[3], moment_axis[3];      // unit axes
 	// closed-loop force / moment control (MotionForceTask.cpp:327-349, 357-378, 484-487), passivity controller off (POPC default)

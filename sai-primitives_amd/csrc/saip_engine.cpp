@@ -1318,6 +1318,16 @@ static saip_status make_params(saip_batch* b, CycleParams& P, bool diag) {
 			TaskDev d = T.dev;
 			d.diag_N = diag ? T.diag_dev : nullptr;
 			if (T.otg_enabled) d.goal = T.desired_dev;  // the law tracks the OTG output (JointTask.cpp:317-319, MotionForceTask.cpp:394-406)
+			d.law_identity = 0;
+			if (d.type == saip::TASK_MOTION_FORCE && d.k == 6 && !d.general_law) {
+				bool id = true;
+				for (int i = 0; i < 36 && id; i++) id = d.Bm[i] == ((i % 7 == 0) ? 1.0 : 0.0);
+				for (int i = 0; i < 9 && id; i++) {
+					const double e = (i % 4 == 0) ? 1.0 : 0.0;
+					id = d.Ppos[i] == e && d.Pori[i] == e && d.sig_p[i] == e && d.sig_o[i] == e;
+				}
+				d.law_identity = id ? 1 : 0;
+			}
 			tmp.push_back(d);
 		}
 		HIP_TRY(hipMemcpyAsync(b->tasks_dev, tmp.data(), tmp.size() * sizeof(TaskDev), hipMemcpyHostToDevice, b->stream));

@@ -322,6 +322,22 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				const double* G = sm.goal;
 				const double* vw = sm.vw;
 				double v[3], w[3], e3[3], tmp[3], oe[3] = {0, 0, 0}, dphi[3];
+				if (tk.law_identity) {
+					// full 6-dof task, no force / moment space (the reference default): the projections and sigma matrices are identities -- none of their
+					// 36 products, none of the 36 scalar loads in front of them (round 4)
+					UNR for (int i = 0; i < 3; i++) e3[i] = pw[i] - G[i];
+					UNR for (int i = 0; i < 3; i++) ip[i] = fma(e3[i], tk.dt, ip[i]);
+					UNR for (int i = 0; i < 3; i++) sm.Fum[i] = G[18 + i] - tk.kp_pos[i] * e3[i] - tk.kv_pos[i] * (vw[i] - G[12 + i]) - tk.ki_pos[i] * ip[i];
+					UNR for (int c = 0; c < 3; c++) {  // orientationError(desired, current) = -1/2 sum_c Rc[:,c] x Rd[:,c]
+						const double a0 = Rcf[c], a1 = Rcf[3 + c], a2 = Rcf[6 + c], b0 = G[3 + c], b1 = G[6 + c], b2 = G[9 + c];
+						oe[0] -= 0.5 * (a1 * b2 - a2 * b1);
+						oe[1] -= 0.5 * (a2 * b0 - a0 * b2);
+						oe[2] -= 0.5 * (a0 * b1 - a1 * b0);
+					}
+					UNR for (int i = 0; i < 3; i++) io[i] = fma(oe[i], tk.dt, io[i]);
+					UNR for (int i = 0; i < 3; i++) sm.Fum[3 + i] = G[21 + i] - tk.kp_ori[i] * oe[i] - tk.kv_ori[i] * (vw[3 + i] - G[15 + i]) - tk.ki_ori[i] * io[i];
+					UNR for (int i = 0; i < 6; i++) sm.Ff[i] = 0.0;
+				} else {
 				UNR for (int i = 0; i < 3; i++) {
 					v[i] = tk.Ppos[3 * i] * vw[0] + tk.Ppos[3 * i + 1] * vw[1] + tk.Ppos[3 * i + 2] * vw[2];
 					w[i] = tk.Pori[3 * i] * vw[3] + tk.Pori[3 * i + 1] * vw[4] + tk.Pori[3 * i + 2] * vw[5];
@@ -341,6 +357,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				UNR for (int i = 0; i < 3; i++) tmp[i] = G[21 + i] - tk.kp_ori[i] * dphi[i] - tk.kv_ori[i] * (w[i] - G[15 + i]) - tk.ki_ori[i] * io[i];
 				UNR for (int i = 0; i < 3; i++) sm.Fum[3 + i] = tk.sig_o[3 * i] * tmp[0] + tk.sig_o[3 * i + 1] * tmp[1] + tk.sig_o[3 * i + 2] * tmp[2];
 				UNR for (int i = 0; i < 6; i++) sm.Ff[i] = 0.0;
+				}
 			}
 			if (ovf) sm.flag2 = 1;
 			if (closed)
@@ -356,7 +373,10 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		wv_sync();
 		if (lane < 8) {  // fhat = Bm^T F_um, ffhat = Bm^T F_f
 			double s1 = 0.0, s2 = 0.0;
-			if (lane < k)
+			if (tk.law_identity) {  // Bm = I: no per-lane loads of its columns
+				s1 = lane < 6 ? sm.Fum[lane < 6 ? lane : 0] : 0.0;
+				s2 = lane < 6 ? sm.Ff[lane < 6 ? lane : 0] : 0.0;
+			} else if (lane < k)
 				for (int i = 0; i < 6; i++) {
 					s1 = fma(tk.Bm[i * 6 + lane], sm.Fum[i], s1);
 					s2 = fma(tk.Bm[i * 6 + lane], sm.Ff[i], s2);
@@ -367,26 +387,27 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		wv_sync();
 	}
 	WSTAMP(2);
-	// ---------------------------------------------------------------- M(q) in stored form: M_ij = S_min(i,j) . F_max(i,j); identity beyond n
+	// ---------------------------------------------------------------- M(q) in stored form: M_ij = S_min(i,j) . F_max(i,j); identity beyond n.
+	// On the matrix cores (round 4): with S = (w, v) and F' = (nO, f) as 6 x n matrices, P = S^T F' holds S_i . F_j in its upper triangle and
+	// P^T = F'^T S the same for the lower one -- two products of depth 6 (16 MFMAs, 8 LDS reads per lane) where every lane used to form 32 dot
+	// products of six from 100 LDS reads.
 	double Minv[8][2];
 	{
-		double Sc[2][6], Fc[2][6];
-		UNR for (int t = 0; t < 2; t++)
-			UNR for (int e = 0; e < 6; e++) {
-				Sc[t][e] = sm.jd[16 * t + lo][e];
-				Fc[t][e] = sm.jd[16 * t + lo][6 + e];
+		double Sst[2][2], Fst[2][2];  // stored forms: row = component 4 ks + hi (6, 7: padding), column = joint 16 t + lo
+		UNR for (int ks = 0; ks < 2; ks++)
+			UNR for (int t = 0; t < 2; t++) {
+				const int c = 4 * ks + hi, cs = c < 6 ? c : 0;
+				Sst[ks][t] = c < 6 ? sm.jd[16 * t + lo][cs] : 0.0;
+				Fst[ks][t] = c < 6 ? sm.jd[16 * t + lo][cs < 3 ? 9 + cs : 3 + cs] : 0.0;  // F' = (nO, f): w . nO + v . f
 			}
+		double Pm[8][2], Pt[8][2];
+		wv_mm<false, false>(Sst, Fst, Pm);  // S_i . F_j
+		wv_mm<false, false>(Fst, Sst, Pt);  // S_j . F_i
 		UNR for (int ks = 0; ks < 8; ks++) {
 			const int i = 4 * ks + hi;
-			double Si[6], Fi[6];
-			UNR for (int e = 0; e < 6; e++) {
-				Si[e] = sm.jd[i][e];
-				Fi[e] = sm.jd[i][6 + e];
-			}
 			UNR for (int t = 0; t < 2; t++) {
 				const int jc = 16 * t + lo;
-				const double d1 = wv_dot6(Si, Fc[t]), d2 = wv_dot6(Sc[t], Fi);
-				double val = (i <= jc) ? d1 : d2;
+				double val = (i <= jc) ? Pm[ks][t] : Pt[ks][t];
 				if (i >= n || jc >= n) val = (i == jc) ? 1.0 : 0.0;
 				Minv[ks][t] = val;
 				if (i == jc) sm.diagM[i] = val;
@@ -471,8 +492,13 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		oct_mat3_vec(Rb, tu.pos, pw);
 		UNR for (int e = 0; e < 3; e++) pw[e] += ob[e];
 		double bm[2][6];
-		UNR for (int ks = 0; ks < 2; ks++)
-			UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi < ku) ? tu.Bm[i * 6 + (4 * ks + hi < 6 ? 4 * ks + hi : 0)] : 0.0;
+		if (tu.law_identity) {  // Bm = I: row a of Jb is row a of the world Jacobian (unit vectors: no loads)
+			UNR for (int ks = 0; ks < 2; ks++)
+				UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi == i) ? 1.0 : 0.0;
+		} else {
+			UNR for (int ks = 0; ks < 2; ks++)
+				UNR for (int i = 0; i < 6; i++) bm[ks][i] = (4 * ks + hi < ku) ? tu.Bm[i * 6 + (4 * ks + hi < 6 ? 4 * ks + hi : 0)] : 0.0;
+		}
 		UNR for (int tt = 0; tt < 2; tt++) {
 			const int jj = 16 * tt + lo;
 			const double* S = sm.jd[jj];
@@ -511,7 +537,11 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			// Jb^T = Jw^T Bm (n x k) in stored form: lane (lo, hi) owns task direction lo of joints 4 ks + hi; column j of
 			// JWorldFrame is (w_j x p + v_j; w_j) for the joints up to the body (MotionForceTask.cpp:262)
 			double bmc[6];
-			UNR for (int i = 0; i < 6; i++) bmc[i] = (lo < k) ? tk.Bm[i * 6 + (lo < 6 ? lo : 0)] : 0.0;
+			if (tk.law_identity) {
+				UNR for (int i = 0; i < 6; i++) bmc[i] = (lo == i) ? 1.0 : 0.0;
+			} else {
+				UNR for (int i = 0; i < 6; i++) bmc[i] = (lo < k) ? tk.Bm[i * 6 + (lo < 6 ? lo : 0)] : 0.0;
+			}
 			double Jbt[8][1];
 			UNR for (int ks = 0; ks < 8; ks++) {
 				const int jj = 4 * ks + hi;
