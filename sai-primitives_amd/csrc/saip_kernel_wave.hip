@@ -439,10 +439,19 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			flagged = true;
 		} else if (nclamp > 0) {
 			myidx = lo < nclamp ? sm.idx[lo] : -1;
-			double Em[8][1], ME[8][1], K4[4][1];
-			UNR for (int ks = 0; ks < 8; ks++) Em[ks][0] = (myidx == 4 * ks + hi) ? 1.0 : 0.0;
-			wv_mm<false, false>(Minv, Em, ME);  // M^-1 E (n x c)
-			wv_mm<false, false>(Em, ME, K4);    // E^T M^-1 E (c x c)
+			// E^T M^-1 E (c x c) is the submatrix of M^-1 on the clamped joints: a gather through the LDS image (free here: N_prec moves in later) instead
+			// of two products with the index matrix (24 MFMAs; round 4)
+			double K4[4][1];
+			UNR for (int ks = 0; ks < 8; ks++)
+				UNR for (int tt = 0; tt < 2; tt++) sm.img[(4 * ks + hi) * LDI + 16 * tt + lo] = Minv[ks][tt];
+			wv_sync();
+			UNR for (int ks = 0; ks < 4; ks++) {
+				const int i = 4 * ks + hi;
+				const bool in = ks < 2 && i < nclamp && lo < nclamp;
+				const int ri = in ? sm.idx[i < 8 ? i : 0] : 0;
+				K4[ks][0] = in ? sm.img[ri * LDI + (myidx >= 0 ? myidx : 0)] : 0.0;
+			}
+			wv_sync();
 			UNR for (int ks = 0; ks < 4; ks++) {
 				const int i = 4 * ks + hi;
 				if (i == lo) {
@@ -452,10 +461,11 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			}
 			Kmat[0][0] = K4[0][0];
 			Kmat[1][0] = K4[1][0];
-			const double mp = wv_sweep<1>(K4, 2, lo, hi);
+			const int nbk = (nclamp + 3) >> 2;  // c <= 4 clamped joints: one pivot block (the identity padding behind it is left alone)
+			const double mp = wv_sweep<1>(K4, nbk, lo, hi);
 			if (!(mp > 0.0)) flagged = true;
 			Kinv[0][0] = -K4[0][0];
-			Kinv[1][0] = -K4[1][0];
+			Kinv[1][0] = nbk > 1 ? -K4[1][0] : K4[1][0];
 		}
 	}
 	WSTAMP(5);
@@ -589,7 +599,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 					if ((i >= k || lo >= k) && i < 8 && lo < 8) val = (i == lo) ? 1.0 : 0.0;
 					Gc[ks][0] = val;
 				}
-				const double mp = wv_sweep<1>(Gc, 2, lo, hi);
+				const double mp = wv_sweep<1, true>(Gc, 2, lo, hi);  // (the pivots are all the certificate wants)
 				certified = wv_uniform((mp > 1e-13) && ok_s0 && (tr > 0.0) && !nonfinite);
 			}
 			// (no branch on the certificate yet: its chain -- three dependent products, a sweep -- and the Lambda chain below are independent; in one
@@ -835,7 +845,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 							if ((i >= nclamp || lo >= nclamp) && i < 8 && lo < 8) val = (i == lo) ? 1.0 : 0.0;
 							Sm4[ks][0] = val;
 						}
-						const double mp = wv_sweep<1>(Sm4, 2, lo, hi);  // -> -(K - Z^T Y^-1 Z)^-1
+						const double mp = wv_sweep<1>(Sm4, (nclamp + 3) >> 2, lo, hi);  // -> -(K - Z^T Y^-1 Z)^-1 (one pivot block for c <= 4)
 						if (!(mp > 0.0)) flagged = true;
 						wv_matvec(Xm, fr8, yu);  // -Y^-1 f, column distribution
 						wv_sync();

@@ -164,7 +164,9 @@ __device__ __forceinline__ void wv_load_rows(const double* x, const int hi, doub
 //   X  -= W P'^T                         T x T MFMAs; P' = P with -I on the pivot's own columns and those columns of X zeroed first, so
 //                                        that the block column comes out as +W exactly (sweep operator: a_ik <- a_ik / a_kk)
 //   v[kb][t] = W_t, diagonal block = -D^-1
-template <int T>
+// PIVOTS_LAST: the caller only wants the pivots (a positive-definiteness certificate): the last block step stops behind its four pivots -- no
+// inverse of that block, no panel, no update (v is then NOT an inverse).
+template <int T, bool PIVOTS_LAST = false>
 __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, const int lo, const int hi) {
 	double minpiv = 1.0e300;
 	bool nanpiv = false;
@@ -200,6 +202,13 @@ __device__ __forceinline__ double wv_sweep(double (&v)[4 * T][T], const int nb, 
 				const double detS = fma(s00, s11, -s10 * s10);
 				const double iS = oct_rcp(detS);
 				const double si00 = s11 * iS, si10 = -s10 * iS, si11 = s00 * iS;
+				if (PIVOTS_LAST && kb == nb - 1) {
+					const double p1 = detA * __builtin_amdgcn_rcp(a00), p3 = detS * __builtin_amdgcn_rcp(s00);
+					minpiv = fmin(fmin(minpiv, a00), fmin(p1, fmin(s00, p3)));
+					const double psum = (a00 + p1) + (s00 + p3);
+					nanpiv = nanpiv || (psum != psum);
+					continue;
+				}
 				const double f00 = fma(si00, e00, si10 * e10), f01 = fma(si00, e01, si10 * e11);
 				const double f10 = fma(si10, e00, si11 * e10), f11 = fma(si10, e01, si11 * e11);
 				Di[0][0] = fma(e00, f00, fma(e10, f10, ai00));
