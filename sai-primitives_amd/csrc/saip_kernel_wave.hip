@@ -50,6 +50,7 @@ struct WaveSmem {
 	double jd[32][12];     // per joint, about the world origin: motion axis S = (w, v), F = Ic S = (f, nO)
 	double fr[32][12];     // world frame of every body: R (row-major), o
 	double q[32], dq[32], tau[32], va[32], vb[32], vc[32], vd[32], act[32], diagM[32];
+	double tg[32];         // jointGravityVector entry of every joint (gravity compensation): parked here from the inertia phase to the epilogue
 	double goal[96];
 	double vw[8], Fum[8], Ff[8], xp[4], Rc[12];
 	double f8[SAIP_MAXT][8], ff8[SAIP_MAXT][8], g8[16];  // per motion-force task: B^T F_um, B^T F_f (range(P) coordinates); g = Lambda_mod fhat + ffhat
@@ -247,6 +248,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			} else {
 				tg = -m * (z[0] * g[0] + z[1] * g[1] + z[2] * g[2]);
 			}
+			if (lane < 32) sm.tg[j] = tg;
 		}
 	}
 	wv_sync();
@@ -705,8 +707,8 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 				if (j < m) {
 					double cur = 0.0, vel = 0.0, sw = 0.0;
 					if (tk.s_identity) {
-						cur = qj;
-						vel = dqj;
+						cur = sm.q[j];  // (from LDS, not the registers of the kernel's first lines: those would live across the whole task loop)
+						vel = sm.dq[j];
 						sw = sm.vd[j];
 					} else {
 						for (int jj = 0; jj < n; jj++) {
@@ -1123,7 +1125,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 		// tau = JLA.computeTorques(tau) + N_constraints^T tau,  N_constraints^T = I - S^T (S M^-1 S^T)^-1 S M^-1 (padded to n x n)
 		bool actj = false;
 		double jl = 0.0;
-		if (jv) jl = jla_joint(qj, dqj, md.q_lower[j], md.q_upper[j], md.vel_limit[j], md.effort[j], tv, &actj);
+		if (jv) jl = jla_joint(sm.q[j], sm.dq[j], md.q_lower[j], md.q_upper[j], md.vel_limit[j], md.effort[j], tv, &actj);
 		const unsigned long long am = __ballot(actj && lane < 32);
 		wv_sync();
 		if (lane < 32) {
@@ -1159,7 +1161,7 @@ __global__ void __launch_bounds__(64, SAIP_WAVE_OCC) saip_cycle_wave(const Cycle
 			}
 		}
 	}
-	if (P.gravity_comp) tv += tg;
+	if (P.gravity_comp) tv += sm.tg[j];
 	// a flagged instance holds its last valid torques (or gets them from the general kernel launched behind) unless NaN was asked for
 	if (lane < 32 && jv) {
 		if (!flagged) P.tau[(size_t)j * ld + b] = tv;
