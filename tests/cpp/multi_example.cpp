@@ -106,6 +106,37 @@ int main(int argc, char** argv) {
 	std::ofstream o(argv[5], std::ios::binary);
 	o.write((const char*)first.data(), first.size() * sizeof(double));
 	o.write((const char*)last.data(), last.size() * sizeof(double));
+	// round 4: the timed forms -- K cycles between HIP events on every device's stream with the grouped all-gather behind the last cycle (mode 0)
+	// or behind every cycle (mode 1); with one device no collective is issued and the gather time is 0.  The torques must come out the same.
+	for (int mode = 0; mode < 2; mode++) {
+		double ms = -1.0, gms = -1.0;
+		OK(saip_multi_time_steps(m, 10, mode, &ms, &gms));
+		if (!(ms > 0.0) || !(gms >= 0.0) || (n == 1 && gms != 0.0)) {
+			std::cerr << "saip_multi_time_steps: implausible times " << ms << " / " << gms << std::endl;
+			return 1;
+		}
+		std::cout << "MULTI_TIMED mode " << mode << " ms " << ms << " gather_ms " << gms << std::endl;
+	}
+	if (n > 1) OK(saip_multi_all_gather_torques(m));
+	std::vector<double> again((size_t)n * dof * B);
+	if (n > 1) {
+		OK(saip_multi_get_gathered_host(m, 0, again.data()));
+		if (memcmp(again.data(), first.data(), again.size() * sizeof(double)) != 0) {
+			std::cerr << "torques changed between the plain and the timed steps" << std::endl;
+			return 1;
+		}
+	}
+	{   // the one-process-per-GPU form without a communicator (one rank): begin / end and the gather-timed entry point
+		saip_batch* b0 = saip_multi_batch(m, 0);
+		double ms = -1.0, gms = -1.0;
+		OK(saip_batch_time_steps_begin(b0, 10));
+		OK(saip_batch_synchronize(b0));
+		OK(saip_batch_time_steps_end(b0, &ms));
+		if (!(ms > 0.0)) return 1;
+		OK(saip_batch_time_steps_gather(b0, nullptr, nullptr, 10, 1, &ms, &gms));
+		if (!(ms > 0.0) || gms != 0.0) return 1;
+		if (saip_batch_time_steps_gather(b0, nullptr, nullptr, 0, 0, &ms, &gms) == SAIP_OK) return 1;  // bad arguments are refused
+	}
 	saip_multi_destroy(m);
 	saip_model_destroy(model);
 	std::cout << "MULTI_OK" << std::endl;

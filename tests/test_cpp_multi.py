@@ -47,6 +47,7 @@ def test_cpp_multi_device_shards_and_rccl_gather(tmp_path, n_req):
     np.ascontiguousarray(blob).tofile(inp)
     out = subprocess.run([exe, robot, str(B), str(n_req), str(inp), str(outp)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "MULTI_OK" in out.stdout, out.stdout + out.stderr
+    assert out.stdout.count("MULTI_TIMED") == 2     # saip_multi_time_steps in both gather modes (round 4)
     n = int(out.stdout.split("MULTI_DEVICES")[1].split()[0])
     print(out.stdout)
     first, last = np.fromfile(outp).reshape(2, n, 7, B)
