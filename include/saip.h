@@ -257,6 +257,13 @@ saip_status saip_batch_enable_torque_saturation(saip_batch*, int enabled);
 /* torques of an instance that ends a cycle flagged (status 1): 0 (default) = not written, i.e. the last valid torques of that instance are
  * held (zero before the first valid cycle); 1 = NaN.  The reference has no such state: it never refuses an instance. */
 saip_status saip_batch_set_flagged_torque_policy(saip_batch*, int nan);
+/* where the eight-lane kernels recompute the instances they cannot finish themselves (a task outside SingularityHandler's non-singular branch,
+ * SingularityHandler.cpp:100-121, 146-158, 310-367): 0 (default) = in the kernel, by the wavefront that met them, right behind its epilogue -- no
+ * second launch; costs nothing when there are none and ~70 us per instance and wavefront when there are, one after the other; 1 = on a device-side
+ * list that a second launch behind every cycle spreads over the chip (+4.5 us per cycle, always) -- faster when MANY instances of one group of
+ * eight are singular at once (measured, config 3's stack, 4096 instances: 1/8 of the batch packed into whole groups: 96 against 271 us per cycle;
+ * spread evenly: 89 against 86).  Same results either way. */
+saip_status saip_batch_set_flagged_recompute(saip_batch*, int on_list);
 /* integrator state policy: 0 = advance the integral terms only while the task's ki != 0 (default; elides the
  * state traffic), 1 = advance every cycle like the reference does (MotionForceTask.cpp:411-413,446; JointTask.cpp:323) */
 saip_status saip_batch_set_integrator_tracking(saip_batch*, int always);

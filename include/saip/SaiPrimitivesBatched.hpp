@@ -575,6 +575,7 @@ public:
 	void enableTorqueSaturation(bool e) { check(saip_batch_enable_torque_saturation(_batch, e)); }
 	// torques of instances that end a cycle flagged (status 1): false (default) = the last valid torques are held, true = NaN
 	void setFlaggedTorquePolicy(bool nan) { check(saip_batch_set_flagged_torque_policy(_batch, nan ? 1 : 0)); }
+	void setFlaggedRecompute(bool on_list) { check(saip_batch_set_flagged_recompute(_batch, on_list ? 1 : 0)); }
 	void reinitializeTasks() {
 		pushState();
 		check(saip_batch_reinitialize_tasks(_batch));

@@ -160,6 +160,7 @@ def lib():
         "saip_batch_enable_torque_saturation": (C.c_int, [vp, C.c_int]),
         "saip_batch_set_integrator_tracking": (C.c_int, [vp, C.c_int]),
         "saip_batch_set_flagged_torque_policy": (C.c_int, [vp, C.c_int]),
+        "saip_batch_set_flagged_recompute": (C.c_int, [vp, C.c_int]),
         "saip_batch_set_state_host": (C.c_int, [vp, dp, dp]),
         "saip_batch_set_goal_host": (C.c_int, [vp, C.c_int, dp]),
         "saip_batch_set_goal_field_host": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp]),

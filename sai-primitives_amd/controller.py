@@ -978,6 +978,11 @@ class RobotController:
         """torques of instances that end a cycle flagged (status 1): False (default) = the last valid torques are held, True = NaN"""
         self._call("saip_batch_set_flagged_torque_policy", int(bool(nan)))
 
+    def setFlaggedRecompute(self, on_list: bool):
+        """where the eight-lane kernels recompute instances outside the non-singular branch: False (default) = in the kernel's slow tail, True = on the
+        device-side list behind every cycle (saip_batch_set_flagged_recompute: faster when many instances of one group are singular at once)"""
+        self._call("saip_batch_set_flagged_recompute", int(bool(on_list)))
+
     def setIntegratorTracking(self, always: bool):
         self._call("saip_batch_set_integrator_tracking", int(always))
 

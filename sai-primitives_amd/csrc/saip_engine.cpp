@@ -378,6 +378,7 @@ struct saip_batch {
 	hipEvent_t sync_event = nullptr;         // saip_batch_wait_for
 	hipEvent_t time_ev[2] = {nullptr, nullptr};  // saip_batch_time_steps (created once: event creation is not part of a timed region)
 	bool flag_nan = false;                   // saip_batch_set_flagged_torque_policy
+	bool flagged_on_list = false;            // saip_batch_set_flagged_recompute: eight-lane kernels hand flagged instances to the list launch instead of their slow tail
 	int* flag_buf = nullptr;                 // [2 * (32 + ld)]: two { count, list } pairs of the device-side slow path, used alternately (CycleParams::flag_*)
 	unsigned flag_parity = 0;                // advanced only by a launch that hands the pair to a kernel
 	bool flag_clean[2] = {true, true};       // whether each pair's count is known to be zero (the buffer is zeroed at allocation)
@@ -1182,6 +1183,11 @@ extern "C" saip_status saip_batch_set_flagged_torque_policy(saip_batch* b, int n
 	b->flag_nan = nan != 0;
 	return SAIP_OK;
 }
+extern "C" saip_status saip_batch_set_flagged_recompute(saip_batch* b, int on_list) {
+	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
+	b->flagged_on_list = on_list != 0;
+	return SAIP_OK;
+}
 extern "C" saip_status saip_batch_set_integrator_tracking(saip_batch* b, int always) {
 	if (!b) return fail(SAIP_ERR_INVALID_ARGUMENT, "null batch");
 	b->integ_always = always != 0;
@@ -1608,7 +1614,7 @@ static saip_status launch_cycle(saip_batch* b, bool diag) {
 		// its own LDS block) -- no list and no second launch behind the kernel (round 4; SAIP_NO_SLOW_TAIL=1 restores the list launch for A/B runs)
 		static const bool tail_on = getenv("SAIP_NO_SLOW_TAIL") == nullptr;
 		P.slow_tail = 0;
-		if (slow && tail_on && ((oct && P.oct_general_joint != 0) || octjf)) {
+		if (slow && tail_on && !b->flagged_on_list && ((oct && P.oct_general_joint != 0) || octjf)) {
 			slow = false;
 			P.slow_tail = 1;
 			P.flag_count = P.flag_count_next = P.flag_list = nullptr;

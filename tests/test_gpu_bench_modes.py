@@ -68,3 +68,30 @@ def test_time_steps_entry_points_agree():
     assert np.isfinite(tau).all() and (ctrl.status & 1).sum() == 0
     with pytest.raises(Exception):
         capi.check(capi.lib().saip_batch_time_steps_gather(ctrl._h, None, None, 0, 0, C.byref(C.c_double()), C.byref(C.c_double())))
+
+
+def test_flagged_instances_in_the_kernel_tail_or_on_the_list_give_the_same_torques():
+    """saip_batch_set_flagged_recompute: config 3's stack with an eighth of the batch near the elbow singularity, packed into whole groups of eight
+    (the slow tail's worst case) -- the in-kernel tail and the list launch must agree bit for bit, and with the oracle"""
+    from oracle import Oracle
+    from sai_primitives_amd.controller import controller_from_specs
+    B = 512
+    d = W.make_inputs(3, B)
+    q = d["q"].copy()
+    q[:64, 3] = -0.07 - 0.2 * np.random.default_rng(3).uniform(size=64)
+    out = []
+    for on_list in (False, True):
+        robot, ctrl, _ = controller_from_specs(d["model"].name, d["tasks"], B, device=0)
+        ctrl.setFlaggedRecompute(on_list)
+        robot.setQ(q)
+        robot.setDq(d["dq"])
+        robot.updateModel()
+        ctrl.updateControllerTaskModels()
+        ctrl.setGoals(d["goals"])
+        out.append((ctrl.computeControlTorques(), ctrl.status.copy(), ctrl.kernelName()))
+    assert out[0][2] == out[1][2] == "saip_cycle_oct"
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    ref, st = Oracle(d["model"], d["tasks"]).step(q, d["dq"], d["goals"], nthreads=8)
+    assert np.array_equal(out[0][1] & 9, st & 9) and (st & 8).sum() > 0
+    ok = (st & 1) == 0
+    assert W.torque_error(out[0][0][ok], ref[ok]) < 1e-5
