@@ -113,6 +113,35 @@ def test_config4_shard_size_and_lean_variant():
         assert W.torque_error(tau2[:4096], ref[:4096]) < TOL and W.torque_error(tau2[-4096:], ref[:4096]) < TOL
 
 
+def test_config4_whole_batch_equals_its_eight_shards():
+    """BASELINE config 4 at its FULL size on one GPU: 65536 instances in one batch, and the same stream as the eight 8192-instance shards a
+    node would run (make_inputs(shard=r) = rank r's block).  Size-independent property of the sharded path: an instance's torque does not
+    depend on which shard (or batch size, or kernel: the whole batch runs the lane kernel, a shard the eight-lane kernel) computed it;
+    the concatenation of the shards is what the final all-gather delivers.  Plus the oracle on a random sample of the whole batch."""
+    from oracle import Oracle
+    world, per = 8, 8192
+    d = W.make_inputs(4, world * per)
+    robot, ctrl, _ = _engine(d["model"].name, d["tasks"], world * per)
+    tau = _run(robot, ctrl, d["q"], d["dq"], d["goals"])
+    assert ctrl.status.sum() == 0 and np.isfinite(tau).all()
+    whole_kernel = ctrl.kernelName()
+    del robot, ctrl
+    worst = 0.0
+    for r in range(world):
+        ds = W.make_inputs(4, per, shard=r)
+        assert np.array_equal(ds["q"], d["q"][r * per:(r + 1) * per])          # rank r's block of the seeded stream
+        rb, cs, _ = _engine(ds["model"].name, ds["tasks"], per)
+        ts = _run(rb, cs, ds["q"], ds["dq"], ds["goals"])
+        assert cs.status.sum() == 0 and cs.kernelName() == "saip_cycle_oct"
+        worst = max(worst, W.torque_error(ts, tau[r * per:(r + 1) * per]))
+        del rb, cs
+    print("config 4: whole batch on", whole_kernel, "vs eight shards on saip_cycle_oct: max rel difference", worst)
+    assert worst < 1e-9
+    idx = np.random.default_rng(4).choice(world * per, 2048, replace=False)
+    ref, st = Oracle(d["model"], d["tasks"]).step(d["q"][idx], d["dq"][idx], [g[idx] for g in d["goals"]], nthreads=8)
+    assert st.sum() == 0 and W.torque_error(tau[idx], ref) < TOL
+
+
 def test_general_kernel_explicitly_selected():
     from oracle import Oracle
     d = W.make_inputs(2, 512)
